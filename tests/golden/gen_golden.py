@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference; the GPU box has neither
+the reference nor a need for this script -- it reads the committed .npz files):
+
+    cd /tmp && PYTHONPATH=/root/reference MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 \
+        python3 /root/repo/tests/golden/gen_golden.py
+
+The fixtures are DATA: inputs (architecture, weights, x, y, sigma, seeds, RNG
+draws) and the outputs the reference produced for them.  Groups follow SURVEY.md
+section 8c (G1..G8).  Versions at generation time are stored in each file.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("QUINN_REFERENCE", "/root/reference")
+if REF not in sys.path:
+    sys.path.insert(0, REF)
+os.environ.setdefault("MPLBACKEND", "Agg")
+os.chdir(tempfile.mkdtemp(prefix="quinn_golden_"))      # nnfit drops PNGs into the CWD
+
+from quinn.nns.mlp import MLP                            # noqa: E402
+from quinn.nns.nnwrap import NNWrap, nn_p                # noqa: E402
+from quinn.solvers.nn_mcmc import NN_MCMC                # noqa: E402
+from quinn.solvers.nn_vi import NN_VI                    # noqa: E402
+from quinn.solvers.nn_ens import NN_Ens                  # noqa: E402
+from quinn.mcmc.admcmc import AMCMC                      # noqa: E402
+from quinn.mcmc.hmc import HMC                           # noqa: E402
+from quinn.mcmc.mala import MALA                         # noqa: E402
+from quinn.vi.bnet import BNet                           # noqa: E402
+
+VERS = np.array([torch.__version__, np.__version__])
+
+
+def data(N, d, o, noise, seed):
+    rs = np.random.RandomState(seed)
+    x = (rs.rand(N, d) * 2 - 1) * np.pi
+    y = np.stack([np.sum(np.sin((k + 1) * x), axis=1) for k in range(o)], axis=1) + noise * rs.randn(N, o)
+    return x, y
+
+
+def save(name, **kw):
+    np.savez_compressed(os.path.join(OUT, name), versions=VERS, **kw)
+    print("wrote", name, {k: np.asarray(v).shape for k, v in kw.items()})
+
+
+# ---------------------------------------------------------------- G1: logpost / grad
+def g1():
+    cases = [(1, 1, (16, 16), "tanh", 64), (1, 1, (64, 64, 64), "tanh", 48),
+             (2, 1, (8, 8), "relu", 40), (2, 2, (8,), "tanh", 33), (3, 2, (5, 7), "identity", 20)]
+    for ci, (d, o, hls, act, N) in enumerate(cases):
+        net = MLP(d, o, hls, activ=act)
+        solver = NN_MCMC(net, verbose=False)
+        p = solver.pdim
+        x, y = data(N, d, o, 0.05, 10 + ci)
+        sigma = 0.3
+        lpinfo = {"model": nn_p, "xd": x, "yd": [yy for yy in y], "ltype": "classical",
+                  "lparams": {"sigma": sigma}}
+        rs = np.random.RandomState(100 + ci)
+        W = 0.4 * rs.randn(8, p)
+        lp = np.array([solver.logpost(w, lpinfo) for w in W])
+        gr = np.array([solver.logpostgrad(w, lpinfo) for w in W])
+        pred = np.array([nn_p(w, x, solver.nnmodel) for w in W])
+        save(f"g1_logpost_{ci}.npz", dims=np.array((d,) + tuple(hls) + (o,)), activ=np.array(act),
+             x=x, y=y, sigma=sigma, W=W, logpost=lp, grad=gr, pred=pred)
+
+
+# ---------------------------------------------------------------- G2/G3/G8: chains
+def _solver(d, o, hls, act, N, seed, sigma):
+    net = MLP(d, o, hls, activ=act)
+    solver = NN_MCMC(net, verbose=False)
+    x, y = data(N, d, o, 0.05, seed)
+    return solver, x, y
+
+
+def _record_uniforms():
+    """Wrap np.random.random_sample to capture the accept-test uniforms."""
+    drawn = []
+    orig = np.random.random_sample
+
+    def wrapped(*a, **k):
+        u = orig(*a, **k)
+        drawn.append(u)
+        return u
+    np.random.random_sample = wrapped
+    return drawn, orig
+
+
+def run_fit(solver, x, y, sigma, nmcmc, sampler, sp, seed):
+    np.random.seed(seed)
+    drawn, orig = _record_uniforms()
+    try:
+        solver.fit(x, y, zflag=False, datanoise=sigma, nmcmc=nmcmc, sampler=sampler, sampler_params=dict(sp))
+    finally:
+        np.random.random_sample = orig
+    return np.array(drawn)
+
+
+def g2_g3_g8():
+    d, o, hls, act, N, sigma = 1, 1, (8, 8), "tanh", 32, 0.2
+    # G2 adaptive Metropolis, adaptation fires (t0 / tadapt small)
+    for gi, (gamma, nmcmc, seed) in enumerate([(0.1, 400, 7), (0.01, 400, 8)]):
+        solver, x, y = _solver(d, o, hls, act, N, 20, sigma)
+        sp = {"gamma": gamma, "t0": 20, "tadapt": 50}
+        u = run_fit(solver, x, y, sigma, nmcmc, "amcmc", sp, seed)
+        # re-run through the sampler class directly to get the full result dict
+        np.random.seed(seed)
+        ini = np.random.rand(solver.pdim)
+        mc = AMCMC(**sp)
+        mc.setLogPost(solver.logpost, None, lpinfo=solver.lpinfo)
+        res = mc.run(param_ini=ini, nmcmc=nmcmc)
+        assert np.array_equal(res["chain"], solver.samples)
+        save(f"g2_amcmc_{gi}.npz", dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y,
+             sigma=sigma, seed=seed, nmcmc=nmcmc, gamma=gamma, t0=20, tadapt=50,
+             chain=res["chain"], logpost=res["logpost"], alphas=res["alphas"], accrate=res["accrate"],
+             mapparams=res["mapparams"], maxpost=res["maxpost"], uniforms=u)
+    # cfg1-shaped short chain (2x16, N=256), default t0/tadapt -> no adaptation inside 60 steps
+    solver, x, y = _solver(1, 1, (16, 16), "tanh", 256, 21, 0.02)
+    np.random.seed(3)
+    ini = np.random.rand(solver.pdim)
+    mc = AMCMC(gamma=0.01)
+    solver.lpinfo = {"model": nn_p, "xd": x, "yd": [yy for yy in y], "ltype": "classical",
+                     "lparams": {"sigma": 0.1}}
+    mc.setLogPost(solver.logpost, None, lpinfo=solver.lpinfo)
+    res = mc.run(param_ini=ini, nmcmc=60)
+    save("g2_amcmc_cfg1.npz", dims=np.array((1, 16, 16, 1)), activ=np.array("tanh"), x=x, y=y, sigma=0.1,
+         seed=3, nmcmc=60, gamma=0.01, t0=100, tadapt=1000, chain=res["chain"], logpost=res["logpost"],
+         alphas=res["alphas"], accrate=res["accrate"], mapparams=res["mapparams"], maxpost=res["maxpost"])
+    # G3 HMC (through NN_MCMC.fit) and MALA (standalone: unreachable via fit in the reference)
+    for gi, (L, eps, nmcmc, seed) in enumerate([(3, 0.002, 120, 11), (10, 0.001, 60, 12)]):
+        solver, x, y = _solver(d, o, hls, act, N, 22, sigma)
+        np.random.seed(seed)
+        ini = np.random.rand(solver.pdim)
+        solver.lpinfo = {"model": nn_p, "xd": x, "yd": [yy for yy in y], "ltype": "classical",
+                         "lparams": {"sigma": sigma}}
+        mc = HMC(epsilon=eps, L=L)
+        mc.setLogPost(solver.logpost, solver.logpostgrad, lpinfo=solver.lpinfo)
+        res = mc.run(param_ini=ini, nmcmc=nmcmc)
+        save(f"g3_hmc_{gi}.npz", dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y,
+             sigma=sigma, seed=seed, nmcmc=nmcmc, L=L, epsilon=eps, chain=res["chain"],
+             logpost=res["logpost"], alphas=res["alphas"], accrate=res["accrate"],
+             mapparams=res["mapparams"], maxpost=res["maxpost"])
+    solver, x, y = _solver(d, o, hls, act, N, 23, sigma)
+    np.random.seed(13)
+    ini = np.random.rand(solver.pdim)
+    solver.lpinfo = {"model": nn_p, "xd": x, "yd": [yy for yy in y], "ltype": "classical",
+                     "lparams": {"sigma": sigma}}
+    mc = MALA(epsilon=0.002)
+    mc.setLogPost(solver.logpost, solver.logpostgrad, lpinfo=solver.lpinfo)
+    res = mc.run(param_ini=ini, nmcmc=100)
+    save("g3_mala.npz", dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y, sigma=sigma,
+         seed=13, nmcmc=100, epsilon=0.002, chain=res["chain"], logpost=res["logpost"],
+         alphas=res["alphas"], accrate=res["accrate"], mapparams=res["mapparams"], maxpost=res["maxpost"])
+    # G8 multi-chain definition: C sequential fits, chain c preceded by np.random.seed(seed0 + c)
+    C, seed0, nmcmc = 4, 40, 150
+    chains, lps, als, accs, maps = [], [], [], [], []
+    solver, x, y = _solver(d, o, hls, act, N, 24, sigma)
+    for c in range(C):
+        np.random.seed(seed0 + c)
+        ini = np.random.rand(solver.pdim)
+        mc = AMCMC(gamma=0.05, t0=30, tadapt=40)
+        solver.lpinfo = {"model": nn_p, "xd": x, "yd": [yy for yy in y], "ltype": "classical",
+                         "lparams": {"sigma": sigma}}
+        mc.setLogPost(solver.logpost, None, lpinfo=solver.lpinfo)
+        res = mc.run(param_ini=ini, nmcmc=nmcmc)
+        chains.append(res["chain"]); lps.append(res["logpost"]); als.append(res["alphas"])
+        accs.append(res["accrate"]); maps.append(res["mapparams"])
+    save("g8_multichain.npz", dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y, sigma=sigma,
+         seed0=seed0, nchains=C, nmcmc=nmcmc, gamma=0.05, t0=30, tadapt=40, chain=np.array(chains),
+         logpost=np.array(lps), alphas=np.array(als), accrate=np.array(accs), mapparams=np.array(maps))
+    # G7 prediction from a chain: predict_ens thinning + predict_mom_sample(msc=2)
+    solver.samples = chains[0]
+    solver.cmode = maps[0]
+    xg = np.linspace(-3, 3, 17)[:, None]
+    yens = solver.predict_ens(xg, nens=10, nburn=50)
+    solver.nens = 10
+    import functools
+    solver.predict_ens = functools.partial(solver.predict_ens, nburn=50)
+    ymean, yvar, ycov = solver.predict_mom_sample(xg, msc=2, nsam=10)
+    save("g7_predict.npz", dims=np.array((d,) + hls + (o,)), activ=np.array(act), chain=chains[0], xg=xg,
+         nens=10, nburn=50, yens=yens, ymean=ymean, yvar=yvar, ycov=ycov, ymap=solver.predict_MAP(xg))
+
+
+# ---------------------------------------------------------------- G4/G5: VI
+def _bnet_flat(bm):
+    mus = [p.detach().flatten().numpy() for n, p in bm.named_parameters() if n.endswith("_mu")]
+    rhos = [p.detach().flatten().numpy() for n, p in bm.named_parameters() if n.endswith("_rho")]
+    return np.concatenate(mus), np.concatenate(rhos)
+
+
+def _bnet_grads(bm):
+    gm = [p.grad.detach().flatten().numpy() for n, p in bm.named_parameters() if n.endswith("_mu")]
+    gr = [p.grad.detach().flatten().numpy() for n, p in bm.named_parameters() if n.endswith("_rho")]
+    return np.concatenate(gm), np.concatenate(gr)
+
+
+def _record_normals():
+    drawn = []
+    orig = torch.distributions.Normal.sample
+
+    def wrapped(self, sample_shape=torch.Size()):
+        z = orig(self, sample_shape)
+        drawn.append(z.detach().flatten().numpy().copy())
+        return z
+    torch.distributions.Normal.sample = wrapped
+    return drawn, orig
+
+
+def g4_g5():
+    for ci, (d, o, hls, act, N, S, prior) in enumerate([
+            (1, 1, (8, 8), "tanh", 24, 1, (0.5, 1.0, 1.0)),
+            (2, 1, (16, 16, 16), "tanh", 40, 3, (0.5, 1.0, 1.0)),
+            (2, 2, (8,), "relu", 30, 8, (0.3, 0.5, 2.0))]):
+        torch.manual_seed(50 + ci)
+        net = MLP(d, o, hls, activ=act)
+        x, y = data(N, d, o, 0.05, 30 + ci)
+        bm = BNet(net, pi=prior[0], sigma1=prior[1], sigma2=prior[2])
+        mu, rho = _bnet_flat(bm)
+        datanoise, nb = 0.1, 3
+        bm.loss_params = [datanoise, S, nb]
+        drawn, orig = _record_normals()
+        try:
+            xt, yt = torch.tensor(x), torch.tensor(y)
+            lp, lq, nll = bm.sample_elbo(xt, yt, S, likparams=[datanoise])
+            n_first = len(drawn)
+            loss = bm.viloss(xt, yt)
+        finally:
+            torch.distributions.Normal.sample = orig
+        loss.backward()
+        dmu, drho = _bnet_grads(bm)
+        eps_elbo = np.concatenate(drawn[:n_first]).reshape(S, -1)
+        eps_loss = np.concatenate(drawn[n_first:]).reshape(S, -1)
+        save(f"g4_viloss_{ci}.npz", dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y,
+             mu=mu, rho=rho, nsam=S, datanoise=datanoise, num_batches=nb, prior=np.array(prior),
+             eps_elbo=eps_elbo, elbo_log_prior=lp.item(), elbo_log_q=lq.item(), elbo_nll=nll.item(),
+             eps_loss=eps_loss, loss=loss.item(), dmu=dmu, drho=drho, torch_seed=50 + ci)
+    # G5 NN_VI.fit, 20 epochs, minibatches
+    d, o, hls, act, N = 1, 1, (8, 8), "tanh", 24
+    torch.manual_seed(60)
+    net = MLP(d, o, hls, activ=act)
+    w_net = NNWrap(net).p_flatten().detach().numpy().flatten()
+    x, y = data(N, d, o, 0.05, 33)
+    xv, yv = data(9, d, o, 0.05, 34)
+    vi = NN_VI(net, verbose=False)
+    mu0, rho0 = _bnet_flat(vi.bmodel)
+    gen_state = torch.get_rng_state().numpy().copy()
+    vi.fit(x, y, val=[xv, yv], datanoise=0.1, lrate=0.01, batch_size=10, nsam=2, nepochs=20, freq_out=1000)
+    mu1, rho1 = _bnet_flat(vi.bmodel)
+    mub, rhob = _bnet_flat(vi.best_model)
+    # history lives only inside nnfit's return; rerun identically through nnfit to capture it
+    from quinn.nns.nnfit import nnfit
+    torch.manual_seed(60)
+    net2 = MLP(d, o, hls, activ=act)
+    vi2 = NN_VI(net2, verbose=False)
+    vi2.bmodel.loss_params = [0.1, 2, (N + 1) // 10]
+    info = nnfit(vi2.bmodel, x, y, val=[xv, yv], loss_xy=vi2.bmodel.viloss, lrate=0.01, batch_size=10,
+                 nepochs=20, freq_out=1000)
+    mu2, rho2 = _bnet_flat(vi2.bmodel)
+    assert np.array_equal(mu1, mu2) and np.array_equal(rho1, rho2)
+    save("g5_vifit.npz", dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y, xval=xv, yval=yv,
+         mu0=mu0, rho0=rho0, gen_state=gen_state, datanoise=0.1, lrate=0.01, batch_size=10, nsam=2,
+         nepochs=20, mu_final=mu1, rho_final=rho1, mu_best=mub, rho_best=rhob,
+         history=np.array(info["history"]), best_loss=info["best_loss"], best_epoch=info["best_epoch"],
+         torch_seed=60, w_net=w_net)
+
+
+# ---------------------------------------------------------------- G6: deep ensemble
+def g6():
+    d, o, hls, act, N = 1, 1, (8, 8), "tanh", 30
+    torch.manual_seed(70)
+    net = MLP(d, o, hls, activ=act)
+    w0 = NNWrap(net).p_flatten().detach().numpy().flatten()
+    x, y = data(N, d, o, 0.05, 35)
+    xv, yv = data(8, d, o, 0.05, 36)
+    M = 3
+    ens = NN_Ens(net, nens=M, dfrac=0.8, verbose=False)
+    np.random.seed(71)
+    torch.manual_seed(72)
+    ens.fit(x, y, val=[xv, yv], lrate=0.01, batch_size=8, nepochs=20, freq_out=1000)
+    hist = np.array([np.array(l.nnmodel.history) for l in ens.learners])
+    best = np.array([NNWrap(l.best_model).p_flatten().detach().numpy().flatten() for l in ens.learners])
+    final = np.array([np.concatenate([p.detach().flatten().numpy() for p in l.nnmodel.nnmodel.parameters()])
+                      for l in ens.learners])
+    xg = np.linspace(-3, 3, 11)[:, None]
+    np.random.seed(73)
+    yens = ens.predict_ens(xg)
+    save("g6_ens.npz", dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y, xval=xv, yval=yv,
+         w0=w0, nens=M, dfrac=0.8, lrate=0.01, batch_size=8, nepochs=20, np_seed=71, torch_seed=72,
+         history=hist, best=best, final=final, xg=xg, predict_seed=73, yens=yens)
+    # full-batch, dfrac=1: all members identical (shared deepcopy) -- a property the build must keep
+    ens2 = NN_Ens(net, nens=2, dfrac=1.0, verbose=False)
+    np.random.seed(74); torch.manual_seed(75)
+    ens2.fit(x, y, lrate=0.05, nepochs=15, freq_out=1000)
+    best2 = np.array([NNWrap(l.best_model).p_flatten().detach().numpy().flatten() for l in ens2.learners])
+    hist2 = np.array([np.array(l.nnmodel.history) for l in ens2.learners])
+    save("g6_ens_fullbatch.npz", dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y, w0=w0,
+         nens=2, lrate=0.05, nepochs=15, np_seed=74, torch_seed=75, best=best2, history=hist2)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "chains", "vi", "ens"]
+    if "g1" in which:
+        g1()
+    if "chains" in which:
+        g2_g3_g8()
+    if "vi" in which:
+        g4_g5()
+    if "ens" in which:
+        g6()
