@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Headline benchmark: log-posterior evals/sec, 64 chains x (3x64 tanh MLP) x N=4096 per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f64|f32] [--kind logpost|grad]
+
+One *step* = one lock-step evaluation of the log-posterior of all 64 chains' proposals on this
+GPU (64 evals; `--kind grad`: log-posterior + parameter gradient, the HMC inner step), through
+the C ABI, with weights / dataset resident in HBM.  Successive steps use different weight
+batches (8 resident batches in rotation), nothing is cached between steps.  Chains shard over
+ranks with no data-path collective (weak scaling: 64 chains per GPU); one RCCL all_gather of
+the final log-posteriors happens after the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from quinn_amd.ops import MLPArch, BatchedMLP, neg_log_post_from_sse  # noqa: E402
+from quinn_amd import _lib  # noqa: E402
+
+CHAINS, N, DIMS, SIGMA = 64, 4096, (1, 64, 64, 64, 1), 0.02
+PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}      # MI355X dense matrix/vector peak (spec)
+NBATCH = 8
+
+
+def synthetic(n, d, noise=0.02, seed=0):
+    """x ~ U[-pi,pi]^d, y = sum_j sin(x_j) + noise*randn (shape of ex_ufit.py:56-62)."""
+    rs = np.random.RandomState(seed)
+    x = rs.rand(n, d) * 2 * np.pi - np.pi
+    y = noise * rs.randn(n, 1) + np.sum(np.sin(x), axis=1).reshape(-1, 1)
+    return x, y
+
+
+def cpu_baseline(arch, x, y, budget_s=15.0):
+    """The oracle's sequential float64 path (one eval at a time: unflatten -> Linear/tanh ->
+    NegLogPost -> .item(), as the reference does) on this host's cores; bounded sample."""
+    from oracle import mlp_ref
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    mod = mlp_ref.build_module(mlp_ref.MLPSpec(arch.dims, arch.activ))
+    yd = [v for v in y]
+    ws = [0.1 * np.random.RandomState(1000 + c).randn(arch.nparams) for c in range(16)]
+    for i in range(20):
+        mlp_ref.logpost(mod, ws[i % 16], x, yd, SIGMA)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        mlp_ref.logpost(mod, ws[n % 16], x, yd, SIGMA)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 5000:
+            break
+    return {"value": n / el, "unit": "log-posterior evals/s", "cores": ncores, "kind": "port",
+            "sample": f"{n} sequential float64 evals of the same workload (one chain at a time, "
+                      f"N={x.shape[0]}, 3x64 tanh MLP) in {el:.1f} s, torch threads={ncores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--kind", default="logpost", choices=["logpost", "grad"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", default="auto", choices=["auto", "generic", "fused"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    tdt = "float64" if args.dtype == "f64" else "float32"
+    arch = MLPArch(DIMS, "tanh")
+    x, y = synthetic(N, DIMS[0])
+    op = BatchedMLP(arch, x, y, device=dev, dtype=tdt)
+    _lib.lib().qn_set_path({"auto": 0, "generic": 1, "fused": 2}[args.path])
+    # this rank's chains: global chain id = rank*CHAINS + c; W[c] = 0.1*RandomState(1000+id).randn(p)
+    batches = []
+    for k in range(NBATCH):
+        Wk = np.stack([0.1 * np.random.RandomState(1000 + (rank * CHAINS + c) + 100003 * k).randn(arch.nparams)
+                       for c in range(CHAINS)])
+        batches.append(op.weights(Wk))
+    want_grad = args.kind == "grad"
+    run = (lambda W: op.sse_grad(W)) if want_grad else (lambda W: (op.sse(W), None))
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        out = run(batches[i % NBATCH])
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        out = run(batches[i % NBATCH])
+        ev[i][1].record()
+    barrier()
+    el = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # device time per launch group
+    lp_last = -neg_log_post_from_sse(out[0].cpu().numpy(), N, SIGMA)
+    assert np.all(np.isfinite(lp_last))
+
+    t_max = el
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_max = float(t.item())
+        gathered = [torch.empty(CHAINS, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, out[0])                 # the single end-of-run collective (RCCL)
+        torch.cuda.synchronize(dev)
+
+    if rank == 0:
+        evals = CHAINS * args.steps * world
+        value = evals / t_max
+        flops = arch.flops_fwdbwd(N) if want_grad else arch.flops_fwd(N)
+        ach = CHAINS * flops / (kern_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.dtype]
+        path = op.path(CHAINS, N, want_grad)
+        res = {
+            "metric": "log-posterior evals/sec (64 chains, 3x64 MLP, N=4096) at 1/2/4/8 GPU",
+            "value": value, "unit": "log-posterior evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: 64 AMCMC chains/GPU, 3x64 tanh MLP (p=8513), N=4096 1-D "
+                                   "regression; step = batched " + ("log-posterior+gradient" if want_grad else "log-posterior")
+                                   + " of all 64 chains", "chains_per_gpu": CHAINS, "N": N, "dims": list(DIMS),
+                       "kind": args.kind, "kernel_path": {1: "generic", 2: "fused"}.get(path, str(path)),
+                       "parallelism": f"chains sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                         "traffic": None, "flops_per_eval": flops, "evals_per_launch": CHAINS,
+                         "kernel_ms": kern_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(arch, x, y)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,119 @@
+/* quinn_amd.h -- C ABI of the MI355X (gfx950) hot path for QUiNN.
+ *
+ * The reference (sandialabs/quinn) is pure Python and has no FFI layer; its operator
+ * boundaries for this path are Python callables.  Each entry point below replaces the
+ * inner loop behind one of them and is what a ctypes binding in the reference would call
+ * (INTEGRATION.md shows the stubs).  Citations are file:line relative to the reference.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is a BORROWED DEVICE pointer
+ *     (HIP), never allocated or freed across this boundary;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     enqueued on it, no call synchronises the device;
+ *   - return value: QN_OK (0) or a negative QN_E* code; qn_last_error() gives the text
+ *     of the calling thread's last failure;
+ *   - dtype: QN_F64 (the reference's arithmetic, quinn/nns/tchutils.py:9) or QN_F32.
+ *
+ * Flat parameter layout of one weight vector (quinn/nns/nnwrap.py:70-77, i.e.
+ * module.parameters() order of quinn/nns/mlp.py:55-84):
+ *   [ W_0 (h_1 x d, row-major), b_0 (h_1), W_1 (h_2 x h_1), b_1, ..., W_L (o x h_L), b_L ]
+ */
+#ifndef QUINN_AMD_H
+#define QUINN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { QN_F64 = 0, QN_F32 = 1 };
+enum { QN_ACT_IDENTITY = 0, QN_ACT_TANH = 1, QN_ACT_RELU = 2 };
+enum { QN_OK = 0, QN_EINVAL = -1, QN_EWORKSPACE = -2, QN_EHIP = -3, QN_EUNSUPPORTED = -4 };
+/* kernel families, for qn_set_path (tests / profiling) */
+enum { QN_PATH_AUTO = 0, QN_PATH_GENERIC = 1, QN_PATH_FUSED = 2 };
+
+typedef struct qn_desc qn_desc;
+
+/* Architecture descriptor of a quinn-style MLP: dims = {d, h_1, ..., h_L, o} (ndims >= 2),
+ * one activation between consecutive Linear layers, none after the last
+ * (quinn/nns/mlp.py:46-84: 'tanh' | 'relu' | identity). */
+int qn_mlp_desc_create(const int* dims, int ndims, int act, int has_bias, qn_desc** out);
+int qn_mlp_desc_destroy(qn_desc* desc);
+/* p = number of entries of one flat weight vector. */
+int64_t qn_mlp_num_params(const qn_desc* desc);
+
+/* Bytes of scratch the two calls below need for B weight vectors x Nb rows each. */
+size_t qn_workspace_bytes(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
+
+/* Which kernel family the next call with these sizes would run (QN_PATH_GENERIC/FUSED). */
+int qn_mlp_path(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
+/* Force a kernel family (QN_PATH_AUTO restores dispatch). Returns the previous setting. */
+int qn_set_path(int path);
+
+/* sse_out[b] = sum_{n,o} (Y[r(b,n),o] - f_{W[b]}(X[r(b,n),:])[o])^2 for b < B.
+ * Replaces the per-weight-vector loop over NN_MCMC.logpost -> NNWrap.calc_loss ->
+ * NegLogPost.forward -> MLP.forward (quinn/solvers/nn_mcmc.py:45-71,
+ * quinn/nns/nnwrap.py:109-126, quinn/nns/losses.py:197-198, quinn/nns/mlp.py:92-101), the
+ * per-sample loop of BNet.sample_elbo (quinn/vi/bnet.py:202-205) and the forward of one
+ * ensemble member's loss in nnfit (quinn/nns/nnfit.py:133-140); with pred_out also
+ * nn_p / Learner.predict (quinn/nns/nnwrap.py:330-347, quinn/ens/learner.py:75-93).
+ *   W        [B, p]   dtype, row-major flat weight vectors (layout above)
+ *   X        [N, d]   dtype, row-major shared dataset
+ *   Y        [N, o]   dtype
+ *   row_idx  [B, Nb]  int32 or NULL. NULL: Nb must equal N and r(b,n) = n (all vectors see
+ *                     the whole dataset); else r(b,n) = row_idx[b*Nb+n] (per-member
+ *                     minibatch / data subset, quinn/nns/nnfit.py:131, nn_ens.py:63-64)
+ *   sse_out  [B]      float64 always
+ *   pred_out [B, Nb, o] dtype or NULL
+ * The scalar tails (log-posterior, NLL, MSE) are applied by the caller in float64. */
+int qn_mlp_sse_fwd(const qn_desc* desc, int dtype, const void* W, const void* X, const void* Y,
+                   const int32_t* row_idx, int B, int N, int Nb, double* sse_out, void* pred_out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* As above plus gradW_out[b, :] = d sse_out[b] / d W[b, :]  ([B, p] dtype).  Replaces
+ * NN_MCMC.logpostgrad -> NNWrap.calc_lossgrad (quinn/solvers/nn_mcmc.py:73-98,
+ * quinn/nns/nnwrap.py:128-150) and loss.backward() in nnfit (quinn/nns/nnfit.py:163-165). */
+int qn_mlp_sse_fwdbwd(const qn_desc* desc, int dtype, const void* W, const void* X, const void* Y,
+                      const int32_t* row_idx, int B, int N, int Nb, double* sse_out, void* pred_out,
+                      void* gradW_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Mean-field Gaussian VI, sampling + KL terms (quinn/vi/bnet.py:142-163,
+ * quinn/rvar/rvs.py:96-127, 159-173; sigma = exp(rho), bnet.py:80):
+ *   W_out[s,i]  = mu[i] + exp(rho[i]) * eps[s,i]                          [S, p] dtype
+ *   logq_out[s] = sum_i( -log sqrt(2 pi) - rho[i] - (w-mu)^2 / (2 sigma^2) )   float64
+ *   logp_out[s] = sum_i log( pi N(w;0,sigma1) + (1-pi) N(w;0,sigma2) )          float64
+ * mu, rho: [p] float64 (the variational parameters stay float64); eps: [S, p] float64. */
+int qn_vi_sample_kl(const double* mu, const double* rho, const double* eps, int S, int64_t p,
+                    double pi, double sigma1, double sigma2, int dtype, void* W_out,
+                    double* logq_out, double* logp_out, void* stream);
+
+/* Chain rule of viloss = (mean_s logq - mean_s logp) * kl_scale + NLL  (bnet.py:229-232)
+ * to (mu, rho), given gW[s,:] = d NLL / d W[s,:] * gw_scale taken from qn_mlp_sse_fwdbwd
+ * (gw_scale = 0.5 / (S * o * sigma_d^2) turns dSSE into dNLL, bnet.py:215):
+ *   dmu[i]  = sum_s gW[s,i]*gw_scale - kl_scale/S * sum_s gp(w_si)
+ *   drho[i] = sum_s gW[s,i]*gw_scale*sigma_i*eps_si - kl_scale*(1 + 1/S sum_s gp(w_si)*sigma_i*eps_si)
+ * with gp = d/dw log prior density.  dmu, drho: [p] float64. */
+int qn_vi_grad(const double* mu, const double* rho, const double* eps, const void* gW, int S,
+               int64_t p, double pi, double sigma1, double sigma2, double gw_scale, double kl_scale,
+               int dtype, double* dmu_out, double* drho_out, void* stream);
+
+/* One Adam step for B independent members at once (torch.optim.Adam defaults as used by
+ * quinn/nns/nnfit.py:74-75, single-tensor update order):
+ *   g = G*gscale + wd*W;  m += (g-m)*(1-b1);  v = v*b2 + (1-b2)*g*g;
+ *   W -= lr[b]/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * W, m, v: [B, p] float64 master state; G: [B, p] dtype; lr: [B] float64 (device);
+ * step t >= 1.  Members with lr[b] == 0 are left untouched. */
+int qn_adam_batched(double* W, const void* G, double* m, double* v, const double* lr, int B,
+                    int64_t p, int dtype, double gscale, double wd, double beta1, double beta2,
+                    double eps, int step, void* stream);
+
+const char* qn_last_error(void);
+/* "quinn_amd <version> gfx950" */
+const char* qn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUINN_AMD_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of the C-ABI library (include/quinn_amd.h) and its in-tree build.
+
+The product path has no CPU fallback: if libquinn_amd.so is missing or a call fails,
+an exception is raised.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIBDIR = os.path.join(_HERE, "lib")
+LIBPATH = os.path.join(LIBDIR, "libquinn_amd.so")
+SOURCES = ["qn_api.hip", "qn_generic.hip", "qn_fused.hip"]
+
+QN_F64, QN_F32 = 0, 1
+ACT_CODES = {"identity": 0, "tanh": 1, "relu": 2}
+PATH_AUTO, PATH_GENERIC, PATH_FUSED = 0, 1, 2
+
+# every symbol include/quinn_amd.h declares (tests check the .so exports all of them)
+SYMBOLS = ["qn_mlp_desc_create", "qn_mlp_desc_destroy", "qn_mlp_num_params", "qn_workspace_bytes",
+           "qn_mlp_path", "qn_set_path", "qn_mlp_sse_fwd", "qn_mlp_sse_fwdbwd", "qn_vi_sample_kl",
+           "qn_vi_grad", "qn_adam_batched", "qn_last_error", "qn_version"]
+
+
+class QuinnAmdError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 into quinn_amd/lib/libquinn_amd.so (hipcc
+    cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "qn_common.h"), os.path.join(_HERE, "..", "include", "quinn_amd.h")]
+    if not force and os.path.exists(LIBPATH):
+        if os.path.getmtime(LIBPATH) >= max(os.path.getmtime(d) for d in deps):
+            return LIBPATH
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", LIBPATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIBPATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises QuinnAmdError if it is not built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBPATH):
+        raise QuinnAmdError(f"{LIBPATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = ctypes.CDLL(LIBPATH)
+    vp, i32, i64, f64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_size_t
+    L.qn_mlp_desc_create.argtypes = [ctypes.POINTER(i32), i32, i32, i32, ctypes.POINTER(vp)]
+    L.qn_mlp_desc_create.restype = i32
+    L.qn_mlp_desc_destroy.argtypes = [vp]
+    L.qn_mlp_desc_destroy.restype = i32
+    L.qn_mlp_num_params.argtypes = [vp]
+    L.qn_mlp_num_params.restype = i64
+    L.qn_workspace_bytes.argtypes = [vp, i32, i32, i32, i32]
+    L.qn_workspace_bytes.restype = sz
+    L.qn_mlp_path.argtypes = [vp, i32, i32, i32, i32]
+    L.qn_mlp_path.restype = i32
+    L.qn_set_path.argtypes = [i32]
+    L.qn_set_path.restype = i32
+    L.qn_mlp_sse_fwd.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, sz, vp]
+    L.qn_mlp_sse_fwd.restype = i32
+    L.qn_mlp_sse_fwdbwd.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]
+    L.qn_mlp_sse_fwdbwd.restype = i32
+    L.qn_vi_sample_kl.argtypes = [vp, vp, vp, i32, i64, f64, f64, f64, i32, vp, vp, vp, vp]
+    L.qn_vi_sample_kl.restype = i32
+    L.qn_vi_grad.argtypes = [vp, vp, vp, vp, i32, i64, f64, f64, f64, f64, f64, i32, vp, vp, vp]
+    L.qn_vi_grad.restype = i32
+    L.qn_adam_batched.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, f64, f64, f64, f64, f64, i32, vp]
+    L.qn_adam_batched.restype = i32
+    L.qn_last_error.restype = ctypes.c_char_p
+    L.qn_version.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise QuinnAmdError(f"{what} failed (code {rc}): {lib().qn_last_error().decode()}")

@@ -1,0 +1,306 @@
+// C-ABI entry points (include/quinn_amd.h): descriptor, dispatch between the kernel
+// families, and the small elementwise kernels of the VI / ensemble trainers.
+#include "qn_common.h"
+#include <cmath>
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+static int g_forced_path = QN_PATH_AUTO;
+
+void qn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int qn_forced_path() { return g_forced_path; }
+
+extern "C" const char* qn_last_error(void) { return g_err; }
+extern "C" const char* qn_version(void) { return "quinn_amd 0.1 gfx950"; }
+extern "C" int qn_set_path(int path) {
+    const int old = g_forced_path;
+    if (path == QN_PATH_AUTO || path == QN_PATH_GENERIC || path == QN_PATH_FUSED) g_forced_path = path;
+    return old;
+}
+
+extern "C" int qn_mlp_desc_create(const int* dims, int ndims, int act, int has_bias, qn_desc** out) {
+    if (!dims || !out || ndims < 2 || ndims > QN_MAX_LAYERS + 1) {
+        qn_set_error("qn_mlp_desc_create: need 2 <= ndims <= %d", QN_MAX_LAYERS + 1);
+        return QN_EINVAL;
+    }
+    if (act != QN_ACT_IDENTITY && act != QN_ACT_TANH && act != QN_ACT_RELU) {
+        qn_set_error("qn_mlp_desc_create: unknown activation %d", act);
+        return QN_EINVAL;
+    }
+    qn_desc* d = new qn_desc();
+    d->nlayers = ndims - 1;
+    d->act = act;
+    d->has_bias = has_bias ? 1 : 0;
+    d->hmax = 0;
+    int64_t off = 0;
+    for (int i = 0; i < ndims; ++i) {
+        if (dims[i] <= 0) {
+            delete d;
+            qn_set_error("qn_mlp_desc_create: dims[%d] = %d", i, dims[i]);
+            return QN_EINVAL;
+        }
+        d->dims[i] = dims[i];
+        if (i > 0 && dims[i] > d->hmax) d->hmax = dims[i];
+    }
+    for (int l = 0; l < d->nlayers; ++l) {
+        d->offW[l] = off;
+        off += (int64_t)d->dims[l] * d->dims[l + 1];
+        d->offB[l] = off;
+        if (d->has_bias) off += d->dims[l + 1];
+    }
+    d->p = off;
+    *out = d;
+    return QN_OK;
+}
+
+extern "C" int qn_mlp_desc_destroy(qn_desc* d) {
+    delete d;
+    return QN_OK;
+}
+
+extern "C" int64_t qn_mlp_num_params(const qn_desc* d) { return d ? d->p : -1; }
+
+static bool use_fused(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
+    if (g_forced_path == QN_PATH_GENERIC) return false;
+    return qn_fused_supported(d, B, Nb, want_grad, dtype);
+}
+
+extern "C" int qn_mlp_path(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
+    if (!d) return QN_EINVAL;
+    return use_fused(d, B, Nb, want_grad, dtype) ? QN_PATH_FUSED : QN_PATH_GENERIC;
+}
+
+extern "C" size_t qn_workspace_bytes(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
+    if (!d || B <= 0 || Nb <= 0) return 0;
+    // sized for either family so that qn_set_path never invalidates a caller's buffer
+    size_t g = qn_generic_workspace(d, B, Nb, want_grad, dtype);
+    size_t f = qn_fused_supported(d, B, Nb, want_grad, dtype) ? qn_fused_workspace(d, B, Nb, want_grad, dtype) : 0;
+    if (g_forced_path == QN_PATH_AUTO && f) return f;
+    return g > f ? g : f;
+}
+
+static int check_common(const char* fn, const qn_desc* d, int dtype, const void* W, const void* X, const void* Y,
+                        const int32_t* row_idx, int B, int N, int Nb, double* sse, void* ws) {
+    if (!d || !W || !X || !Y || !sse || !ws) {
+        qn_set_error("%s: null argument", fn);
+        return QN_EINVAL;
+    }
+    if (dtype != QN_F64 && dtype != QN_F32) {
+        qn_set_error("%s: dtype %d", fn, dtype);
+        return QN_EINVAL;
+    }
+    if (B <= 0 || N <= 0 || Nb <= 0 || B > 65535) {
+        qn_set_error("%s: B=%d N=%d Nb=%d out of range", fn, B, N, Nb);
+        return QN_EINVAL;
+    }
+    if (!row_idx && Nb != N) {
+        qn_set_error("%s: row_idx is NULL but Nb (%d) != N (%d)", fn, Nb, N);
+        return QN_EINVAL;
+    }
+    return QN_OK;
+}
+
+static int run(const char* fn, const qn_desc* d, int dtype, const void* W, const void* X, const void* Y,
+               const int32_t* row_idx, int B, int N, int Nb, double* sse, void* pred, void* gradW, void* ws,
+               size_t ws_bytes, void* stream) {
+    int rc = check_common(fn, d, dtype, W, X, Y, row_idx, B, N, Nb, sse, ws);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int want_grad = gradW != nullptr;
+    if (g_forced_path == QN_PATH_FUSED && !qn_fused_supported(d, B, Nb, want_grad, dtype)) {
+        qn_set_error("%s: fused path forced but not supported for this shape", fn);
+        return QN_EUNSUPPORTED;
+    }
+    if (use_fused(d, B, Nb, want_grad, dtype))
+        return qn_fused_run(d, dtype, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
+    return qn_generic_run(d, dtype, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
+}
+
+extern "C" int qn_mlp_sse_fwd(const qn_desc* d, int dtype, const void* W, const void* X, const void* Y,
+                              const int32_t* row_idx, int B, int N, int Nb, double* sse_out, void* pred_out,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    return run("qn_mlp_sse_fwd", d, dtype, W, X, Y, row_idx, B, N, Nb, sse_out, pred_out, nullptr, workspace,
+               workspace_bytes, stream);
+}
+
+extern "C" int qn_mlp_sse_fwdbwd(const qn_desc* d, int dtype, const void* W, const void* X, const void* Y,
+                                 const int32_t* row_idx, int B, int N, int Nb, double* sse_out, void* pred_out,
+                                 void* gradW_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!gradW_out) {
+        qn_set_error("qn_mlp_sse_fwdbwd: gradW_out is NULL");
+        return QN_EINVAL;
+    }
+    return run("qn_mlp_sse_fwdbwd", d, dtype, W, X, Y, row_idx, B, N, Nb, sse_out, pred_out, gradW_out, workspace,
+               workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// VI: sampling + KL terms, chain rule to (mu, rho); batched Adam.  HBM-bound elementwise /
+// row-reduction kernels: coalesced along the parameter index, fixed-order reductions.
+namespace {
+
+constexpr int BLK = 256;
+constexpr double kLogSqrt2Pi = 0.91893853320467274178;   // log(sqrt(2*pi))
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// log N(w; 0, s) as torch.distributions.Normal.log_prob orders it:
+//   -(w^2) / (2 s^2) - log(s) - log(sqrt(2 pi))
+__device__ __forceinline__ double normal_logpdf(double w, double var2, double log_s) {
+    return -(w * w) / var2 - log_s - kLogSqrt2Pi;
+}
+
+constexpr int KLB = 1024;   // one block per MC sample: fixed-order reduction, no scratch
+
+template <typename T>
+__global__ __launch_bounds__(KLB) void k_vi_sample_kl(const double* __restrict__ mu, const double* __restrict__ rho,
+                                                      const double* __restrict__ eps, int64_t p, double pi,
+                                                      double s1, double s2, T* __restrict__ Wout,
+                                                      double* __restrict__ logq, double* __restrict__ logp) {
+    __shared__ double red[2][KLB / 64];
+    const int s = blockIdx.x;
+    const double v1 = 2.0 * s1 * s1, v2 = 2.0 * s2 * s2, l1 = log(s1), l2 = log(s2);
+    double aq = 0.0, ap = 0.0;
+    for (int64_t i = threadIdx.x; i < p; i += KLB) {
+        const double m = mu[i], r = rho[i], e = eps[(int64_t)s * p + i];
+        const double sig = exp(r);
+        const double w = m + sig * e;
+        Wout[(int64_t)s * p + i] = (T)w;
+        const double dq = w - m;
+        aq += -kLogSqrt2Pi - r - (dq * dq) / (2.0 * (sig * sig));   // log(exp(r)) == r
+        const double p1 = exp(normal_logpdf(w, v1, l1)), p2 = exp(normal_logpdf(w, v2, l2));
+        ap += log(pi * p1 + (1.0 - pi) * p2);
+    }
+    aq = wave_sum(aq);
+    ap = wave_sum(ap);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = aq; red[1][threadIdx.x >> 6] = ap; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double q = 0.0, pp = 0.0;
+        for (int w = 0; w < KLB / 64; ++w) { q += red[0][w]; pp += red[1][w]; }
+        logq[s] = q;
+        logp[s] = pp;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_vi_grad(const double* __restrict__ mu, const double* __restrict__ rho,
+                                                 const double* __restrict__ eps, const T* __restrict__ gW, int S,
+                                                 int64_t p, double pi, double s1, double s2, double gw_scale,
+                                                 double kl_scale, double* __restrict__ dmu, double* __restrict__ drho) {
+    const int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (i >= p) return;
+    const double m = mu[i], sig = exp(rho[i]);
+    const double v1 = 2.0 * s1 * s1, v2 = 2.0 * s2 * s2, l1 = log(s1), l2 = log(s2);
+    double gm = 0.0, gr = 0.0, pm = 0.0, pr = 0.0;
+    for (int s = 0; s < S; ++s) {
+        const double e = eps[(int64_t)s * p + i];
+        const double w = m + sig * e;
+        const double g = (double)gW[(int64_t)s * p + i] * gw_scale;
+        gm += g;
+        gr += g * sig * e;
+        const double p1 = pi * exp(normal_logpdf(w, v1, l1)), p2 = (1.0 - pi) * exp(normal_logpdf(w, v2, l2));
+        const double gp = (p1 * (-w / (s1 * s1)) + p2 * (-w / (s2 * s2))) / (p1 + p2);
+        pm += gp;
+        pr += gp * sig * e;
+    }
+    dmu[i] = gm - kl_scale * (pm / S);
+    drho[i] = gr - kl_scale * (1.0 + pr / S);
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_adam(double* __restrict__ W, const T* __restrict__ G, double* __restrict__ m,
+                                              double* __restrict__ v, const double* __restrict__ lr, int64_t p,
+                                              double gscale, double wd, double b1, double b2, double eps, double bc1,
+                                              double bc2_sqrt) {
+    const int b = blockIdx.y;
+    const double lrb = lr[b];
+    if (lrb == 0.0) return;
+    const double step_size = lrb / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < p; i += (int64_t)gridDim.x * BLK) {
+        const int64_t k = (int64_t)b * p + i;
+        double w = W[k];
+        double g = (double)G[k] * gscale;
+        if (wd != 0.0) g = g + wd * w;
+        double mm = m[k];
+        mm = mm + (1.0 - b1) * (g - mm);                 // lerp_(grad, 1-beta1), weight < 0.5 branch
+        double vv = v[k] * b2;
+        vv = vv + ((1.0 - b2) * g) * g;                  // addcmul_(grad, grad, value=1-beta2)
+        const double denom = sqrt(vv) / bc2_sqrt + eps;
+        w = w + (-step_size) * (mm / denom);             // addcdiv_(exp_avg, denom, value=-step_size)
+        W[k] = w;
+        m[k] = mm;
+        v[k] = vv;
+    }
+}
+
+}  // namespace
+
+extern "C" int qn_vi_sample_kl(const double* mu, const double* rho, const double* eps, int S, int64_t p,
+                               double pi, double sigma1, double sigma2, int dtype, void* W_out, double* logq_out,
+                               double* logp_out, void* stream) {
+    if (!mu || !rho || !eps || !W_out || !logq_out || !logp_out || S <= 0 || p <= 0 || S > 65535) {
+        qn_set_error("qn_vi_sample_kl: bad argument");
+        return QN_EINVAL;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == QN_F64)
+        hipLaunchKernelGGL((k_vi_sample_kl<double>), dim3(S), dim3(KLB), 0, st, mu, rho, eps, p, pi, sigma1, sigma2,
+                           (double*)W_out, logq_out, logp_out);
+    else
+        hipLaunchKernelGGL((k_vi_sample_kl<float>), dim3(S), dim3(KLB), 0, st, mu, rho, eps, p, pi, sigma1, sigma2,
+                           (float*)W_out, logq_out, logp_out);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
+
+extern "C" int qn_vi_grad(const double* mu, const double* rho, const double* eps, const void* gW, int S, int64_t p,
+                          double pi, double sigma1, double sigma2, double gw_scale, double kl_scale, int dtype,
+                          double* dmu_out, double* drho_out, void* stream) {
+    if (!mu || !rho || !eps || !gW || !dmu_out || !drho_out || S <= 0 || p <= 0) {
+        qn_set_error("qn_vi_grad: bad argument");
+        return QN_EINVAL;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((p + BLK - 1) / BLK));
+    if (dtype == QN_F64)
+        hipLaunchKernelGGL((k_vi_grad<double>), grid, dim3(BLK), 0, st, mu, rho, eps, (const double*)gW, S, p, pi,
+                           sigma1, sigma2, gw_scale, kl_scale, dmu_out, drho_out);
+    else
+        hipLaunchKernelGGL((k_vi_grad<float>), grid, dim3(BLK), 0, st, mu, rho, eps, (const float*)gW, S, p, pi,
+                           sigma1, sigma2, gw_scale, kl_scale, dmu_out, drho_out);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
+
+extern "C" int qn_adam_batched(double* W, const void* G, double* m, double* v, const double* lr, int B, int64_t p,
+                               int dtype, double gscale, double wd, double beta1, double beta2, double eps, int step,
+                               void* stream) {
+    if (!W || !G || !m || !v || !lr || B <= 0 || B > 65535 || p <= 0 || step < 1) {
+        qn_set_error("qn_adam_batched: bad argument");
+        return QN_EINVAL;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const double bc1 = 1.0 - std::pow(beta1, (double)step);
+    const double bc2_sqrt = std::sqrt(1.0 - std::pow(beta2, (double)step));
+    int nblk = (int)((p + BLK - 1) / BLK);
+    if (nblk > 1024) nblk = 1024;
+    dim3 grid(nblk, B);
+    if (dtype == QN_F64)
+        hipLaunchKernelGGL((k_adam<double>), grid, dim3(BLK), 0, st, W, (const double*)G, m, v, lr, p, gscale, wd,
+                           beta1, beta2, eps, bc1, bc2_sqrt);
+    else
+        hipLaunchKernelGGL((k_adam<float>), grid, dim3(BLK), 0, st, W, (const float*)G, m, v, lr, p, gscale, wd,
+                           beta1, beta2, eps, bc1, bc2_sqrt);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}

@@ -1,0 +1,49 @@
+// Internal definitions shared by the HIP translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <vector>
+#include "../../include/quinn_amd.h"
+
+#define QN_MAX_LAYERS 16
+
+struct qn_desc {
+    int nlayers;                    // number of Linear layers (= ndims - 1)
+    int dims[QN_MAX_LAYERS + 1];    // d, h_1, ..., o
+    int act;
+    int has_bias;
+    int64_t p;                      // flat parameter count
+    int64_t offW[QN_MAX_LAYERS];    // offset of W_l in the flat vector
+    int64_t offB[QN_MAX_LAYERS];    // offset of b_l (valid if has_bias)
+    int hmax;                       // widest hidden/output layer
+};
+
+void qn_set_error(const char* fmt, ...);
+int qn_forced_path();
+
+#define QN_HIP_CHECK(expr)                                                          \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            qn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                         __FILE__, __LINE__);                                       \
+            return QN_EHIP;                                                         \
+        }                                                                           \
+    } while (0)
+
+static inline size_t qn_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ---- generic (any-shape) path: qn_generic.hip
+size_t qn_generic_workspace(const qn_desc* d, int B, int Nb, int want_grad, int dtype);
+int qn_generic_run(const qn_desc* d, int dtype, const void* W, const void* X, const void* Y,
+                   const int32_t* row_idx, int B, int N, int Nb, double* sse, void* pred,
+                   void* gradW, void* ws, size_t ws_bytes, hipStream_t st);
+
+// ---- fused MFMA path with LDS-resident weights: qn_fused.hip
+bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtype);
+size_t qn_fused_workspace(const qn_desc* d, int B, int Nb, int want_grad, int dtype);
+int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, const void* Y,
+                 const int32_t* row_idx, int B, int N, int Nb, double* sse, void* pred,
+                 void* gradW, void* ws, size_t ws_bytes, hipStream_t st);

@@ -1,0 +1,246 @@
+"""The batched operator behind every solver: for B flat weight vectors at once, the MLP's
+sum of squared errors over a (shared or per-member) set of data rows, its gradient, and
+the predictions -- evaluated by the HIP kernels through the C ABI.
+
+torch is used for device memory and streams only.
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import QuinnAmdError
+
+_TORCH_DT = {"float64": torch.float64, "float32": torch.float32}
+_QN_DT = {"float64": _lib.QN_F64, "float32": _lib.QN_F32}
+
+
+@dataclass(frozen=True)
+class MLPArch:
+    """dims = (d, h_1, ..., h_L, o); flat layout [W_0, b_0, W_1, b_1, ...] with W row-major
+    (out x in), i.e. module.parameters() order (reference quinn/nns/nnwrap.py:70-77)."""
+    dims: Tuple[int, ...]
+    activ: str = "tanh"
+    bias: bool = True
+
+    @property
+    def nparams(self):
+        return sum(a * b + (b if self.bias else 0) for a, b in zip(self.dims[:-1], self.dims[1:]))
+
+    @property
+    def nweights(self):
+        return sum(a * b for a, b in zip(self.dims[:-1], self.dims[1:]))
+
+    def flops_fwd(self, n):
+        """2*N*Wn."""
+        return 2 * n * self.nweights
+
+    def flops_fwdbwd(self, n):
+        """6*N*Wn - 2*N*d*h_1 (no input gradient for the first layer)."""
+        return 6 * n * self.nweights - 2 * n * self.dims[0] * self.dims[1]
+
+    @staticmethod
+    def from_module(nnmodel):
+        """Pattern-match Sequential(Linear, act, Linear, ..., Linear) -- directly, or as the
+        `.nnmodel` attribute of a quinn-style MLP (reference quinn/nns/mlp.py:86)."""
+        seq = nnmodel
+        if not isinstance(seq, torch.nn.Sequential):
+            seq = getattr(nnmodel, "nnmodel", None)
+        if not isinstance(seq, torch.nn.Sequential):
+            raise NotImplementedError(
+                f"{type(nnmodel).__name__}: only MLPs built as Sequential(Linear, act, ..., Linear) "
+                "are handled by the MI355X path")
+        mods = list(seq)
+        dims, acts, bias = [], set(), None
+        expect_linear = True
+        for m in mods:
+            if expect_linear:
+                if not isinstance(m, torch.nn.Linear):
+                    raise NotImplementedError(f"unexpected layer {type(m).__name__} (wanted Linear)")
+                if not dims:
+                    dims.append(m.in_features)
+                elif dims[-1] != m.in_features:
+                    raise ValueError("layer widths do not chain")
+                dims.append(m.out_features)
+                b = m.bias is not None
+                if bias is None:
+                    bias = b
+                elif bias != b:
+                    raise NotImplementedError("mixed bias / no-bias layers")
+                expect_linear = False
+            else:
+                if isinstance(m, torch.nn.Tanh):
+                    acts.add("tanh")
+                elif isinstance(m, torch.nn.ReLU):
+                    acts.add("relu")
+                elif isinstance(m, torch.nn.Identity):
+                    acts.add("identity")
+                else:
+                    raise NotImplementedError(f"activation {type(m).__name__} is not handled")
+                expect_linear = True
+        if expect_linear or len(dims) < 2:
+            raise NotImplementedError("module must end with a Linear layer")
+        if len(acts) > 1:
+            raise NotImplementedError("mixed activations")
+        return MLPArch(tuple(dims), acts.pop() if acts else "identity", bool(bias))
+
+
+def flatten_module(nnmodel):
+    """Flat float64 numpy vector of module.parameters() (reference nnwrap.py:70-77)."""
+    return np.concatenate([p.detach().cpu().double().flatten().numpy() for p in nnmodel.parameters()])
+
+
+def default_device(device=None):
+    if device is not None:
+        dev = torch.device(device)
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    if dev is None or dev.type != "cuda" or not torch.cuda.is_available():
+        raise QuinnAmdError("quinn_amd needs an AMD GPU (HIP device) -- there is no CPU fallback")
+    return dev
+
+
+class BatchedMLP:
+    """Device-resident dataset + architecture descriptor + workspace; calls the C ABI."""
+
+    def __init__(self, arch: MLPArch, x, y, device=None, dtype="float64", max_workspace_bytes=16 << 30):
+        self.arch = arch
+        self.device = default_device(device)
+        if dtype not in _TORCH_DT:
+            raise ValueError(f"dtype {dtype!r}")
+        self.dtype = dtype
+        self.tdt = _TORCH_DT[dtype]
+        self.qdt = _QN_DT[dtype]
+        self.max_ws = int(max_workspace_bytes)
+        self._L = _lib.lib()
+        dims = (ctypes.c_int * len(arch.dims))(*arch.dims)
+        h = ctypes.c_void_p()
+        _lib.check(self._L.qn_mlp_desc_create(dims, len(arch.dims), _lib.ACT_CODES[arch.activ],
+                                              int(arch.bias), ctypes.byref(h)), "qn_mlp_desc_create")
+        self._desc = h
+        self.p = int(self._L.qn_mlp_num_params(h))
+        assert self.p == arch.nparams
+        self._ws = None
+        self.set_data(x, y)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_desc", None):
+                self._L.qn_mlp_desc_destroy(self._desc)
+                self._desc = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ data / buffers
+    def _dev(self, a, dt=None):
+        dt = dt or self.tdt
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dt).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), device=self.device).to(dt).contiguous()
+
+    def set_data(self, x, y):
+        d, o = self.arch.dims[0], self.arch.dims[-1]
+        self.X = self._dev(x).reshape(-1, d)
+        self.N = self.X.shape[0]
+        if y is None:
+            self.Y = torch.zeros(self.N, o, device=self.device, dtype=self.tdt)
+        else:
+            self.Y = self._dev(y).reshape(-1, o)
+        if self.Y.shape[0] != self.N:
+            raise ValueError("x and y row counts differ")
+
+    def workspace_bytes(self, B, Nb, want_grad):
+        return int(self._L.qn_workspace_bytes(self._desc, B, Nb, int(want_grad), self.qdt))
+
+    def path(self, B, Nb=None, want_grad=False):
+        return int(self._L.qn_mlp_path(self._desc, B, Nb or self.N, int(want_grad), self.qdt))
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _chunk(self, B, Nb, want_grad):
+        bc = B
+        while bc > 1 and self.workspace_bytes(bc, Nb, want_grad) > self.max_ws:
+            bc = (bc + 1) // 2
+        return bc
+
+    def weights(self, W):
+        """[B, p] device tensor in the compute dtype (numpy float64 input is uploaded)."""
+        Wt = self._dev(W)
+        if Wt.dim() == 1:
+            Wt = Wt.unsqueeze(0)
+        if Wt.shape[1] != self.p:
+            raise ValueError(f"weight vectors have {Wt.shape[1]} entries, the network has {self.p}")
+        return Wt
+
+    # ------------------------------------------------------------------ the operator
+    def _call(self, W, row_idx, want_pred, want_grad, X=None, Y=None):
+        X = self.X if X is None else X
+        Y = self.Y if Y is None else Y
+        N = X.shape[0]
+        Wt = self.weights(W)
+        B = Wt.shape[0]
+        if row_idx is not None:
+            ridx = torch.as_tensor(row_idx, device=self.device).to(torch.int32).contiguous().reshape(B, -1)
+            Nb = ridx.shape[1]
+        else:
+            ridx, Nb = None, N
+        o = self.arch.dims[-1]
+        sse = torch.empty(B, dtype=torch.float64, device=self.device)
+        pred = torch.empty(B, Nb, o, dtype=self.tdt, device=self.device) if want_pred else None
+        grad = torch.empty(B, self.p, dtype=self.tdt, device=self.device) if want_grad else None
+        bc = self._chunk(B, Nb, want_grad)
+        ws = self._workspace(self.workspace_bytes(bc, Nb, want_grad))
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            for b0 in range(0, B, bc):
+                b1 = min(B, b0 + bc)
+                nb = b1 - b0
+                args = [self._desc, self.qdt, Wt[b0:b1].data_ptr(), X.data_ptr(), Y.data_ptr(),
+                        ridx[b0:b1].data_ptr() if ridx is not None else None, nb, N, Nb,
+                        sse[b0:b1].data_ptr(), pred[b0:b1].data_ptr() if pred is not None else None]
+                if want_grad:
+                    rc = self._L.qn_mlp_sse_fwdbwd(*args, grad[b0:b1].data_ptr(), ws.data_ptr(), ws.numel(), stream)
+                    _lib.check(rc, "qn_mlp_sse_fwdbwd")
+                else:
+                    rc = self._L.qn_mlp_sse_fwd(*args, ws.data_ptr(), ws.numel(), stream)
+                    _lib.check(rc, "qn_mlp_sse_fwd")
+        return sse, pred, grad
+
+    def sse(self, W, row_idx=None):
+        """sum_{n,o} (y - f_W(x))^2 for every weight vector: float64 device tensor [B]."""
+        return self._call(W, row_idx, False, False)[0]
+
+    def sse_grad(self, W, row_idx=None):
+        """(sse [B] float64, d sse / d W [B, p] compute dtype), device tensors."""
+        s, _, g = self._call(W, row_idx, False, True)
+        return s, g
+
+    def sse_pred(self, W, row_idx=None):
+        s, pr, _ = self._call(W, row_idx, True, False)
+        return s, pr
+
+    def predict(self, W, x=None):
+        """f_W(x) for every weight vector: [B, N, o] device tensor (x defaults to the stored X)."""
+        if x is None:
+            return self._call(W, None, True, False)[1]
+        X = self._dev(x).reshape(-1, self.arch.dims[0])
+        Y = torch.zeros(X.shape[0], self.arch.dims[-1], device=self.device, dtype=self.tdt)
+        return self._call(W, None, True, False, X=X, Y=Y)[1]
+
+
+def neg_log_post_from_sse(sse, n, sigma):
+    """0.5*SSE/sigma^2 + (n/2)*log(2*pi) + n*log(sigma) in float64 with the operation order
+    of the reference's NegLogPost.forward (quinn/nns/losses.py:198-200); sse: float64 array."""
+    sse = np.asarray(sse, dtype=np.float64)
+    sig = np.float64(sigma)
+    val = 0.5 * sse / sig ** 2
+    val = val + (n / 2) * np.log(2 * np.float64(np.pi))
+    val = val + n * np.log(sig)
+    return val

@@ -1,0 +1,164 @@
+"""MCMC wrapper around a user MLP, all chains' log-posteriors evaluated in one launch.
+
+Mirror of the reference's `NN_MCMC` (quinn/solvers/nn_mcmc.py:15-200): same constructor,
+`fit` / `logpost` / `logpostgrad` / `predict_*` signatures and attributes (`samples`,
+`cmode`, `pdim`, `lpinfo`).  Build-only keyword extras (defaults = reference behaviour):
+`nchains`, `seeds` on `fit`; `device`, `dtype` on the constructor.
+
+logpost(w) = -[ 0.5*SSE(w)/sigma^2 + (N/2) log 2pi + N log sigma ]   (no prior,
+nn_mcmc.py:64 -> losses.py:197-200); SSE and dSSE/dw come from the HIP kernels, the scalar
+tail is applied here in float64.
+"""
+import copy
+import sys
+
+import numpy as np
+from scipy.optimize import minimize
+
+from ..mcmc.admcmc import AMCMC
+from ..mcmc.hmc import HMC
+from ..mcmc.mala import MALA
+from ..ops import BatchedMLP, neg_log_post_from_sse
+from .quinn import QUiNNBase
+
+
+class NN_MCMC(QUiNNBase):
+    """Attributes: samples `(nmcmc+1, p)` (or `(C, nmcmc+1, p)` for C chains), cmode (MAP
+    weights), pdim, lpinfo, verbose."""
+
+    def __init__(self, nnmodel, verbose=True, device=None, dtype="float64"):
+        super().__init__(nnmodel, device=device, dtype=dtype)
+        self.verbose = verbose
+        self.pdim = sum(p.numel() for p in self.nnmodel.parameters())
+        print("Number of parameters:", self.pdim)
+        if self.verbose:
+            self.print_params(names_only=True)
+        self.samples = None
+        self.cmode = None
+        self.lpinfo = {}
+        self._op = None
+        self._op_key = None
+
+    # -- device operator bound to lpinfo's dataset -----------------------------------------
+    def _operator(self, lpinfo):
+        key = (id(lpinfo['xd']), id(lpinfo['yd']))
+        if self._op is None or self._op_key != key:
+            xd = np.asarray(lpinfo['xd'], dtype=np.float64)
+            yd = np.asarray(lpinfo['yd'], dtype=np.float64)      # list of (o,) rows -> (N,o)
+            self._op = BatchedMLP(self.arch, xd, yd.reshape(xd.shape[0], -1), device=self._device,
+                                  dtype=self._dtype)
+            self._op_key = key
+        return self._op
+
+    @staticmethod
+    def _check_ltype(lpinfo):
+        if lpinfo['ltype'] != 'classical':
+            print('Likelihood type is not recognized. Exiting.')
+            sys.exit()
+
+    def logpost_batch(self, W, lpinfo=None):
+        """Log-posterior of every row of W `(C,p)`: numpy float64 `(C,)`."""
+        lpinfo = self.lpinfo if lpinfo is None else lpinfo
+        self._check_ltype(lpinfo)
+        op = self._operator(lpinfo)
+        sse = op.sse(np.atleast_2d(W)).cpu().numpy()
+        return -neg_log_post_from_sse(sse, len(lpinfo['yd']), lpinfo['lparams']['sigma'])
+
+    def logpostgrad_batch(self, W, lpinfo=None):
+        """Gradient of the log-posterior for every row of W: numpy float64 `(C,p)`."""
+        lpinfo = self.lpinfo if lpinfo is None else lpinfo
+        self._check_ltype(lpinfo)
+        op = self._operator(lpinfo)
+        _, g = op.sse_grad(np.atleast_2d(W))
+        sig = np.float64(lpinfo['lparams']['sigma'])
+        return -(0.5 * g.double().cpu().numpy() / sig ** 2)
+
+    def logpost(self, modelpars, lpinfo):
+        """float: log-posterior of one flat weight vector (reference signature)."""
+        return float(self.logpost_batch(np.asarray(modelpars).reshape(1, -1), lpinfo)[0])
+
+    def logpostgrad(self, modelpars, lpinfo):
+        """np.ndarray `(p,)`: gradient of the log-posterior (reference signature)."""
+        return self.logpostgrad_batch(np.asarray(modelpars).reshape(1, -1), lpinfo)[0]
+
+    # -- fit -------------------------------------------------------------------------------
+    def fit(self, xtrn, ytrn, zflag=True, datanoise=0.05, nmcmc=6000, param_ini=None, sampler='amcmc',
+            sampler_params=None, *, nchains=1, seeds=None):
+        """Run MCMC over the flat weight vector.
+
+        Args (reference): xtrn `(N,d)`, ytrn `(N,o)`, zflag (BFGS pre-fit of a random start),
+            datanoise (likelihood sigma), nmcmc, param_ini `(p,)` [or `(C,p)`], sampler
+            ('amcmc' | 'hmc' | 'mala'), sampler_params (dict splatted into the sampler).
+        Build-only: nchains (C independent chains in lock-step), seeds (C ints; chain c then
+            equals a reference run preceded by np.random.seed(seeds[c])).  With nchains=1 and
+            seeds=None the global numpy RNG is used, exactly like the reference.
+        """
+        ntrn_, outdim = ytrn.shape
+        assert xtrn.shape[0] == ntrn_
+        self.lpinfo = {'model': None, 'xd': xtrn, 'yd': [y for y in ytrn], 'ltype': 'classical',
+                       'lparams': {'sigma': datanoise}}
+        if seeds is not None:
+            seeds = list(seeds)
+            nchains = len(seeds)
+            rngs = [np.random.RandomState(s) for s in seeds]
+        elif nchains > 1:
+            raise ValueError("nchains > 1 needs seeds=[...] (one per chain)")
+        else:
+            rngs = None
+
+        if param_ini is None:
+            draw = (lambda r: r.rand(self.pdim)) if rngs else (lambda r: np.random.rand(self.pdim))
+            inis = [draw(r) for r in (rngs or [None])]
+            if zflag:
+                inis = [minimize((lambda x, fcn, lpinfo: -fcn(x, lpinfo)), ini, args=(self.logpost, self.lpinfo),
+                                 method='BFGS', options={'gtol': 1e-13}).x for ini in inis]
+            param_ini = np.stack(inis) if rngs else inis[0]
+        param_ini = np.asarray(param_ini, dtype=np.float64)
+        if rngs and param_ini.ndim == 1:
+            param_ini = np.tile(param_ini, (nchains, 1))
+
+        sampler_params = dict(sampler_params)      # None raises, as in the reference
+        if sampler == 'amcmc':
+            mymcmc = AMCMC(**sampler_params)
+            mymcmc.setLogPostBatch(self.logpost_batch, None, lpinfo=self.lpinfo)
+        elif sampler == 'hmc':
+            mymcmc = HMC(**sampler_params)
+            mymcmc.setLogPostBatch(self.logpost_batch, self.logpostgrad_batch, lpinfo=self.lpinfo)
+        elif sampler == 'mala':
+            mymcmc = MALA(**sampler_params)
+            mymcmc.setLogPostBatch(self.logpost_batch, self.logpostgrad_batch, lpinfo=self.lpinfo)
+        else:
+            raise ValueError(f"sampler {sampler!r} is not one of 'amcmc', 'hmc', 'mala'")
+
+        self.mcmc_results = mymcmc.run(nmcmc=nmcmc, param_ini=param_ini, rngs=rngs, verbose=self.verbose)
+        self.samples, self.cmode = self.mcmc_results['chain'], self.mcmc_results['mapparams']
+
+    # -- prediction --------------------------------------------------------------------------
+    def get_best_model(self, param):
+        """A copy of the module carrying the given flat weight vector (nn_mcmc.py:142-154)."""
+        import torch
+        mod = copy.deepcopy(self.nnmodel)
+        s = 0
+        with torch.no_grad():
+            for p in mod.parameters():
+                n = p.numel()
+                p.copy_(torch.as_tensor(np.asarray(param[s:s + n])).view(p.shape).to(p.dtype))
+                s += n
+        return mod
+
+    def predict_sample(self, x, param):
+        """`(N,o)` prediction with one flat weight vector (nn_mcmc.py:168-178)."""
+        return self._predict_batch(np.asarray(param).reshape(1, -1), x)[0]
+
+    def predict_MAP(self, x):
+        cm = self.cmode if np.ndim(self.cmode) == 1 else self.cmode[0]
+        return self.predict_sample(x, cm)
+
+    def predict_ens(self, x, nens=10, nburn=1000, chain=0):
+        """`(M,N,o)`: predictions with M thinned post-burn-in samples, rows
+        nburn + j*int((len-nburn)/nens) of the chain (nn_mcmc.py:194-199) -- one batched
+        forward instead of M sequential ones.  `chain` picks the chain of a multi-chain fit."""
+        samples = self.samples if self.samples.ndim == 2 else self.samples[chain]
+        nevery = int((samples.shape[0] - nburn) / nens)
+        rows = [nburn + j * nevery for j in range(nens)]
+        return self._predict_batch(samples[rows, :], x)
