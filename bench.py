@@ -39,28 +39,36 @@ def synthetic(n, d, noise=0.02, seed=0):
     return x, y
 
 
-def cpu_baseline(arch, x, y, budget_s=15.0):
+def cpu_baseline(arch, x, y, budget_s=16.0):
     """The oracle's sequential float64 path (one eval at a time: unflatten -> Linear/tanh ->
-    NegLogPost -> .item(), as the reference does) on this host's cores; bounded sample."""
+    NegLogPost -> .item(), as the reference does) on this host's cores; bounded sample.
+    Timed with 1 thread and with this box's CPU share (<= 16 threads); the faster is `value`."""
     from oracle import mlp_ref
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
     mod = mlp_ref.build_module(mlp_ref.MLPSpec(arch.dims, arch.activ))
     yd = [v for v in y]
     ws = [0.1 * np.random.RandomState(1000 + c).randn(arch.nparams) for c in range(16)]
-    for i in range(20):
-        mlp_ref.logpost(mod, ws[i % 16], x, yd, SIGMA)
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        mlp_ref.logpost(mod, ws[n % 16], x, yd, SIGMA)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 5000:
-            break
-    return {"value": n / el, "unit": "log-posterior evals/s", "cores": ncores, "kind": "port",
-            "sample": f"{n} sequential float64 evals of the same workload (one chain at a time, "
-                      f"N={x.shape[0]}, 3x64 tanh MLP) in {el:.1f} s, torch threads={ncores}"}
+    share = max(1, min(os.cpu_count() or 1, 16))
+    rates = {}
+    for nt in sorted({1, share}):
+        torch.set_num_threads(nt)
+        for i in range(10):
+            mlp_ref.logpost(mod, ws[i % 16], x, yd, SIGMA)
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            mlp_ref.logpost(mod, ws[n % 16], x, yd, SIGMA)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s / 2 or n >= 4000:
+                break
+        rates[nt] = (n / el, n, el)
+    best = max(rates, key=lambda k: rates[k][0])
+    r, n, el = rates[best]
+    return {"value": r, "unit": "log-posterior evals/s", "cores": best, "kind": "port",
+            "sample": f"{n} sequential float64 evals of the same workload (one chain at a time, N={x.shape[0]}, "
+                      f"3x64 tanh MLP) in {el:.1f} s with {best} torch thread(s); "
+                      + ", ".join(f"{k} thr: {v[0]:.1f}/s" for k, v in sorted(rates.items())),
+            "host_cpus": os.cpu_count()}
 
 
 def main():

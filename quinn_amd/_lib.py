@@ -55,6 +55,10 @@ def lib():
     if not os.path.exists(LIBPATH):
         raise QuinnAmdError(f"{LIBPATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).
+    # It must be the one already mapped when this library is loaded, otherwise the process ends
+    # up with two runtimes and ours sees no device / cannot share torch's streams and memory.
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIBPATH)
     vp, i32, i64, f64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_size_t
     L.qn_mlp_desc_create.argtypes = [ctypes.POINTER(i32), i32, i32, i32, ctypes.POINTER(vp)]

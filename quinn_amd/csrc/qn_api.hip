@@ -253,6 +253,7 @@ extern "C" int qn_vi_sample_kl(const double* mu, const double* rho, const double
         return QN_EINVAL;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
     if (dtype == QN_F64)
         hipLaunchKernelGGL((k_vi_sample_kl<double>), dim3(S), dim3(KLB), 0, st, mu, rho, eps, p, pi, sigma1, sigma2,
                            (double*)W_out, logq_out, logp_out);
@@ -272,6 +273,7 @@ extern "C" int qn_vi_grad(const double* mu, const double* rho, const double* eps
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid((unsigned)((p + BLK - 1) / BLK));
+    (void)hipGetLastError();
     if (dtype == QN_F64)
         hipLaunchKernelGGL((k_vi_grad<double>), grid, dim3(BLK), 0, st, mu, rho, eps, (const double*)gW, S, p, pi,
                            sigma1, sigma2, gw_scale, kl_scale, dmu_out, drho_out);
@@ -295,6 +297,7 @@ extern "C" int qn_adam_batched(double* W, const void* G, double* m, double* v, c
     int nblk = (int)((p + BLK - 1) / BLK);
     if (nblk > 1024) nblk = 1024;
     dim3 grid(nblk, B);
+    (void)hipGetLastError();
     if (dtype == QN_F64)
         hipLaunchKernelGGL((k_adam<double>), grid, dim3(BLK), 0, st, W, (const double*)G, m, v, lr, p, gscale, wd,
                            beta1, beta2, eps, bc1, bc2_sqrt);

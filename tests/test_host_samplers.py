@@ -4,7 +4,7 @@ as the model callable, the batched stepper must reproduce the reference's chains
 import numpy as np
 import pytest
 
-from conftest import load_golden, spec_of
+from conftest import load_golden, spec_of, assert_chain_matches_fixture
 from oracle import mlp_ref
 from quinn_amd.mcmc.admcmc import AMCMC
 from quinn_amd.mcmc.hmc import HMC
@@ -21,10 +21,7 @@ def _closures(g):
 
 
 def _same(res, g, c=None):
-    pick = (lambda a: a) if c is None else (lambda a: a[c])
-    for k in ("chain", "logpost", "alphas", "mapparams"):
-        assert np.array_equal(pick(res[k]), g[k] if c is None else g[k][c], equal_nan=True), k
-    assert float(pick(res["accrate"])) == float(g["accrate"] if c is None else g["accrate"][c])
+    assert_chain_matches_fixture(res, g, c)
 
 
 @pytest.mark.parametrize("exact", [False, True])
@@ -37,7 +34,15 @@ def test_amcmc_single_chain_global_rng(exact):
     mc.setLogPost(lp, None)
     res = mc.run(int(g["nmcmc"]), ini, verbose=False)
     _same(res, g)
-    assert res["maxpost"] == float(g["maxpost"])
+    # and bit-exact against the oracle stepping the same chain on this host
+    from oracle import mcmc_ref
+    rng = np.random.RandomState(int(g["seed"]))
+    ini2 = rng.rand(spec.nparams)
+    ref = mcmc_ref.run_chain(lp, mcmc_ref.AmcmcState(gamma=float(g["gamma"]), t0=int(g["t0"]), tadapt=int(g["tadapt"])),
+                             int(g["nmcmc"]), ini2, rng)
+    for k in ("chain", "logpost", "alphas", "mapparams"):
+        assert np.array_equal(res[k], ref[k], equal_nan=True), k
+    assert res["maxpost"] == ref["maxpost"] and res["accrate"] == ref["accrate"]
 
 
 def test_amcmc_lockstep_multichain():
@@ -62,9 +67,7 @@ def test_hmc_matches_reference(name):
     mc = HMC(epsilon=float(g["epsilon"]), L=int(g["L"]))
     mc.setLogPost(lp, lg)
     res = mc.run(int(g["nmcmc"]), ini.reshape(1, -1), rngs=[rng], verbose=False)
-    _same(res, g, None if False else 0) if False else None
-    for k in ("chain", "logpost", "alphas"):
-        assert np.array_equal(res[k][0], g[k], equal_nan=True), k
+    _same({k: v[0] for k, v in res.items()}, g)
 
 
 def test_mala_matches_reference():
