@@ -109,6 +109,9 @@ int qn_adam_batched(double* W, const void* G, double* m, double* v, const double
                     int64_t p, int dtype, double gscale, double wd, double beta1, double beta2,
                     double eps, int step, void* stream);
 
+/* Diagnostic: y[i] = device tanh(x[i]) in float64 (the activation used by every kernel). */
+int qn_debug_tanh(const double* x, double* y, int64_t n, void* stream);
+
 const char* qn_last_error(void);
 /* "quinn_amd <version> gfx950" */
 const char* qn_version(void);

@@ -20,7 +20,7 @@ PATH_AUTO, PATH_GENERIC, PATH_FUSED = 0, 1, 2
 # every symbol include/quinn_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = ["qn_mlp_desc_create", "qn_mlp_desc_destroy", "qn_mlp_num_params", "qn_workspace_bytes",
            "qn_mlp_path", "qn_set_path", "qn_mlp_sse_fwd", "qn_mlp_sse_fwdbwd", "qn_vi_sample_kl",
-           "qn_vi_grad", "qn_adam_batched", "qn_last_error", "qn_version"]
+           "qn_vi_grad", "qn_adam_batched", "qn_debug_tanh", "qn_last_error", "qn_version"]
 
 
 class QuinnAmdError(RuntimeError):
@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
     """Compile the HIP sources for gfx950 into quinn_amd/lib/libquinn_amd.so (hipcc
     cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "qn_common.h"), os.path.join(_HERE, "..", "include", "quinn_amd.h")]
+    deps = srcs + [os.path.join(CSRC, "qn_common.h"), os.path.join(CSRC, "qn_math.h"), os.path.join(_HERE, "..", "include", "quinn_amd.h")]
     if not force and os.path.exists(LIBPATH):
         if os.path.getmtime(LIBPATH) >= max(os.path.getmtime(d) for d in deps):
             return LIBPATH
@@ -83,6 +83,8 @@ def lib():
     L.qn_vi_grad.restype = i32
     L.qn_adam_batched.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, f64, f64, f64, f64, f64, i32, vp]
     L.qn_adam_batched.restype = i32
+    L.qn_debug_tanh.argtypes = [vp, vp, i64, vp]
+    L.qn_debug_tanh.restype = i32
     L.qn_last_error.restype = ctypes.c_char_p
     L.qn_version.restype = ctypes.c_char_p
     _lib = L

@@ -1,6 +1,7 @@
 // C-ABI entry points (include/quinn_amd.h): descriptor, dispatch between the kernel
 // families, and the small elementwise kernels of the VI / ensemble trainers.
 #include "qn_common.h"
+#include "qn_math.h"
 #include <cmath>
 #include <cstring>
 
@@ -304,6 +305,27 @@ extern "C" int qn_adam_batched(double* W, const void* G, double* m, double* v, c
     else
         hipLaunchKernelGGL((k_adam<float>), grid, dim3(BLK), 0, st, W, (const float*)G, m, v, lr, p, gscale, wd,
                            beta1, beta2, eps, bc1, bc2_sqrt);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Diagnostic: the device tanh on an array (accuracy tests of qn_math.h).
+namespace {
+__global__ void k_tanh_f64(const double* __restrict__ x, double* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = qn_tanh_f64(x[i]);
+}
+}  // namespace
+
+extern "C" int qn_debug_tanh(const double* x, double* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0) {
+        qn_set_error("qn_debug_tanh: bad argument");
+        return QN_EINVAL;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_tanh_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       y, n);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }

@@ -9,14 +9,15 @@
 // This family is the always-correct fallback; qn_fused.hip is the MFMA path for
 // LDS-resident weights.
 #include "qn_common.h"
+#include "qn_math.h"
 
 namespace {
 
 constexpr int BLK = 256;
 
 template <typename T> __device__ __forceinline__ T qn_tanh(T x);
-template <> __device__ __forceinline__ double qn_tanh<double>(double x) { return tanh(x); }
-template <> __device__ __forceinline__ float qn_tanh<float>(float x) { return tanhf(x); }
+template <> __device__ __forceinline__ double qn_tanh<double>(double x) { return qn_tanh_f64(x); }
+template <> __device__ __forceinline__ float qn_tanh<float>(float x) { return qn_tanh_f32(x); }
 
 template <typename T> __device__ __forceinline__ T apply_act(T z, int act) {
     if (act == QN_ACT_TANH) return qn_tanh<T>(z);

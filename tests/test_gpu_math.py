@@ -1,0 +1,45 @@
+"""GPU: accuracy of the device float64 tanh (quinn_amd/csrc/qn_math.h) against a
+high-precision reference (numpy longdouble / mpmath-free: tanh via expm1 in float128)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from quinn_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_tanh(x):
+    xl = x.astype(np.longdouble)
+    e = np.expm1(-2 * np.abs(xl))
+    return (np.sign(xl) * (-e / (2 + e))).astype(np.longdouble)
+
+
+def test_tanh_f64_ulp_error():
+    rs = np.random.RandomState(0)
+    xs = np.concatenate([rs.uniform(-20, 20, 200000), rs.uniform(-1, 1, 200000), rs.uniform(-1e-3, 1e-3, 50000),
+                         10.0 ** rs.uniform(-300, -3, 20000), np.array([0.0, -0.0, 19.0, 19.07, 25.0, -40.0, 1e300,
+                                                                           -1e300, np.inf, -np.inf, 5e-324, 0.5493061443340549])])
+    x = torch.tensor(xs, device="cuda")
+    y = torch.empty_like(x)
+    L = _lib.lib()
+    _lib.check(L.qn_debug_tanh(x.data_ptr(), y.data_ptr(), x.numel(), None), "qn_debug_tanh")
+    torch.cuda.synchronize()
+    got = y.cpu().numpy()
+    ref = _ref_tanh(xs)
+    ulp = np.spacing(np.abs(ref.astype(np.float64)))
+    err = np.abs(got.astype(np.longdouble) - ref) / np.maximum(ulp, 5e-324)
+    assert err.max() < 3.0, (err.max(), xs[np.argmax(err)])
+    assert np.mean(err) < 0.7
+    assert got[np.where(xs == np.inf)[0][0]] == 1.0 and got[np.where(xs == -np.inf)[0][0]] == -1.0
+    assert np.signbit(got[np.where(xs == 0.0)[0][1]])          # tanh(-0.0) = -0.0
+    z = torch.tensor([np.nan], device="cuda", dtype=torch.float64)
+    w = torch.empty_like(z)
+    _lib.check(L.qn_debug_tanh(z.data_ptr(), w.data_ptr(), 1, None), "qn_debug_tanh")
+    assert torch.isnan(w).all()
+    # against torch's CPU tanh (what the reference computes with): a few ulp at most
+    tref = torch.tanh(torch.tensor(xs)).numpy()
+    fin = np.isfinite(xs)
+    assert np.max(np.abs(got[fin] - tref[fin]) / ulp[fin]) < 4.0
