@@ -20,6 +20,15 @@ class MLPBase(torch.nn.Module):
         self.history = None
         self.device = device
 
+    def fit(self, xtrn, ytrn, **kwargs):
+        """Train with `nnfit`; keeps the best model and the loss history (nnbase.py:95-115)."""
+        from .nnfit import nnfit
+        fit_info = nnfit(self, xtrn, ytrn, **kwargs)
+        object.__setattr__(self, 'best_model', fit_info['best_nnmodel'])
+        self.history = fit_info['history']
+        self.trained = True
+        return self.best_model
+
     def numpar(self):
         return sum(p.numel() for p in self.parameters())
 
