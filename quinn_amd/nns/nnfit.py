@@ -61,13 +61,14 @@ def draw_perms(nmembers, nepochs, ntrn):
 
 def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lrate=0.1, wd=0.0,
                 optimizer='adam', loss_fn='mse', datanoise=None, lmbd=None, perm_mode='reference',
-                device=None, dtype='float64', freq_out=100, verbose=True):
+                device=None, dtype='float64', freq_out=100, verbose=True, perms=None):
     """Train M members in lock-step.
 
     Args:
         arch (MLPArch); W0 [M,p] initial flat weights; xtrn (N,d), ytrn (N,o): the FULL dataset;
         rows [M, ntrn] int: the dataset rows member j trains on; xval, yval: validation set
-        shared by all members; the rest as in `nnfit`.
+        shared by all members; perms: optional precomputed [M, nepochs, ntrn] permutations (a shard of
+        `draw_perms` when members are split over ranks); the rest as in `nnfit`.
     Returns:
         dict with per-member arrays: 'best_w' [M,p], 'final_w' [M,p], 'best_loss' [M],
         'best_epoch' [M], 'best_fepoch' [M], 'history' [M, nupdates, 4].
@@ -104,7 +105,7 @@ def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lra
     v = torch.zeros_like(W)
     rows_d = torch.as_tensor(rows, device=dev, dtype=torch.int64)
     if perm_mode == 'reference':
-        perms = torch.as_tensor(draw_perms(M, nepochs, ntrn), device=dev)
+        perms = torch.as_tensor(draw_perms(M, nepochs, ntrn) if perms is None else perms, device=dev)
     nsub = len(range(0, ntrn, batch_size))
     nupd = nepochs * nsub
     hist = torch.zeros(M, nupd, 4, dtype=torch.float64, device=dev)

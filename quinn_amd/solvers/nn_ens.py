@@ -12,7 +12,8 @@ import copy
 import numpy as np
 
 from ..ens.learner import Learner
-from ..nns.nnfit import fit_members, load_flat_into
+from ..nns.nnfit import fit_members, load_flat_into, draw_perms
+from ..parallel import shard_bounds, all_gather_rows, dist_info
 from ..ops import flatten_module
 from .quinn import QUiNNBase
 
@@ -48,9 +49,17 @@ class NN_Ens(QUiNNBase):
         if kwargs.pop('scheduler_lr', None) is not None or kwargs.pop('priorparams', None) is not None:
             raise NotImplementedError("schedulers / priors are not part of the accelerated path yet")
         w0 = flatten_module(self.learners[0].nnmodel)
-        res = fit_members(self.arch, np.tile(w0, (self.nens, 1)), xtrn, ytrn, rows, xval, yval,
-                          kwargs.pop('nepochs', 5000), kwargs.pop('batch_size', None), device=self._device,
-                          dtype=self._dtype, verbose=self.verbose, **kwargs)
+        nepochs = kwargs.pop('nepochs', 5000)
+        # members shard over ranks (torch.distributed); every rank consumes the random streams of ALL
+        # members in the reference's order, trains its block, and ONE all_gather returns the results
+        lo, hi = shard_bounds(self.nens)
+        perms = None
+        if kwargs.get('perm_mode', 'reference') == 'reference':
+            perms = draw_perms(self.nens, nepochs, rows.shape[1])[lo:hi]
+        res = fit_members(self.arch, np.tile(w0, (hi - lo, 1)), xtrn, ytrn, rows[lo:hi], xval, yval, nepochs,
+                          kwargs.pop('batch_size', None), device=self._device, dtype=self._dtype,
+                          verbose=self.verbose and dist_info()[0] == 0, perms=perms, **kwargs)
+        res = {k: all_gather_rows(v, self.nens) for k, v in res.items()}
         self.fit_results = res
         self._best_w = res['best_w']
         for j, learner in enumerate(self.learners):

@@ -19,6 +19,7 @@ from ..mcmc.admcmc import AMCMC
 from ..mcmc.hmc import HMC
 from ..mcmc.mala import MALA
 from ..ops import BatchedMLP, neg_log_post_from_sse
+from ..parallel import dist_info, run_chains_sharded
 from .quinn import QUiNNBase
 
 
@@ -130,7 +131,11 @@ class NN_MCMC(QUiNNBase):
         else:
             raise ValueError(f"sampler {sampler!r} is not one of 'amcmc', 'hmc', 'mala'")
 
-        self.mcmc_results = mymcmc.run(nmcmc=nmcmc, param_ini=param_ini, rngs=rngs, verbose=self.verbose)
+        if rngs is not None and dist_info()[1] > 1:
+            # chains shard over ranks; one all_gather of the result arrays at the end
+            self.mcmc_results = run_chains_sharded(lambda: mymcmc, nmcmc, param_ini, seeds, verbose=False)
+        else:
+            self.mcmc_results = mymcmc.run(nmcmc=nmcmc, param_ini=param_ini, rngs=rngs, verbose=self.verbose)
         self.samples, self.cmode = self.mcmc_results['chain'], self.mcmc_results['mapparams']
 
     # -- prediction --------------------------------------------------------------------------

@@ -1,0 +1,63 @@
+"""Worker for tests/test_dist_gloo.py: launched by torch.distributed.run with world_size 2 on the
+CPU (gloo).  Exercises the N>1 path: chains sharded over ranks, per-chain random streams, ONE
+all_gather at the end; results must equal the single-process run and the reference fixture."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from conftest import load_golden, spec_of, assert_chain_matches_fixture  # noqa: E402
+from oracle import mlp_ref  # noqa: E402
+from quinn_amd.mcmc.admcmc import AMCMC  # noqa: E402
+from quinn_amd.parallel import all_gather_rows, run_chains_sharded, shard_bounds  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.set_num_threads(1)
+    # 1. uneven gather
+    n = 5
+    lo, hi = shard_bounds(n)
+    local = np.arange(lo, hi, dtype=np.float64)[:, None] * np.ones((1, 3))
+    full = all_gather_rows(local, n)
+    assert full.shape == (5, 3) and np.array_equal(full[:, 0], np.arange(5.0)), full
+    assert [shard_bounds(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+    # 2. sharded chains == fixture == single-process lock-step
+    g = load_golden("g8_multichain.npz")
+    spec = spec_of(g)
+    mod = mlp_ref.build_module(spec)
+    yd = [v for v in g["y"]]
+    lp = lambda w: mlp_ref.logpost(mod, w, g["x"], yd, float(g["sigma"]))
+    C = int(g["nchains"])
+    seeds = [int(g["seed0"]) + c for c in range(C)]
+
+    def make():
+        mc = AMCMC(gamma=float(g["gamma"]), t0=int(g["t0"]), tadapt=int(g["tadapt"]))
+        mc.setLogPost(lp, None)
+        mc.pdim = spec.nparams
+        return mc
+    res = run_chains_sharded(make, int(g["nmcmc"]), None, seeds)
+    assert res["chain"].shape == g["chain"].shape
+    for c in range(C):
+        assert_chain_matches_fixture(res, g, c)
+    if rank == 0:
+        rngs = [np.random.RandomState(s) for s in seeds]
+        ini = np.stack([r.rand(spec.nparams) for r in rngs])
+        single = make().run(int(g["nmcmc"]), ini, rngs=rngs, verbose=False)
+        for k in ("chain", "logpost", "alphas", "accrate", "mapparams", "maxpost"):
+            assert np.array_equal(res[k], single[k], equal_nan=True), k
+    dist.barrier()
+    with open(os.path.join(os.environ["QN_DIST_OUT"], f"ok_{rank}"), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
