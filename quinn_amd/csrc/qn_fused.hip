@@ -226,6 +226,381 @@ __global__ __launch_bounds__(WG, 2) void k_fused_fwd_f64(FusedArgs a, const doub
     }
 }
 
+
+// =============================================================================================
+// Fused forward + backward (float64): gradient of the SSE w.r.t. every weight, per chain.
+//
+// One workgroup = 4 waves = 64 data rows per iteration (one 16-row group per wave), one chain.
+// Forward as above, but every hidden activation a_1..a_NH stays in registers.  Backward, per layer:
+//   dA^T = W^T . dZ^T        MFMA; A operand = transposed W fragment straight from the swizzled LDS
+//                            image (conflict-free), B operand = dZ in accumulator layout -> registers
+//   dW  += dZ^T . A          the contraction runs over DATA ROWS, which sit on the lane index in the
+//                            accumulator layout, so dZ and A are transposed through two LDS stashes
+//                            SD, SA ([feature][64 rows + 2], stride 66 -> conflict-free fragment
+//                            reads); wave w owns output tiles {w, w+4, ...} and accumulates them in
+//                            registers over all iterations of the workgroup
+//   db, dW_first, dW_last    column sums over the stashes on the VALU (thread = (feature, row part))
+// At the end each workgroup writes its partial gradient to a slab [B][nsplit][p]; k_grad_reduce sums
+// the slabs in a fixed order (bitwise reproducible).  LDS at 3x64: 68.7 KB image + 2 x 33.8 KB
+// stashes -> one workgroup per CU, one wave per SIMD (the DP pipe is serial anyway, section 4.1 of
+// DESIGN.md).
+constexpr int NHMAX = 4;
+constexpr int ROWS_IT = 64;          // rows per workgroup iteration in the backward kernel
+constexpr int NSP = ROWS_IT + 2;     // stash row stride (doubles)
+
+__host__ __device__ inline int bwd_lds_doubles(int H, int dp, int o, int nhid) {
+    return lds_doubles(H, dp, o, nhid) + 2 * H * NSP + ROWS_IT * dp + ROWS_IT * OMAX + 8;
+}
+
+// activation of one 16x16 tile (4 values per lane); the switch is wave-uniform and sits OUTSIDE the
+// element loop, the sched_barrier keeps the scheduler from interleaving more than one tile's tanh
+// chains (register pressure)
+__device__ __forceinline__ void act_tile(const v4d& z, double (&out)[4], int act) {
+    if (act == QN_ACT_TANH) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = qn_tanh_f64(z[i]);
+    } else if (act == QN_ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = z[i] > 0.0 ? z[i] : 0.0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = z[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ double act_deriv_rt(double aout, int act) {
+    return act == QN_ACT_TANH ? 1.0 - aout * aout : (act == QN_ACT_RELU ? (aout > 0.0 ? 1.0 : 0.0) : 1.0);
+}
+
+template <int H, int NH, int DP>
+__global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const double* __restrict__ W,
+                                                         const double* __restrict__ X, const double* __restrict__ Y,
+                                                         const int32_t* __restrict__ row_idx,
+                                                         double* __restrict__ pred_out, double* __restrict__ partial,
+                                                         double* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    constexpr int T = H / 16;
+    constexpr int S = stride_of(H);
+    constexpr int TT = T * T;
+    constexpr int TPW = (TT + 3) / 4;            // dW tiles per wave
+    constexpr int TPF = WG / H;                  // threads per feature in the column sums
+    constexpr int RPT = ROWS_IT / TPF;           // rows per such thread
+    const int b = blockIdx.y, split = blockIdx.x;
+    const int d = a.d, o = a.o, act_kind = a.act;
+    const int nb = a.has_bias ? 1 : 0;
+    const int offW0 = 0, offb0 = H * DP, offHH = offb0 + H;
+    const int offWl = offHH + (NH - 1) * (H * S + H), offbl = offWl + o * H;
+    const int img = lds_doubles(H, DP, o, NH);
+    double* SA = lds + ((img + 1) & ~1);
+    double* SD = SA + H * NSP;
+    double* Sx = SD + H * NSP;
+    double* Sdl = Sx + ROWS_IT * DP;
+    double* red = Sdl + ROWS_IT * OMAX;
+
+    stage_weights<H, DP>(lds, W + (int64_t)b * a.p, a);
+    __syncthreads();
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    const int fl = swz(c);
+    int swq[4];                                   // swz(4*s + q) for s & 3 = 0..3
+#pragma unroll
+    for (int m = 0; m < 4; ++m) swq[m] = swz(4 * m + q);
+    const int fj = tid / TPF, part = tid % TPF;   // column-sum role
+    const int wrow = wave * 16 + c;               // this lane's row inside the 64-row tile
+
+    double sse = 0.0;
+    v4d dWacc[NH > 1 ? NH - 1 : 1][TPW];
+#pragma unroll
+    for (int l = 0; l < (NH > 1 ? NH - 1 : 1); ++l)
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) dWacc[l][u] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double dbacc[NH];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) dbacc[k] = 0.0;
+    double dW0acc[DP], dWlacc[OMAX], dblacc = 0.0;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) dW0acc[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < OMAX; ++k) dWlacc[k] = 0.0;
+
+    for (int it = 0; it < a.iters; ++it) {
+        const int n = split * a.rows_per_split + it * ROWS_IT + wrow;
+        const bool valid = n < a.Nb;
+        const int nn = valid ? n : 0;
+        const int64_t rrow = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
+        double xk[DP];
+#pragma unroll
+        for (int k = 0; k < DP; ++k) xk[k] = k < d ? X[rrow * d + k] : 0.0;
+        // ------------------------------------------------------------------ forward
+        double act[NH][T][4];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            v4d z;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = 16 * t + q + 4 * i;
+                z[i] = lds[offb0 + j];
+#pragma unroll
+                for (int k = 0; k < DP; ++k) z[i] = fma(lds[offW0 + j * DP + k], xk[k], z[i]);
+            }
+            act_tile(z, act[0][t], act_kind);
+        }
+#pragma unroll
+        for (int layer = 1; layer < NH; ++layer) {
+            {
+                const double* Wl = lds + offHH + (layer - 1) * (H * S + H);
+                const double* bl = Wl + H * S;
+                v4d acc[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t][i] = bl[16 * t + q + 4 * i];
+                double wf[T], wn[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) wn[t] = Wl[(16 * t + c) * S + (q ^ fl)];
+#pragma unroll
+                for (int s = 0; s < H / 4; ++s) {       // fragments of step s+1 are in flight under the MFMAs of step s
+#pragma unroll
+                    for (int t = 0; t < T; ++t) wf[t] = wn[t];
+                    if (s + 1 < H / 4) {
+                        const int col = (4 * (s + 1) + q) ^ fl;
+#pragma unroll
+                        for (int t = 0; t < T; ++t) wn[t] = Wl[(16 * t + c) * S + col];
+                    }
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[t], act[layer - 1][s >> 2][s & 3], acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int t = 0; t < T; ++t) act_tile(acc[t], act[layer][t], act_kind);
+            }
+        }
+        double (&alast)[T][4] = act[NH - 1];
+        // ------------------------------------------------------------------ last layer, residual
+        double delta[OMAX];
+#pragma unroll
+        for (int qo = 0; qo < OMAX; ++qo) {
+            delta[qo] = 0.0;
+            if (qo < o) {
+                double pd = 0.0;
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pd = fma(lds[offWl + qo * H + 16 * t + q + 4 * i], alast[t][i], pd);
+                pd += __shfl_xor(pd, 16, 64);
+                pd += __shfl_xor(pd, 32, 64);
+                const double pr = pd + lds[offbl + qo];
+                const double res = pr - Y[rrow * o + qo];
+                if (valid) {
+                    delta[qo] = 2.0 * res;
+                    if (q == 0) {
+                        sse += res * res;
+                        if (pred_out) pred_out[((int64_t)b * a.Nb + n) * o + qo] = pr;
+                    }
+                }
+            }
+        }
+        // ------------------------------------------------------------------ backward: last layer
+        __syncthreads();                                   // previous iteration's stash readers are done
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) SA[(16 * t + q + 4 * i) * NSP + wrow] = alast[t][i];
+        if (q == 0) {
+#pragma unroll
+            for (int qo = 0; qo < OMAX; ++qo) Sdl[wrow * OMAX + qo] = delta[qo];
+#pragma unroll
+            for (int k = 0; k < DP; ++k) Sx[wrow * DP + k] = xk[k];
+        }
+        __syncthreads();
+        {
+            double sum[OMAX] = {0.0, 0.0, 0.0, 0.0};
+            for (int rr = 0; rr < RPT; ++rr) {
+                const int row = part * RPT + rr;
+                const double av = SA[fj * NSP + row];
+#pragma unroll
+                for (int qo = 0; qo < OMAX; ++qo) sum[qo] = fma(av, Sdl[row * OMAX + qo], sum[qo]);
+            }
+#pragma unroll
+            for (int qo = 0; qo < OMAX; ++qo) dWlacc[qo] += sum[qo];
+            if (tid < o) {
+                double sb = 0.0;
+                for (int row = 0; row < ROWS_IT; ++row) sb += Sdl[row * OMAX + tid];
+                dblacc += sb;
+            }
+        }
+        double dz[T][4];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double g = 0.0;
+#pragma unroll
+                for (int qo = 0; qo < OMAX; ++qo)
+                    if (qo < o) g = fma(lds[offWl + qo * H + 16 * t + q + 4 * i], delta[qo], g);
+                dz[t][i] = g * act_deriv_rt(alast[t][i], act_kind);
+            }
+        // ------------------------------------------------------------------ backward: hidden -> hidden layers
+#pragma unroll
+        for (int layer = NH - 1; layer >= 1; --layer) {
+            {
+                const double* Wl = lds + offHH + (layer - 1) * (H * S + H);
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        SD[(16 * t + q + 4 * i) * NSP + wrow] = dz[t][i];
+                        SA[(16 * t + q + 4 * i) * NSP + wrow] = act[layer - 1][t][i];
+                    }
+                __syncthreads();
+                // dW_layer tiles owned by this wave, contraction over the 64 rows of the tile
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    const int tile = wave + 4 * u;
+                    if (tile < TT) {
+                        const int tj = tile / T, ti = tile % T;
+                        const double* pa = SD + (16 * tj + c) * NSP + q;
+                        const double* pb = SA + (16 * ti + c) * NSP + q;
+#pragma unroll
+                        for (int s4 = 0; s4 < ROWS_IT / 16; ++s4) {
+                            double fa[4], fb[4];
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) { fa[m] = pa[16 * s4 + 4 * m]; fb[m] = pb[16 * s4 + 4 * m]; }
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+                                dWacc[layer - 1][u] =
+                                    __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], fb[m], dWacc[layer - 1][u], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                {   // bias gradient of this layer: column sums of dZ
+                    double sb = 0.0;
+                    for (int rr = 0; rr < RPT; ++rr) sb += SD[fj * NSP + part * RPT + rr];
+                    dbacc[layer] += sb;
+                }
+                // dA = W^T dZ (transposed fragment reads of the same LDS image), then dZ of the layer below
+                v4d nd[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) nd[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+                double tf[T], tn[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) tn[t] = Wl[q * S + ((16 * t + c) ^ swq[0])];
+#pragma unroll
+                for (int s = 0; s < H / 4; ++s) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) tf[t] = tn[t];
+                    if (s + 1 < H / 4) {
+                        const double* wrow_p = Wl + (4 * (s + 1) + q) * S;
+                        const int sw = swq[(s + 1) & 3];
+#pragma unroll
+                        for (int t = 0; t < T; ++t) tn[t] = wrow_p[(16 * t + c) ^ sw];
+                    }
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+                        nd[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[t], dz[s >> 2][s & 3], nd[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dz[t][i] = nd[t][i] * act_deriv_rt(act[layer - 1][t][i], act_kind);
+            }
+        }
+        // ------------------------------------------------------------------ backward: first layer
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) SD[(16 * t + q + 4 * i) * NSP + wrow] = dz[t][i];
+        __syncthreads();
+        {
+            double sb = 0.0, sw0[DP];
+#pragma unroll
+            for (int k = 0; k < DP; ++k) sw0[k] = 0.0;
+            for (int rr = 0; rr < RPT; ++rr) {
+                const int row = part * RPT + rr;
+                const double g = SD[fj * NSP + row];
+                sb += g;
+#pragma unroll
+                for (int k = 0; k < DP; ++k) sw0[k] = fma(g, Sx[row * DP + k], sw0[k]);
+            }
+            dbacc[0] += sb;
+#pragma unroll
+            for (int k = 0; k < DP; ++k) dW0acc[k] += sw0[k];
+        }
+    }
+
+    // ---------------------------------------------------------------------- write the partial gradient
+    double* out = slab + ((int64_t)b * a.nsplit + split) * a.p;
+    const int64_t gW0 = 0, gb0 = (int64_t)H * d, gHH = gb0 + nb * H;
+    const int64_t gWl = gHH + (int64_t)(NH - 1) * (H * H + nb * H), gbl = gWl + (int64_t)o * H;
+    // column-sum accumulators: add up the TPF threads of a feature (adjacent lanes)
+#pragma unroll
+    for (int m = 1; m < TPF; m <<= 1) {
+#pragma unroll
+        for (int k = 0; k < NH; ++k) dbacc[k] += __shfl_xor(dbacc[k], m, 64);
+#pragma unroll
+        for (int k = 0; k < DP; ++k) dW0acc[k] += __shfl_xor(dW0acc[k], m, 64);
+#pragma unroll
+        for (int k = 0; k < OMAX; ++k) dWlacc[k] += __shfl_xor(dWlacc[k], m, 64);
+    }
+    if (part == 0) {
+#pragma unroll
+        for (int k = 0; k < DP; ++k)
+            if (k < d) out[gW0 + (int64_t)fj * d + k] = dW0acc[k];
+        if (nb) {
+            out[gb0 + fj] = dbacc[0];
+#pragma unroll
+            for (int layer = 1; layer < NH; ++layer)
+                out[gHH + (int64_t)(layer - 1) * (H * H + H) + H * H + fj] = dbacc[layer];
+        }
+#pragma unroll
+        for (int qo = 0; qo < OMAX; ++qo)
+            if (qo < o) out[gWl + (int64_t)qo * H + fj] = dWlacc[qo];
+    }
+    if (nb && tid < o) out[gbl + tid] = dblacc;
+#pragma unroll
+    for (int layer = 1; layer < NH; ++layer) {
+        {
+            double* og = out + gHH + (int64_t)(layer - 1) * (H * H + nb * H);
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                const int tile = wave + 4 * u;
+                if (tile < TT) {
+                    const int tj = tile / T, ti = tile % T;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) og[(int64_t)(16 * tj + q + 4 * r) * H + 16 * ti + c] = dWacc[layer - 1][u][r];
+                }
+            }
+        }
+    }
+    sse = wave_sum(sse);
+    __syncthreads();
+    if (lane == 0) red[wave] = sse;
+    __syncthreads();
+    if (tid == 0) {
+        double sum = 0.0;
+        for (int w = 0; w < WG / 64; ++w) sum += red[w];
+        partial[(int64_t)b * a.nsplit + split] = sum;
+    }
+}
+
+// gradW[b][e] = sum over the nsplit slabs, fixed order
+__global__ __launch_bounds__(256) void k_grad_reduce(const double* __restrict__ slab, int nsplit, int64_t p, int B,
+                                                     double* __restrict__ gradW) {
+    const int b = blockIdx.y;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < p; e += (int64_t)gridDim.x * 256) {
+        double sacc = 0.0;
+        for (int k = 0; k < nsplit; ++k) sacc += slab[((int64_t)b * nsplit + k) * p + e];
+        gradW[(int64_t)b * p + e] = sacc;
+    }
+}
+
 __global__ void k_sum_partials(const double* __restrict__ partial, int n, int B, double* __restrict__ out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -246,10 +621,12 @@ bool uniform_hidden(const qn_desc* d, int* H, int* nhid) {
 
 constexpr int G_FWD = 2;
 
-void plan(const qn_desc* d, int B, int Nb, int G, FusedArgs* a) {
-    const int rows_it = (WG / 64) * 16 * G;              // rows one workgroup covers per iteration
+void plan(const qn_desc* d, int B, int Nb, int want_grad, FusedArgs* a) {
+    // rows one workgroup covers per iteration; target workgroups per chip: 2/CU forward, 1/CU backward
+    const int rows_it = want_grad ? ROWS_IT : (WG / 64) * 16 * G_FWD;
+    const int target = want_grad ? 256 : 512;
     const int max_split = (Nb + rows_it - 1) / rows_it;
-    int nsplit = (512 + B - 1) / B;                      // aim at >= 2 workgroups per CU
+    int nsplit = (target + B - 1) / B;
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
     int rps = (Nb + nsplit - 1) / nsplit;
@@ -260,63 +637,102 @@ void plan(const qn_desc* d, int B, int Nb, int G, FusedArgs* a) {
     a->iters = rps / rows_it;
 }
 
-}  // namespace
-
-bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
-    int H, nhid;
-    if (dtype != QN_F64 || want_grad) return false;
-    if (!uniform_hidden(d, &H, &nhid)) return false;
-    if (H != 16 && H != 32 && H != 64) return false;
-    if (d->dims[0] > DMAX || d->dims[d->nlayers] > OMAX) return false;
-    const size_t bytes = (size_t)lds_doubles(H, padded_d(d->dims[0]), d->dims[d->nlayers], nhid) * sizeof(double);
-    return bytes <= 150 * 1024;
+size_t lds_need(int H, int d, int o, int nhid, int want_grad) {
+    return sizeof(double) * (size_t)(want_grad ? bwd_lds_doubles(H, 4, o, nhid) : lds_doubles(H, padded_d(d), o, nhid));
 }
 
-size_t qn_fused_workspace(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
-    FusedArgs a;
-    plan(d, B, Nb, G_FWD, &a);
-    return qn_align((size_t)B * a.nsplit * sizeof(double)) + 256;
-}
+using fwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*);
+using bwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*,
+                        double*);
 
-int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, const void* Y, const int32_t* row_idx,
-                 int B, int N, int Nb, double* sse, void* pred, void* gradW, void* ws, size_t ws_bytes,
-                 hipStream_t st) {
-    int H, nhid;
-    if (!uniform_hidden(d, &H, &nhid) || gradW || dtype != QN_F64) {
-        qn_set_error("qn_fused_run: unsupported configuration");
-        return QN_EUNSUPPORTED;
-    }
-    FusedArgs a;
-    a.p = d->p; a.B = B; a.N = N; a.Nb = Nb; a.d = d->dims[0]; a.o = d->dims[d->nlayers]; a.nhid = nhid;
-    a.act = d->act; a.has_bias = d->has_bias;
-    plan(d, B, Nb, G_FWD, &a);
-    const size_t need = qn_align((size_t)B * a.nsplit * sizeof(double));
-    if (need > ws_bytes) {
-        qn_set_error("workspace too small: need %zu bytes, got %zu", need, ws_bytes);
-        return QN_EWORKSPACE;
-    }
-    double* partial = static_cast<double*>(ws);
-    const int dp = padded_d(a.d);
-    const size_t lds_bytes = (size_t)lds_doubles(H, dp, a.o, nhid) * sizeof(double);
-    dim3 grid(a.nsplit, B);
-    (void)hipGetLastError();
-    using fwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*);
-    fwd_fn kern = nullptr;
-#define QN_PICK(HH, AA, DD) if (H == HH && a.act == AA && dp == DD) kern = k_fused_fwd_f64<HH, G_FWD, AA, DD>;
+fwd_fn pick_fwd(int H, int act, int dp) {
+#define QN_PICK(HH, AA, DD) if (H == HH && act == AA && dp == DD) return k_fused_fwd_f64<HH, G_FWD, AA, DD>;
 #define QN_PICK_H(HH)                                                                          \
     QN_PICK(HH, QN_ACT_TANH, 2) QN_PICK(HH, QN_ACT_TANH, 4) QN_PICK(HH, QN_ACT_RELU, 2)        \
     QN_PICK(HH, QN_ACT_RELU, 4) QN_PICK(HH, QN_ACT_IDENTITY, 2) QN_PICK(HH, QN_ACT_IDENTITY, 4)
     QN_PICK_H(16) QN_PICK_H(32) QN_PICK_H(64)
 #undef QN_PICK_H
 #undef QN_PICK
-    if (!kern) {
-        qn_set_error("qn_fused_run: no kernel instance for H=%d act=%d", H, a.act);
+    return nullptr;
+}
+
+bwd_fn pick_bwd(int H, int nhid) {
+#define QN_PICK(HH, NN) if (H == HH && nhid == NN) return k_fused_bwd_f64<HH, NN, 4>;
+    QN_PICK(16, 1) QN_PICK(16, 2) QN_PICK(16, 3) QN_PICK(16, 4)
+    QN_PICK(32, 1) QN_PICK(32, 2) QN_PICK(32, 3) QN_PICK(32, 4)
+    QN_PICK(64, 1) QN_PICK(64, 2) QN_PICK(64, 3)
+#undef QN_PICK
+    return nullptr;
+}
+
+}  // namespace
+
+bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
+    int H, nhid;
+    if (dtype != QN_F64) return false;
+    if (!uniform_hidden(d, &H, &nhid)) return false;
+    if (H != 16 && H != 32 && H != 64) return false;
+    if (d->dims[0] > DMAX || d->dims[d->nlayers] > OMAX) return false;
+    if (want_grad && !pick_bwd(H, nhid)) return false;
+    return lds_need(H, d->dims[0], d->dims[d->nlayers], nhid, want_grad) <= 160 * 1024;
+}
+
+size_t qn_fused_workspace(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
+    FusedArgs a;
+    plan(d, B, Nb, want_grad, &a);
+    size_t tot = qn_align((size_t)B * a.nsplit * sizeof(double));
+    if (want_grad) tot += qn_align((size_t)B * a.nsplit * d->p * sizeof(double));
+    return tot + 256;
+}
+
+int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, const void* Y, const int32_t* row_idx,
+                 int B, int N, int Nb, double* sse, void* pred, void* gradW, void* ws, size_t ws_bytes,
+                 hipStream_t st) {
+    int H, nhid;
+    const int want_grad = gradW != nullptr;
+    if (!uniform_hidden(d, &H, &nhid) || dtype != QN_F64) {
+        qn_set_error("qn_fused_run: unsupported configuration");
         return QN_EUNSUPPORTED;
     }
-    QN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
-    hipLaunchKernelGGL(kern, grid, dim3(WG), lds_bytes, st, a, (const double*)W, (const double*)X, (const double*)Y,
-                       row_idx, (double*)pred, partial);
+    FusedArgs a;
+    a.p = d->p; a.B = B; a.N = N; a.Nb = Nb; a.d = d->dims[0]; a.o = d->dims[d->nlayers]; a.nhid = nhid;
+    a.act = d->act; a.has_bias = d->has_bias;
+    plan(d, B, Nb, want_grad, &a);
+    const size_t npart = qn_align((size_t)B * a.nsplit * sizeof(double));
+    const size_t need = npart + (want_grad ? qn_align((size_t)B * a.nsplit * d->p * sizeof(double)) : 0);
+    if (need > ws_bytes) {
+        qn_set_error("workspace too small: need %zu bytes, got %zu", need, ws_bytes);
+        return QN_EWORKSPACE;
+    }
+    double* partial = static_cast<double*>(ws);
+    double* slab = reinterpret_cast<double*>(static_cast<char*>(ws) + npart);
+    const size_t lds_bytes = lds_need(H, a.d, a.o, nhid, want_grad);
+    dim3 grid(a.nsplit, B);
+    (void)hipGetLastError();
+    if (!want_grad) {
+        fwd_fn kern = pick_fwd(H, a.act, padded_d(a.d));
+        if (!kern) {
+            qn_set_error("qn_fused_run: no forward kernel instance for H=%d act=%d", H, a.act);
+            return QN_EUNSUPPORTED;
+        }
+        QN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(kern, grid, dim3(WG), lds_bytes, st, a, (const double*)W, (const double*)X,
+                           (const double*)Y, row_idx, (double*)pred, partial);
+    } else {
+        bwd_fn kern = pick_bwd(H, nhid);
+        if (!kern) {
+            qn_set_error("qn_fused_run: no backward kernel instance for H=%d nhid=%d", H, nhid);
+            return QN_EUNSUPPORTED;
+        }
+        QN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(kern, grid, dim3(WG), lds_bytes, st, a, (const double*)W, (const double*)X,
+                           (const double*)Y, row_idx, (double*)pred, partial, slab);
+        int gx = (int)((d->p + 255) / 256);
+        if (gx > 64) gx = 64;
+        hipLaunchKernelGGL(k_grad_reduce, dim3(gx, B), dim3(256), 0, st, slab, a.nsplit, d->p, B, (double*)gradW);
+    }
     hipLaunchKernelGGL(k_sum_partials, dim3((B + 63) / 64), dim3(64), 0, st, partial, a.nsplit, B, sse);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
