@@ -86,12 +86,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # rehearsal on a 1-GPU box: QN_BENCH_BACKEND=gloo runs all ranks on cuda:0 with CPU-side collectives
+    backend = os.environ.get("QN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     tdt = "float64" if args.dtype == "f64" else "float32"
     arch = MLPArch(DIMS, "tanh")
@@ -130,12 +138,13 @@ def main():
 
     t_max = el
     if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        t = torch.tensor([el], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_max = float(t.item())
-        gathered = [torch.empty(CHAINS, device=dev, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(gathered, out[0])                 # the single end-of-run collective (RCCL)
+        gathered = [torch.empty(CHAINS, device=cdev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, out[0].to(cdev))        # the single end-of-run collective (RCCL)
         torch.cuda.synchronize(dev)
+        assert all(torch.isfinite(gth).all() for gth in gathered)
 
     if rank == 0:
         evals = CHAINS * args.steps * world
@@ -144,6 +153,13 @@ def main():
         ach = CHAINS * flops / (kern_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
         path = op.path(CHAINS, N, want_grad)
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            # HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
+            # correction, + WRITE_SIZE), recorded by tools/prof_traffic.sh for this kernel / config
+            key = f"{args.kind}_{args.dtype}_{ {1: 'generic', 2: 'fused'}.get(path) }"
+            traffic = json.load(open(tfile)).get(key, {}).get("hbm_bytes_per_launch")
         res = {
             "metric": "log-posterior evals/sec (64 chains, 3x64 MLP, N=4096) at 1/2/4/8 GPU",
             "value": value, "unit": "log-posterior evals/s", "n_gpus": world, "steps": args.steps,
@@ -155,7 +171,7 @@ def main():
                        "kind": args.kind, "kernel_path": {1: "generic", 2: "fused"}.get(path, str(path)),
                        "parallelism": f"chains sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": None, "flops_per_eval": flops, "evals_per_launch": CHAINS,
+                         "traffic": traffic, "flops_per_eval": flops, "evals_per_launch": CHAINS,
                          "kernel_ms": kern_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
