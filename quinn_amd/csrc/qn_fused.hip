@@ -136,23 +136,47 @@ __global__ __launch_bounds__(WG, 2) void k_fused_fwd_f64(FusedArgs a, const doub
     const int fl = swz(c);
     double sse = 0.0;
 
-    for (int it = 0; it < a.iters; ++it) {
+    // data of the NEXT iteration is fetched while the current one computes (x, y and row indices come
+    // from HBM/L2; their latency would otherwise be exposed once per iteration)
+    double xn[G][DP], yn[G][OMAX];
+    int nrow_n[G];
+    bool valid_n[G];
+    auto fetch = [&](int it) {
         const int nbase = split * a.rows_per_split + (it * (WG / 64) + wave) * 16 * G;
-        double act[G][T][4];
-        int64_t rrow[G];
-        int nrow[G];
-        bool valid[G];
-        // ---- first layer (VALU): a_1 = act(W0 x + b0)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int n = nbase + 16 * g + c;
-            valid[g] = n < a.Nb;
-            nrow[g] = n;
-            const int nn = valid[g] ? n : 0;
-            rrow[g] = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
-            double xk[DP];
+            valid_n[g] = n < a.Nb;
+            nrow_n[g] = n;
+            const int nn = valid_n[g] ? n : 0;
+            const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
 #pragma unroll
-            for (int k = 0; k < DP; ++k) xk[k] = k < d ? X[rrow[g] * d + k] : 0.0;
+            for (int k = 0; k < DP; ++k) xn[g][k] = k < d ? X[rr * d + k] : 0.0;
+#pragma unroll
+            for (int qo = 0; qo < OMAX; ++qo) yn[g][qo] = qo < o ? Y[rr * o + qo] : 0.0;
+        }
+    };
+    fetch(0);
+
+    for (int it = 0; it < a.iters; ++it) {
+        double act[G][T][4];
+        double yk[G][OMAX];
+        int nrow[G];
+        bool valid[G];
+        double xk[G][DP];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            valid[g] = valid_n[g];
+            nrow[g] = nrow_n[g];
+#pragma unroll
+            for (int k = 0; k < DP; ++k) xk[g][k] = xn[g][k];
+#pragma unroll
+            for (int qo = 0; qo < OMAX; ++qo) yk[g][qo] = yn[g][qo];
+        }
+        if (it + 1 < a.iters) fetch(it + 1);
+        // ---- first layer (VALU): a_1 = act(W0 x + b0)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -160,7 +184,7 @@ __global__ __launch_bounds__(WG, 2) void k_fused_fwd_f64(FusedArgs a, const doub
                     const int j = 16 * t + q + 4 * i;
                     double z = lds[offb0 + j];
 #pragma unroll
-                    for (int k = 0; k < DP; ++k) z = fma(lds[offW0 + j * DP + k], xk[k], z);
+                    for (int k = 0; k < DP; ++k) z = fma(lds[offW0 + j * DP + k], xk[g][k], z);
                     act[g][t][i] = act_apply<ACT>(z);
                 }
         }
@@ -198,7 +222,9 @@ __global__ __launch_bounds__(WG, 2) void k_fused_fwd_f64(FusedArgs a, const doub
         // ---- last layer (VALU + 2 cross-lane adds), residual, SSE
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            for (int qo = 0; qo < o; ++qo) {
+#pragma unroll
+            for (int qo = 0; qo < OMAX; ++qo) {
+                if (qo >= o) break;
                 double part = 0.0;
 #pragma unroll
                 for (int t = 0; t < T; ++t)
@@ -208,7 +234,7 @@ __global__ __launch_bounds__(WG, 2) void k_fused_fwd_f64(FusedArgs a, const doub
                 part += __shfl_xor(part, 16, 64);
                 part += __shfl_xor(part, 32, 64);
                 const double pr = part + lds[offbl + qo];
-                const double res = pr - Y[rrow[g] * o + qo];
+                const double res = pr - yk[g][qo];
                 if (valid[g] && q == 0) {
                     sse += res * res;
                     if (pred_out) pred_out[((int64_t)b * a.Nb + nrow[g]) * o + qo] = pr;

@@ -15,7 +15,7 @@
 //           so 2^n is built with one integer op -- no v_rndne / v_cvt / v_ldexp);
 //   expm1(r) = r + r^2 P(r), P = degree-10 near-minimax fit (8.5e-19 relative);
 //   E = 2^n expm1(r) + (2^n - 1)   (2^n - 1 exact; E in [-1, 0], no cancellation);
-//   quotient: v_rcp_f64 (2^-24) + one Newton step (2^-48) + one residual correction.
+//   quotient: v_rcp_f64 (2^-24) + one cubic Newton step y(1 + e + e^2) (2^-73), then one product.
 // |x| is clamped to 20 (tanh = 1 to the last bit from 19.07 on), NaN is propagated by an integer
 // mask on the high word (no v_cmp / v_cndmask: 20+ cycles a pair on this chip).
 // Measured against an 80-bit reference on [-20, 20]: max error < 3 ulp, mean 0.3 ulp
@@ -45,10 +45,10 @@ __device__ __forceinline__ double qn_tanh_f64(double x) {
     const double s = __hiloint2double((__double2loint(zm) + 1023) << 20, 0);   // 2^n, n in [-58, 0]
     const double E = fma(s, em1r, s - 1.0);
     const double den = 2.0 + E;                                        // in [1, 2]
-    double y = __builtin_amdgcn_rcp(den);
-    y = fma(fma(-den, y, 1.0), y, y);
+    double y = __builtin_amdgcn_rcp(den);                              // 2^-24
+    const double e0 = fma(-den, y, 1.0);
+    y = fma(y, fma(e0, e0, e0), y);                                    // cubic step: error e0^3 = 2^-73
     double q = -E * y;
-    q = fma(fma(-den, q, -E), y, q);
     const int xh = __double2hiint(x);
     const int nanmask = (0x7ff00000 - (xh & 0x7fffffff)) >> 31;        // all ones iff x is NaN
     const int qh = (__double2hiint(q) | (xh & 0x80000000)) | nanmask;
