@@ -444,8 +444,9 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
         __syncthreads();
         {
             double sum[OMAX] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
             for (int rr = 0; rr < RPT; ++rr) {
-                const int row = part * RPT + rr;
+                const int row = part + TPF * rr;          // interleaved rows: conflict-free Sdl / Sx reads
                 const double av = SA[fj * NSP + row];
 #pragma unroll
                 for (int qo = 0; qo < OMAX; ++qo) sum[qo] = fma(av, Sdl[row * OMAX + qo], sum[qo]);
@@ -483,30 +484,58 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
                         SA[(16 * t + q + 4 * i) * NSP + wrow] = act[layer - 1][t][i];
                     }
                 __syncthreads();
-                // dW_layer tiles owned by this wave, contraction over the 64 rows of the tile
+                // dW_layer tiles owned by this wave, contraction over the 64 rows of the tile; two tiles
+                // are advanced together (independent accumulators back to back), fragments of the next
+                // 2 k-steps are in flight under the MFMAs of the current ones
+                constexpr int UP = TPW >= 2 ? 2 : 1;
 #pragma unroll
-                for (int u = 0; u < TPW; ++u) {
-                    const int tile = wave + 4 * u;
-                    if (tile < TT) {
-                        const int tj = tile / T, ti = tile % T;
-                        const double* pa = SD + (16 * tj + c) * NSP + q;
-                        const double* pb = SA + (16 * ti + c) * NSP + q;
+                for (int u0 = 0; u0 < TPW; u0 += UP) {
+                    const double* pa[UP];
+                    const double* pb[UP];
+                    bool live[UP];
 #pragma unroll
-                        for (int s4 = 0; s4 < ROWS_IT / 16; ++s4) {
-                            double fa[4], fb[4];
+                    for (int v = 0; v < UP; ++v) {
+                        const int tile = wave + 4 * (u0 + v);
+                        live[v] = tile < TT;
+                        const int tj = live[v] ? tile / T : 0, ti = live[v] ? tile % T : 0;
+                        pa[v] = SD + (16 * tj + c) * NSP + q;
+                        pb[v] = SA + (16 * ti + c) * NSP + q;
+                    }
+                    constexpr int KB = 2;                              // k-steps per batch
+                    double fa[UP][KB], fb[UP][KB], na[UP][KB], nb2[UP][KB];
 #pragma unroll
-                            for (int m = 0; m < 4; ++m) { fa[m] = pa[16 * s4 + 4 * m]; fb[m] = pb[16 * s4 + 4 * m]; }
+                    for (int v = 0; v < UP; ++v)
 #pragma unroll
-                            for (int m = 0; m < 4; ++m)
-                                dWacc[layer - 1][u] =
-                                    __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], fb[m], dWacc[layer - 1][u], 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
+                        for (int m = 0; m < KB; ++m) { na[v][m] = pa[v][4 * m]; nb2[v][m] = pb[v][4 * m]; }
+#pragma unroll
+                    for (int sb = 0; sb < ROWS_IT / 4 / KB; ++sb) {
+#pragma unroll
+                        for (int v = 0; v < UP; ++v)
+#pragma unroll
+                            for (int m = 0; m < KB; ++m) { fa[v][m] = na[v][m]; fb[v][m] = nb2[v][m]; }
+                        if (sb + 1 < ROWS_IT / 4 / KB) {
+#pragma unroll
+                            for (int v = 0; v < UP; ++v)
+#pragma unroll
+                                for (int m = 0; m < KB; ++m) {
+                                    na[v][m] = pa[v][4 * (KB * (sb + 1) + m)];
+                                    nb2[v][m] = pb[v][4 * (KB * (sb + 1) + m)];
+                                }
                         }
+#pragma unroll
+                        for (int m = 0; m < KB; ++m)
+#pragma unroll
+                            for (int v = 0; v < UP; ++v)
+                                if (live[v])
+                                    dWacc[layer - 1][u0 + v] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                                        fa[v][m], fb[v][m], dWacc[layer - 1][u0 + v], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 {   // bias gradient of this layer: column sums of dZ
                     double sb = 0.0;
-                    for (int rr = 0; rr < RPT; ++rr) sb += SD[fj * NSP + part * RPT + rr];
+#pragma unroll 4
+                    for (int rr = 0; rr < RPT; ++rr) sb += SD[fj * NSP + part + TPF * rr];
                     dbacc[layer] += sb;
                 }
                 // dA = W^T dZ (transposed fragment reads of the same LDS image), then dZ of the layer below
@@ -548,8 +577,9 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
             double sb = 0.0, sw0[DP];
 #pragma unroll
             for (int k = 0; k < DP; ++k) sw0[k] = 0.0;
+#pragma unroll 4
             for (int rr = 0; rr < RPT; ++rr) {
-                const int row = part * RPT + rr;
+                const int row = part + TPF * rr;
                 const double g = SD[fj * NSP + row];
                 sb += g;
 #pragma unroll
