@@ -36,6 +36,7 @@ struct FusedArgs {
     int64_t p;
     int B, N, Nb, d, o, nhid, act, has_bias;
     int nsplit, rows_per_split, iters;
+    int64_t dbg_off;     // diagnostic builds: offset (doubles, from the partials) of a 12-word scratch
 };
 
 __host__ __device__ constexpr int swz(int j) { return ((j & 1) << 4) | (((j >> 1) & 7) << 1); }
@@ -271,6 +272,20 @@ __global__ __launch_bounds__(WG, 2) void k_fused_fwd_f64(FusedArgs a, const doub
 // stashes -> one workgroup per CU, one wave per SIMD (the DP pipe is serial anyway, section 4.1 of
 // DESIGN.md).
 constexpr int NHMAX = 4;
+#ifdef QN_BWD_STAMPS
+// diagnostic build only (tools/bwd_stamps.sh): accumulate per-phase cycles of wave 0 in scalar sums
+#define QN_STAMP(k)                                                                          \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        const long long now_ = __builtin_amdgcn_s_memtime();                                 \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                  \
+        stamp_acc[k] += now_ - stamp_prev;                                                   \
+        stamp_prev = now_;                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#else
+#define QN_STAMP(k) do { } while (0)
+#endif
 constexpr int ROWS_IT = 64;          // rows per workgroup iteration in the backward kernel
 constexpr int NSP = ROWS_IT + 2;     // stash row stride (doubles)
 
@@ -337,6 +352,10 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
     const int wrow = wave * 16 + c;               // this lane's row inside the 64-row tile
 
     double sse = 0.0;
+#ifdef QN_BWD_STAMPS
+    long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
     v4d dWacc[NH > 1 ? NH - 1 : 1][TPW];
 #pragma unroll
     for (int l = 0; l < (NH > 1 ? NH - 1 : 1); ++l)
@@ -345,7 +364,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
     double dbacc[NH];
 #pragma unroll
     for (int k = 0; k < NH; ++k) dbacc[k] = 0.0;
-    double dW0acc[DP], dWlacc[OMAX], dblacc = 0.0;
+    double dW0acc[DP], dWlacc[OMAX], dblacc[OMAX] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < DP; ++k) dW0acc[k] = 0.0;
 #pragma unroll
@@ -359,6 +378,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
         double xk[DP];
 #pragma unroll
         for (int k = 0; k < DP; ++k) xk[k] = k < d ? X[rrow * d + k] : 0.0;
+        QN_STAMP(0);                                       // 0: loop top + x load
         // ------------------------------------------------------------------ forward
         double act[NH][T][4];
 #pragma unroll
@@ -405,6 +425,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
             }
         }
         double (&alast)[T][4] = act[NH - 1];
+        QN_STAMP(1);                                       // 1: forward layers
         // ------------------------------------------------------------------ last layer, residual
         double delta[OMAX];
 #pragma unroll
@@ -429,8 +450,10 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
                 }
             }
         }
+        QN_STAMP(2);                                       // 2: last layer + residual
         // ------------------------------------------------------------------ backward: last layer
         __syncthreads();                                   // previous iteration's stash readers are done
+        QN_STAMP(3);                                       // 3: barrier A (last stage)
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -442,34 +465,46 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
             for (int k = 0; k < DP; ++k) Sx[wrow * DP + k] = xk[k];
         }
         __syncthreads();
+        QN_STAMP(4);                                       // 4: stash write + barrier B (last stage)
         {
-            double sum[OMAX] = {0.0, 0.0, 0.0, 0.0};
+            double sum[OMAX] = {0.0, 0.0, 0.0, 0.0}, sdl[OMAX] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
             for (int rr = 0; rr < RPT; ++rr) {
                 const int row = part + TPF * rr;          // interleaved rows: conflict-free Sdl / Sx reads
                 const double av = SA[fj * NSP + row];
 #pragma unroll
-                for (int qo = 0; qo < OMAX; ++qo) sum[qo] = fma(av, Sdl[row * OMAX + qo], sum[qo]);
+                for (int qo = 0; qo < OMAX; ++qo) {
+                    const double dv = Sdl[row * OMAX + qo];
+                    sum[qo] = fma(av, dv, sum[qo]);
+                    sdl[qo] += dv;                        // every feature's threads see all deltas: feature 0 keeps the bias sum
+                }
             }
 #pragma unroll
-            for (int qo = 0; qo < OMAX; ++qo) dWlacc[qo] += sum[qo];
-            if (tid < o) {
-                double sb = 0.0;
-                for (int row = 0; row < ROWS_IT; ++row) sb += Sdl[row * OMAX + tid];
-                dblacc += sb;
+            for (int qo = 0; qo < OMAX; ++qo) {
+                dWlacc[qo] += sum[qo];
+                dblacc[qo] += sdl[qo];
             }
         }
         double dz[T][4];
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                double g = 0.0;
+            for (int i = 0; i < 4; ++i) dz[t][i] = 0.0;
 #pragma unroll
-                for (int qo = 0; qo < OMAX; ++qo)
-                    if (qo < o) g = fma(lds[offWl + qo * H + 16 * t + q + 4 * i], delta[qo], g);
-                dz[t][i] = g * act_deriv_rt(alast[t][i], act_kind);
+        for (int qo = 0; qo < OMAX; ++qo) {
+            if (qo < o) {                                  // one uniform branch per output, 16 LDS reads in flight
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        dz[t][i] = fma(lds[offWl + qo * H + 16 * t + q + 4 * i], delta[qo], dz[t][i]);
             }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dz[t][i] *= act_deriv_rt(alast[t][i], act_kind);
+        QN_STAMP(5);                                       // 5: last-stage column sums + dz_NH
         // ------------------------------------------------------------------ backward: hidden -> hidden layers
 #pragma unroll
         for (int layer = NH - 1; layer >= 1; --layer) {
@@ -484,6 +519,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
                         SA[(16 * t + q + 4 * i) * NSP + wrow] = act[layer - 1][t][i];
                     }
                 __syncthreads();
+                QN_STAMP(6);                               // 6: hidden stage barriers + stash writes
                 // dW_layer tiles owned by this wave, contraction over the 64 rows of the tile; two tiles
                 // are advanced together (independent accumulators back to back), fragments of the next
                 // 2 k-steps are in flight under the MFMAs of the current ones
@@ -532,12 +568,14 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                QN_STAMP(7);                               // 7: dW MFMAs
                 {   // bias gradient of this layer: column sums of dZ
                     double sb = 0.0;
 #pragma unroll 4
                     for (int rr = 0; rr < RPT; ++rr) sb += SD[fj * NSP + part + TPF * rr];
                     dbacc[layer] += sb;
                 }
+                QN_STAMP(8);                               // 8: db column sums
                 // dA = W^T dZ (transposed fragment reads of the same LDS image), then dZ of the layer below
                 v4d nd[T];
 #pragma unroll
@@ -564,6 +602,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
                 for (int t = 0; t < T; ++t)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) dz[t][i] = nd[t][i] * act_deriv_rt(act[layer - 1][t][i], act_kind);
+                QN_STAMP(9);                               // 9: dA MFMAs + dz
             }
         }
         // ------------------------------------------------------------------ backward: first layer
@@ -589,7 +628,14 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
             for (int k = 0; k < DP; ++k) dW0acc[k] += sw0[k];
         }
+        QN_STAMP(10);                                      // 10: first-layer stage (2 barriers + sums)
     }
+#ifdef QN_BWD_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+        long long* dbg = reinterpret_cast<long long*>(partial + a.dbg_off);
+        for (int k = 0; k < 12; ++k) dbg[k] = stamp_acc[k];
+    }
+#endif
 
     // ---------------------------------------------------------------------- write the partial gradient
     double* out = slab + ((int64_t)b * a.nsplit + split) * a.p;
@@ -603,7 +649,10 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
         for (int k = 0; k < DP; ++k) dW0acc[k] += __shfl_xor(dW0acc[k], m, 64);
 #pragma unroll
-        for (int k = 0; k < OMAX; ++k) dWlacc[k] += __shfl_xor(dWlacc[k], m, 64);
+        for (int k = 0; k < OMAX; ++k) {
+            dWlacc[k] += __shfl_xor(dWlacc[k], m, 64);
+            dblacc[k] += __shfl_xor(dblacc[k], m, 64);
+        }
     }
     if (part == 0) {
 #pragma unroll
@@ -619,7 +668,11 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
         for (int qo = 0; qo < OMAX; ++qo)
             if (qo < o) out[gWl + (int64_t)qo * H + fj] = dWlacc[qo];
     }
-    if (nb && tid < o) out[gbl + tid] = dblacc;
+    if (nb && tid == 0) {
+#pragma unroll
+        for (int qo = 0; qo < OMAX; ++qo)
+            if (qo < o) out[gbl + qo] = dblacc[qo];
+    }
 #pragma unroll
     for (int layer = 1; layer < NH; ++layer) {
         {
@@ -762,6 +815,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
     }
     double* partial = static_cast<double*>(ws);
     double* slab = reinterpret_cast<double*>(static_cast<char*>(ws) + npart);
+    a.dbg_off = (int64_t)(need / sizeof(double));          // the 256 spare bytes behind the slabs
     const size_t lds_bytes = lds_need(H, a.d, a.o, nhid, want_grad);
     dim3 grid(a.nsplit, B);
     (void)hipGetLastError();
