@@ -10,6 +10,7 @@
 // LDS-resident weights.
 #include "qn_common.h"
 #include "qn_math.h"
+#include <algorithm>
 
 namespace {
 
@@ -207,6 +208,201 @@ __global__ __launch_bounds__(BLK) void k_dW(LayerArgs a, const T* __restrict__ d
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// float64 MFMA GEMM for hidden -> hidden layers whose widths are multiples of 64 (cfg3..5:
+// h = 128 / 256, where one chain's weights no longer fit LDS).  One kernel, three operand maps:
+//   FWD  out[j][n]  = act( b_j + sum_i W[j][i] * in[i][n] )                 M=h_out, N'=rows, K=h_in
+//   DA   dzp[i][n]  = act'(a[i][n]) * sum_j W[j][i] * dz[j][n]              M=h_in,  N'=rows, K=h_out
+//   DW   dW[j][i]  += sum_n dz[j][n] * a[i][n]   (split over K = rows)      M=h_out, N'=h_in, K=rows
+// Workgroup = 4 waves = one 64x64 output tile, each wave 2x2 v_mfma_f64_16x16x4_f64 tiles; K in steps
+// of 16 through double-buffered LDS tiles Ps[64][16+2], Qs[16][64+16] (strides 18 / 80 doubles make
+// the A-fragment (16 rows x 2 k) and B-fragment (2 k x 16 cols) ds_read_b64 conflict-free); the next
+// K-step's global loads are issued before the MFMAs of the current one.
+typedef double gv4d __attribute__((ext_vector_type(4)));
+enum { GEMM_FWD = 0, GEMM_DA = 1, GEMM_DW = 2 };
+constexpr int GSP = 18, GSQ = 80, GKB = 16;
+
+struct GemmArgs {
+    int64_t p, offW, offB, out_stride_b, out_stride_k;
+    int h_in, h_out, Nb, act, has_bias, ksplit, kchunk;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(BLK) void k_gemm64_f64(GemmArgs g, const double* __restrict__ W,
+                                                    const double* __restrict__ in0, const double* __restrict__ in1,
+                                                    double* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) double Ps[2][64 * GSP];
+    __shared__ __attribute__((aligned(16))) double Qs[2][GKB * GSQ];
+    const int b = blockIdx.z, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, c = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int Nb = g.Nb;
+    int m0, n0, kbeg, kend;
+    if (MODE == GEMM_DW) {
+        const int tiles_i = g.h_in / 64;
+        m0 = (blockIdx.y / tiles_i) * 64;          // j0
+        n0 = (blockIdx.y % tiles_i) * 64;          // i0
+        kbeg = blockIdx.x * g.kchunk;
+        kend = kbeg + g.kchunk < Nb ? kbeg + g.kchunk : Nb;
+    } else {
+        m0 = blockIdx.y * 64;
+        n0 = blockIdx.x * 64;
+        kbeg = 0;
+        kend = MODE == GEMM_FWD ? g.h_in : g.h_out;
+    }
+    const double* Wl = W + (int64_t)b * g.p + g.offW;
+    const double* I0 = in0 + (int64_t)b * (MODE == GEMM_FWD ? g.h_in : g.h_out) * Nb;
+    const double* I1 = in1 ? in1 + (int64_t)b * g.h_in * Nb : nullptr;
+
+    double pr[4], qr[4];
+    auto gload = [&](int k0) {
+        if (MODE == GEMM_FWD) {          // P[m][k] = W[j0+m][k0+k];  Q[k][n] = in[k0+k][n0+n]
+            const int m = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pr[u] = Wl[(int64_t)(m0 + m) * g.h_in + k0 + kq + u];
+            const int k = tid >> 4, nq = (tid & 15) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) qr[u] = n0 + nq + u < Nb ? I0[(int64_t)(k0 + k) * Nb + n0 + nq + u] : 0.0;
+        } else if (MODE == GEMM_DA) {    // P[m][k] = W[k0+k][i0+m];  Q[k][n] = dz[k0+k][n0+n]
+            const int m = tid & 63, kq = (tid >> 6) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pr[u] = Wl[(int64_t)(k0 + kq + u) * g.h_in + m0 + m];
+            const int k = tid >> 4, nq = (tid & 15) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) qr[u] = n0 + nq + u < Nb ? I0[(int64_t)(k0 + k) * Nb + n0 + nq + u] : 0.0;
+        } else {                         // P[m][k] = dz[j0+m][k0+k];  Q[k][n] = a[i0+n][k0+k]   (k = data row)
+            const int m = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pr[u] = k0 + kq + u < kend ? I0[(int64_t)(m0 + m) * Nb + k0 + kq + u] : 0.0;
+            const int nn = tid & 63, kq2 = (tid >> 6) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) qr[u] = k0 + kq2 + u < kend ? I1[(int64_t)(n0 + nn) * Nb + k0 + kq2 + u] : 0.0;
+        }
+    };
+    auto lstore = [&](int buf) {
+        if (MODE == GEMM_FWD) {
+            const int m = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Ps[buf][m * GSP + kq + u] = pr[u];
+            const int k = tid >> 4, nq = (tid & 15) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Qs[buf][k * GSQ + nq + u] = qr[u];
+        } else if (MODE == GEMM_DA) {
+            const int m = tid & 63, kq = (tid >> 6) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Ps[buf][m * GSP + kq + u] = pr[u];
+            const int k = tid >> 4, nq = (tid & 15) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Qs[buf][k * GSQ + nq + u] = qr[u];
+        } else {
+            const int m = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Ps[buf][m * GSP + kq + u] = pr[u];
+            const int nn = tid & 63, kq2 = (tid >> 6) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Qs[buf][(kq2 + u) * GSQ + nn] = qr[u];
+        }
+    };
+
+    gv4d acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (gv4d){0.0, 0.0, 0.0, 0.0};
+    if (kbeg < kend) {
+        gload(kbeg);
+        lstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += GKB) {
+        const bool more = k0 + GKB < kend;
+        if (more) gload(k0 + GKB);                       // global loads in flight under the MFMAs
+        const double* pa = &Ps[buf][(16 * 2 * wm + c) * GSP + q];
+        const double* pb = &Qs[buf][q * GSQ + 16 * 2 * wn + c];
+#pragma unroll
+        for (int kk = 0; kk < GKB / 4; ++kk) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) af[mi] = pa[mi * 16 * GSP + 4 * kk];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bf[ni] = pb[4 * kk * GSQ + 16 * ni];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // ---- epilogue; C layout: reg r of tile (mi, ni) = row 16*(2wm+mi) + q + 4r, col 16*(2wn+ni) + c
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * (2 * wm + mi) + q + 4 * r;
+                const int n = n0 + 16 * (2 * wn + ni) + c;
+                double v = acc[mi][ni][r];
+                if (MODE == GEMM_FWD) {
+                    if (n < Nb) {
+                        if (g.has_bias) v += W[(int64_t)b * g.p + g.offB + m];
+                        out[((int64_t)b * g.h_out + m) * Nb + n] = apply_act(v, g.act);
+                    }
+                } else if (MODE == GEMM_DA) {
+                    if (n < Nb) {
+                        const int64_t idx = ((int64_t)b * g.h_in + m) * Nb + n;
+                        out[idx] = v * act_deriv(in1[idx], g.act);
+                    }
+                } else {
+                    out[(int64_t)b * g.out_stride_b + (int64_t)blockIdx.x * g.out_stride_k + (int64_t)m * g.h_in + n] = v;
+                }
+            }
+}
+
+// db[b][j] = sum_n dz[b][j][n]   (one block per (j, b); fixed-order reduction)
+__global__ __launch_bounds__(BLK) void k_rowsum(const double* __restrict__ dz, int h, int Nb, int64_t p, int64_t offB,
+                                                double* __restrict__ gradW) {
+    __shared__ double red[BLK / 64];
+    const int j = blockIdx.x, b = blockIdx.y;
+    const double* row = dz + ((int64_t)b * h + j) * Nb;
+    double s = 0.0;
+    for (int n = threadIdx.x; n < Nb; n += BLK) s += row[n];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < BLK / 64; ++w) t += red[w];
+        gradW[(int64_t)b * p + offB + j] = t;
+    }
+}
+
+// gradW[b][off + e] = sum_k slab[b][k][e]
+__global__ __launch_bounds__(BLK) void k_slab_reduce(const double* __restrict__ slab, int ksplit, int64_t n, int64_t p,
+                                                     int64_t off, double* __restrict__ gradW) {
+    const int b = blockIdx.y;
+    for (int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x; e < n; e += (int64_t)gridDim.x * BLK) {
+        double s = 0.0;
+        for (int k = 0; k < ksplit; ++k) s += slab[((int64_t)b * ksplit + k) * n + e];
+        gradW[(int64_t)b * p + off + e] = s;
+    }
+}
+
+inline bool gemm_layer(const qn_desc* d, int l) {
+    return l >= 1 && l + 1 < d->nlayers && d->dims[l] % 64 == 0 && d->dims[l + 1] % 64 == 0;
+}
+inline int dw_ksplit(int B, int tiles, int Nb) {
+    int ks = (512 + B * tiles - 1) / (B * tiles);
+    const int kmax = (Nb + 255) / 256;
+    if (ks > kmax) ks = kmax;
+    if (ks > 16) ks = 16;
+    return ks < 1 ? 1 : ks;
+}
+
 struct Carve {
     char* base; size_t off, cap;
     template <typename U> U* take(size_t n) {
@@ -233,6 +429,19 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
     }
     const int nblk = (Nb + BLK - 1) / BLK;
     double* partial = c.take<double>((size_t)B * nblk);
+    // split-K slabs of the MFMA dW GEMM (float64 hidden->hidden layers with widths % 64 == 0)
+    constexpr bool kF64 = sizeof(T) == 8;
+    double* dwslab = nullptr;
+    if (kF64 && grad) {
+        size_t need = 0;
+        for (int l = 1; l + 1 < L; ++l)
+            if (gemm_layer(d, l)) {
+                const int tiles = (d->dims[l] / 64) * (d->dims[l + 1] / 64);
+                const int ks = dw_ksplit(B, tiles, Nb);
+                if (ks > 1) need = std::max(need, (size_t)B * ks * d->dims[l] * d->dims[l + 1]);
+            }
+        if (need) dwslab = c.take<double>(need);
+    }
     if (c.off > ws_bytes) {
         qn_set_error("workspace too small: need %zu bytes, got %zu", c.off, ws_bytes);
         return QN_EWORKSPACE;
@@ -245,7 +454,21 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         a.d = d->dims[0]; a.o = d->dims[L];
         return a;
     };
+    auto gargs = [&](int l) {
+        GemmArgs g;
+        g.p = d->p; g.offW = d->offW[l]; g.offB = d->offB[l]; g.out_stride_b = 0; g.out_stride_k = 0;
+        g.h_in = d->dims[l]; g.h_out = d->dims[l + 1]; g.Nb = Nb; g.act = d->act; g.has_bias = d->has_bias;
+        g.ksplit = 1; g.kchunk = Nb;
+        return g;
+    };
     for (int l = 0; l + 1 < L; ++l) {
+        if (kF64 && gemm_layer(d, l)) {
+            GemmArgs g = gargs(l);
+            dim3 grid((Nb + 63) / 64, g.h_out / 64, B);
+            hipLaunchKernelGGL((k_gemm64_f64<GEMM_FWD>), grid, dim3(BLK), 0, st, g, (const double*)W,
+                               (const double*)act[l - 1], (const double*)nullptr, (double*)act[l]);
+            continue;
+        }
         LayerArgs a = largs(l);
         dim3 grid(nblk, (a.h_out + JB - 1) / JB, B);
         hipLaunchKernelGGL((k_fwd_hidden<T, JB>), grid, dim3(BLK), 0, st, a, W, l ? act[l - 1] : (const T*)nullptr,
@@ -263,6 +486,34 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         const T* dz = dz_last;
         for (int l = L - 1; l >= 0; --l) {
             LayerArgs a = largs(l);
+            if (kF64 && gemm_layer(d, l)) {
+                GemmArgs g = gargs(l);
+                const int tiles = (g.h_in / 64) * (g.h_out / 64);
+                const int ks = dw_ksplit(B, tiles, Nb);
+                const int64_t nW = (int64_t)g.h_in * g.h_out;
+                g.ksplit = ks;
+                g.kchunk = ((Nb + ks - 1) / ks + GKB - 1) / GKB * GKB;
+                double* dst = (double*)gradW + d->offW[l];
+                g.out_stride_b = d->p; g.out_stride_k = 0;
+                if (ks > 1) { dst = dwslab; g.out_stride_b = (int64_t)ks * nW; g.out_stride_k = nW; }
+                hipLaunchKernelGGL((k_gemm64_f64<GEMM_DW>), dim3(ks, tiles, B), dim3(BLK), 0, st, g, (const double*)W,
+                                   (const double*)dz, (const double*)act[l - 1], dst);
+                if (ks > 1) {
+                    int gx = (int)((nW + BLK - 1) / BLK);
+                    if (gx > 64) gx = 64;
+                    hipLaunchKernelGGL(k_slab_reduce, dim3(gx, B), dim3(BLK), 0, st, dwslab, ks, nW, d->p, d->offW[l],
+                                       (double*)gradW);
+                }
+                if (d->has_bias)
+                    hipLaunchKernelGGL(k_rowsum, dim3(g.h_out, B), dim3(BLK), 0, st, (const double*)dz, g.h_out, Nb,
+                                       d->p, d->offB[l], (double*)gradW);
+                T* dzp = dzbuf[l & 1];
+                g.ksplit = 1; g.kchunk = Nb;
+                hipLaunchKernelGGL((k_gemm64_f64<GEMM_DA>), dim3((Nb + 63) / 64, g.h_in / 64, B), dim3(BLK), 0, st, g,
+                                   (const double*)W, (const double*)dz, (const double*)act[l - 1], (double*)dzp);
+                dz = dzp;
+                continue;
+            }
             dim3 gridw((a.h_in + TK - 1) / TK, (a.h_out + TJ - 1) / TJ, B);
             hipLaunchKernelGGL((k_dW<T, TJ, TK>), gridw, dim3(BLK), 0, st, a, dz, l ? act[l - 1] : (const T*)nullptr,
                                X, row_idx, gradW);
@@ -290,6 +541,16 @@ size_t qn_generic_workspace(const qn_desc* d, int B, int Nb, int want_grad, int 
         if (L > 1) tot += 2 * qn_align((size_t)B * d->hmax * Nb * e);
     }
     tot += qn_align((size_t)B * ((Nb + BLK - 1) / BLK) * sizeof(double));
+    if (want_grad && dtype == QN_F64) {
+        size_t need = 0;
+        for (int l = 1; l + 1 < L; ++l)
+            if (gemm_layer(d, l)) {
+                const int tiles = (d->dims[l] / 64) * (d->dims[l + 1] / 64);
+                const int ks = dw_ksplit(B, tiles, Nb);
+                if (ks > 1) need = std::max(need, (size_t)B * ks * d->dims[l] * d->dims[l + 1]);
+            }
+        tot += qn_align(need * sizeof(double));
+    }
     return tot + 256;
 }
 

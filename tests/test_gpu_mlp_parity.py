@@ -68,6 +68,8 @@ CASES = [  # dims, activ, bias, N, B
     ((2, 8, 1), "identity", False, 17, 3),
     ((4, 3), "tanh", True, 9, 2),                    # single Linear layer
     ((1, 32, 32, 1), "relu", False, 1, 2),           # one data row
+    ((2, 128, 128, 1), "tanh", True, 777, 1),        # MFMA GEMM layer path with split-K dW (ragged rows)
+    ((1, 64, 128, 64, 2), "relu", True, 300, 3),     # non-uniform widths, all multiples of 64
 ]
 
 
