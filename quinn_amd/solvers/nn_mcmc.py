@@ -84,7 +84,7 @@ class NN_MCMC(QUiNNBase):
 
     # -- fit -------------------------------------------------------------------------------
     def fit(self, xtrn, ytrn, zflag=True, datanoise=0.05, nmcmc=6000, param_ini=None, sampler='amcmc',
-            sampler_params=None, *, nchains=1, seeds=None):
+            sampler_params=None, *, nchains=1, seeds=None, engine='host'):
         """Run MCMC over the flat weight vector.
 
         Args (reference): xtrn `(N,d)`, ytrn `(N,o)`, zflag (BFGS pre-fit of a random start),
@@ -93,6 +93,9 @@ class NN_MCMC(QUiNNBase):
         Build-only: nchains (C independent chains in lock-step), seeds (C ints; chain c then
             equals a reference run preceded by np.random.seed(seeds[c])).  With nchains=1 and
             seeds=None the global numpy RNG is used, exactly like the reference.
+            engine='device' (sampler 'amcmc' only): states, proposal factors and history stay on the
+            GPU, no host synchronisation per step (`quinn_amd.mcmc.device_amcmc`); same target and
+            adaptation schedule, chains equal the host engine in distribution, not bit for bit.
         """
         ntrn_, outdim = ytrn.shape
         assert xtrn.shape[0] == ntrn_
@@ -119,6 +122,18 @@ class NN_MCMC(QUiNNBase):
             param_ini = np.tile(param_ini, (nchains, 1))
 
         sampler_params = dict(sampler_params)      # None raises, as in the reference
+        if engine == 'device':
+            if sampler != 'amcmc':
+                raise ValueError("engine='device' is implemented for sampler='amcmc'")
+            from ..mcmc.device_amcmc import DeviceAMCMC
+            op = self._operator(self.lpinfo)
+            eng = DeviceAMCMC(op, datanoise, seed=(seeds[0] if seeds else 0), **sampler_params)
+            res = eng.run(nmcmc, np.atleast_2d(param_ini), verbose=self.verbose)
+            self.mcmc_results = {k: (v.cpu().numpy() if v is not None else None) for k, v in res.items()}
+            if np.ndim(param_ini) == 1:
+                self.mcmc_results = {k: (v[0] if v is not None else None) for k, v in self.mcmc_results.items()}
+            self.samples, self.cmode = self.mcmc_results['chain'], self.mcmc_results['mapparams']
+            return
         if sampler == 'amcmc':
             mymcmc = AMCMC(**sampler_params)
             mymcmc.setLogPostBatch(self.logpost_batch, None, lpinfo=self.lpinfo)
