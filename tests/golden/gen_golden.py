@@ -313,3 +313,42 @@ if __name__ == "__main__":
         g4_g5()
     if "ens" in which:
         g6()
+
+
+# ---------------------------------------------------------------- timing equivalence
+def timing_ratio():
+    """The bench's CPU baseline times the oracle's sequential log-posterior, because the reference
+    cannot travel to the GPU box.  Record here, where both run, that the two cost the same:
+    median time per evaluation of NN_MCMC.logpost (reference) and oracle.mlp_ref.logpost on the
+    cfg2 workload (3x64 tanh MLP, N=4096), same thread count."""
+    import json
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import mlp_ref
+    N, hls = 4096, (64, 64, 64)
+    x, y = mlp_ref.synthetic_data(N, 1, 0.02, seed=0)
+    net = MLP(1, 1, hls, activ='tanh')
+    solver = NN_MCMC(net, verbose=False)
+    lpinfo = {"model": nn_p, "xd": x, "yd": [yy for yy in y], "ltype": "classical", "lparams": {"sigma": 0.02}}
+    mod = mlp_ref.build_module(mlp_ref.MLPSpec((1,) + hls + (1,), "tanh"))
+    ws = [0.1 * np.random.RandomState(1000 + c).randn(solver.pdim) for c in range(8)]
+    out = {}
+    for nt in (1, 8):
+        torch.set_num_threads(nt)
+        def med(fn):
+            for i in range(10):
+                fn(ws[i % 8])
+            ts = []
+            for i in range(120):
+                t0 = time.perf_counter(); fn(ws[i % 8]); ts.append(time.perf_counter() - t0)
+            return float(np.median(ts))
+        tr = med(lambda w: solver.logpost(w, lpinfo))
+        to = med(lambda w: mlp_ref.logpost(mod, w, x, lpinfo["yd"], 0.02))
+        assert solver.logpost(ws[0], lpinfo) == mlp_ref.logpost(mod, ws[0], x, lpinfo["yd"], 0.02)
+        out[f"threads_{nt}"] = {"reference_ms": 1e3 * tr, "oracle_ms": 1e3 * to, "ratio_oracle_over_reference": to / tr}
+    json.dump(out, open(os.path.join(OUT, "timing_ratio.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__" and "timing" in sys.argv[1:]:
+    timing_ratio()
