@@ -109,6 +109,29 @@ int qn_adam_batched(double* W, const void* G, double* m, double* v, const double
                     int64_t p, int dtype, double gscale, double wd, double beta1, double beta2,
                     double eps, int step, void* stream);
 
+/* Device-resident Metropolis-Hastings step (throughput engine of the adaptive Metropolis sampler,
+ * quinn/mcmc/admcmc.py:38-74 + quinn/mcmc/mcmc.py:65-85), two kernels around the batched
+ * log-posterior.  `step_ptr` points to TWO int64 words in device memory: [0] the step counter
+ * (read by both kernels, advanced by qn_mcmc_accept), [1] scratch (must start at 0); keeping the
+ * counter on the device makes one step a static HIP graph.
+ *
+ * qn_mcmc_propose: out[c,:] = cur[c,:] + sd[c,:] * z + c1 * z0_c with z ~ N(0,I), z0_c ~ N(0,1)
+ *   (the initial proposal covariance c1^2 + diag(sd^2) = 0.01 + diag(0.09|x0|), admcmc.py:65);
+ *   with cur == NULL it writes the standard normals z themselves (input of a dense factor product).
+ *   Random numbers: Philox4x32-10 keyed by (seed, step). */
+int qn_mcmc_propose(const double* cur, const double* sd, double c1, int C, int64_t p, uint64_t seed,
+                    const int64_t* step_ptr, double* out, void* stream);
+
+/* qn_mcmc_accept: for every chain c: log-posterior of the proposal from its SSE,
+ *   lp = -(0.5 sse/sigma^2 + (n_rows/2) log 2pi + n_rows log sigma); mh = exp(lp - cur_lp[c]);
+ *   accept iff u_c < mh (mcmc.py:72-75); updates cur, cur_lp, best / best_lp (MAP, mcmc.py:79-81),
+ *   nacc, writes chain[c, step+1, :] (optional), lps[c, step+1], alphas[c, step+1] and the next row
+ *   (cur - x0) of the adaptation window win [C, win_len, p] (optional); then advances the counter. */
+int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int64_t p,
+                   int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
+                   double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0, double* win,
+                   int win_len, int64_t* step_ptr, void* stream);
+
 /* Diagnostic: y[i] = device tanh(x[i]) in float64 (the activation used by every kernel). */
 int qn_debug_tanh(const double* x, double* y, int64_t n, void* stream);
 

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libquinn_amd.so")
-SOURCES = ["qn_api.hip", "qn_generic.hip", "qn_fused.hip"]
+SOURCES = ["qn_api.hip", "qn_generic.hip", "qn_fused.hip", "qn_mcmc.hip"]
 
 QN_F64, QN_F32 = 0, 1
 ACT_CODES = {"identity": 0, "tanh": 1, "relu": 2}
@@ -20,7 +20,8 @@ PATH_AUTO, PATH_GENERIC, PATH_FUSED = 0, 1, 2
 # every symbol include/quinn_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = ["qn_mlp_desc_create", "qn_mlp_desc_destroy", "qn_mlp_num_params", "qn_workspace_bytes",
            "qn_mlp_path", "qn_set_path", "qn_mlp_sse_fwd", "qn_mlp_sse_fwdbwd", "qn_vi_sample_kl",
-           "qn_vi_grad", "qn_adam_batched", "qn_debug_tanh", "qn_last_error", "qn_version"]
+           "qn_vi_grad", "qn_adam_batched", "qn_mcmc_propose", "qn_mcmc_accept", "qn_debug_tanh", "qn_last_error",
+           "qn_version"]
 
 
 class QuinnAmdError(RuntimeError):
@@ -83,6 +84,11 @@ def lib():
     L.qn_vi_grad.restype = i32
     L.qn_adam_batched.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, f64, f64, f64, f64, f64, i32, vp]
     L.qn_adam_batched.restype = i32
+    u64 = ctypes.c_uint64
+    L.qn_mcmc_propose.argtypes = [vp, vp, f64, i32, i64, u64, vp, vp, vp]
+    L.qn_mcmc_propose.restype = i32
+    L.qn_mcmc_accept.argtypes = [vp, vp, f64, i32, i32, i64, i32, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+    L.qn_mcmc_accept.restype = i32
     L.qn_debug_tanh.argtypes = [vp, vp, i64, vp]
     L.qn_debug_tanh.restype = i32
     L.qn_last_error.restype = ctypes.c_char_p

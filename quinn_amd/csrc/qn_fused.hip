@@ -23,6 +23,8 @@
 // data row).  SSE partials are reduced in a fixed order (bitwise reproducible).
 #include "qn_common.h"
 #include "qn_math.h"
+#include <mutex>
+#include <unordered_set>
 
 namespace {
 
@@ -774,6 +776,18 @@ bwd_fn pick_bwd(int H, int nhid) {
     return nullptr;
 }
 
+// raise the dynamic-LDS limit of a kernel once per process (not per launch: keeps the launch
+// function free of non-stream API calls, so it can be captured into a HIP graph)
+int arm_lds(const void* fn) {
+    static std::mutex mu;
+    static std::unordered_set<const void*> armed;
+    std::lock_guard<std::mutex> lock(mu);
+    if (armed.count(fn)) return QN_OK;
+    QN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    armed.insert(fn);
+    return QN_OK;
+}
+
 }  // namespace
 
 bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
@@ -825,8 +839,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
             qn_set_error("qn_fused_run: no forward kernel instance for H=%d act=%d", H, a.act);
             return QN_EUNSUPPORTED;
         }
-        QN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (int rc = arm_lds(reinterpret_cast<const void*>(kern))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(WG), lds_bytes, st, a, (const double*)W, (const double*)X,
                            (const double*)Y, row_idx, (double*)pred, partial);
     } else {
@@ -835,8 +848,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
             qn_set_error("qn_fused_run: no backward kernel instance for H=%d nhid=%d", H, nhid);
             return QN_EUNSUPPORTED;
         }
-        QN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (int rc = arm_lds(reinterpret_cast<const void*>(kern))) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(WG), lds_bytes, st, a, (const double*)W, (const double*)X,
                            (const double*)Y, row_idx, (double*)pred, partial, slab);
         int gx = (int)((d->p + 255) / 256);

@@ -1,0 +1,173 @@
+// Device-side Metropolis-Hastings step kernels (throughput engine of the AMCMC sampler):
+//   qn_mcmc_propose : proposal = current + sqrt(diag) * z + c1 * z0      (Philox4x32-10 normals in-kernel)
+//                     or writes the standard normals z for a dense factor product
+//   qn_mcmc_accept  : log-posterior from the SSE, accept test, state / best / history / statistics update
+// Both read the step counter from DEVICE memory (the accept kernel increments it), so one step is a
+// static HIP graph: propose -> batched log-posterior -> accept.  HBM-bound elementwise work:
+// propose 3 x 8 B per element, accept <= 6 x 8 B per element.
+#include "qn_common.h"
+#include <cmath>
+
+namespace {
+
+constexpr int BLK = 256;
+
+struct Philox {
+    uint32_t c[4], k[2];
+    __device__ __forceinline__ void round() {
+        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+        const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+        const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+    }
+    // 4 x 32 random bits for (seed, stream, counter)
+    __device__ __forceinline__ void gen(uint64_t seed, uint64_t stream, uint64_t ctr) {
+        c[0] = (uint32_t)ctr; c[1] = (uint32_t)(ctr >> 32); c[2] = (uint32_t)stream; c[3] = (uint32_t)(stream >> 32);
+        k[0] = (uint32_t)seed; k[1] = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) round();
+    }
+};
+
+// uniform in (0, 1) with 53 random bits
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {
+    const uint64_t bits = ((uint64_t)hi << 21) ^ (uint64_t)(lo >> 11);        // 53 bits
+    return ((double)bits + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// two independent standard normals (Box-Muller) from one Philox block
+__device__ __forceinline__ void normal2(const Philox& ph, double& a, double& b) {
+    const double u1 = u01(ph.c[0], ph.c[1]), u2 = u01(ph.c[2], ph.c[3]);
+    const double r = sqrt(-2.0 * log(u1));
+    double s, cs;
+    sincospi(2.0 * u2, &s, &cs);
+    a = r * cs;
+    b = r * s;
+}
+
+// stream ids: 2*step -> elementwise normals, 2*step+1 -> per-chain scalars (z0, uniform)
+__global__ __launch_bounds__(BLK) void k_propose(const double* __restrict__ cur, const double* __restrict__ sd,
+                                                 double c1, int C, int64_t p, uint64_t seed,
+                                                 const int64_t* __restrict__ step_ptr, double* __restrict__ out) {
+    const int b = blockIdx.y;
+    const uint64_t step = (uint64_t)*step_ptr;
+    double z0 = 0.0;
+    if (c1 != 0.0) {
+        Philox ph;
+        ph.gen(seed, 2 * step + 1, (uint64_t)b);
+        double dummy;
+        normal2(ph, z0, dummy);
+    }
+    const int64_t npair = (p + 1) / 2;
+    for (int64_t j = (int64_t)blockIdx.x * BLK + threadIdx.x; j < npair; j += (int64_t)gridDim.x * BLK) {
+        Philox ph;
+        ph.gen(seed, 2 * step, (uint64_t)b * npair + j);
+        double za, zb;
+        normal2(ph, za, zb);
+        const int64_t e0 = (int64_t)b * p + 2 * j;
+        if (cur) {
+            out[e0] = cur[e0] + sd[e0] * za + c1 * z0;
+            if (2 * j + 1 < p) out[e0 + 1] = cur[e0 + 1] + sd[e0 + 1] * zb + c1 * z0;
+        } else {
+            out[e0] = za;
+            if (2 * j + 1 < p) out[e0 + 1] = zb;
+        }
+    }
+}
+
+struct AcceptArgs {
+    double half_inv_sig2, lp_const;       // log-posterior = -(half_inv_sig2 * sse + lp_const)
+    int C, nmcmc, win_len;
+    int64_t p;
+    uint64_t seed;
+};
+
+// one workgroup per chain
+__global__ __launch_bounds__(BLK) void k_accept(AcceptArgs a, const double* __restrict__ prop,
+                                                const double* __restrict__ sse_prop, double* __restrict__ cur,
+                                                double* __restrict__ cur_lp, double* __restrict__ best,
+                                                double* __restrict__ best_lp, double* __restrict__ chain,
+                                                double* __restrict__ lps, double* __restrict__ alphas,
+                                                int64_t* __restrict__ nacc, const double* __restrict__ x0,
+                                                double* __restrict__ win, int64_t* __restrict__ step_ptr) {
+    const int b = blockIdx.x;
+    const int64_t step = *step_ptr;
+    const double plp = -(a.half_inv_sig2 * sse_prop[b] + a.lp_const);
+    const double clp = cur_lp[b];
+    const double mh = exp(plp - clp);                               // exp(current_U - proposed_U), mcmc.py:69-72
+    Philox ph;
+    ph.gen(a.seed, 2 * (uint64_t)step + 1, (uint64_t)a.C + b);
+    const double u = u01(ph.c[0], ph.c[1]);
+    const bool take = u < mh;                                       // NaN -> reject, inf -> accept, as `u < mh_prob`
+    const double nlp = take ? plp : clp;
+    const bool better = take && nlp >= best_lp[b];
+    const int64_t base = (int64_t)b * a.p;
+    double* crow = chain ? chain + ((int64_t)b * (a.nmcmc + 1) + step + 1) * a.p : nullptr;
+    double* wrow = win ? win + ((int64_t)b * a.win_len + (step + 1) % a.win_len) * a.p : nullptr;
+    for (int64_t e = threadIdx.x; e < a.p; e += BLK) {
+        const double v = take ? prop[base + e] : cur[base + e];
+        if (take) cur[base + e] = v;
+        if (better) best[base + e] = v;
+        if (crow) crow[e] = v;
+        if (wrow) wrow[e] = v - x0[base + e];                       // next sample of the adaptation window
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cur_lp[b] = nlp;
+        if (better) best_lp[b] = nlp;
+        lps[(int64_t)b * (a.nmcmc + 1) + step + 1] = nlp;
+        alphas[(int64_t)b * (a.nmcmc + 1) + step + 1] = mh;
+        if (take) nacc[b] += 1;
+    }
+    // the step counter is advanced by the last block to get here (all blocks have read it already:
+    // it is read at kernel entry and the increment happens after a device-scope arrival count)
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int arrived = atomicAdd(reinterpret_cast<unsigned int*>(step_ptr + 1), 1u);
+        last = arrived == (unsigned int)(gridDim.x - 1);
+        if (last) {
+            reinterpret_cast<unsigned int*>(step_ptr + 1)[0] = 0u;
+            *step_ptr = step + 1;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int qn_mcmc_propose(const double* cur, const double* sd, double c1, int C, int64_t p, uint64_t seed,
+                               const int64_t* step_ptr, double* out, void* stream) {
+    if (!out || !step_ptr || C <= 0 || p <= 0 || C > 65535 || (cur && !sd)) {
+        qn_set_error("qn_mcmc_propose: bad argument");
+        return QN_EINVAL;
+    }
+    int gx = (int)(((p + 1) / 2 + BLK - 1) / BLK);
+    if (gx > 64) gx = 64;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_propose, dim3(gx, C), dim3(BLK), 0, static_cast<hipStream_t>(stream), cur, sd, c1, C, p, seed,
+                       step_ptr, out);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
+
+extern "C" int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int64_t p,
+                              int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
+                              double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0,
+                              double* win, int win_len, int64_t* step_ptr, void* stream) {
+    if (!prop || !sse_prop || !cur || !cur_lp || !best || !best_lp || !lps || !alphas || !nacc || !step_ptr ||
+        C <= 0 || p <= 0 || sigma <= 0.0 || (win && (!x0 || win_len <= 0))) {
+        qn_set_error("qn_mcmc_accept: bad argument");
+        return QN_EINVAL;
+    }
+    AcceptArgs a;
+    a.half_inv_sig2 = 0.5 / (sigma * sigma);
+    a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
+    a.C = C; a.nmcmc = nmcmc; a.win_len = win_len > 0 ? win_len : 1; a.p = p; a.seed = seed;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_accept, dim3(C), dim3(BLK), 0, static_cast<hipStream_t>(stream), a, prop, sse_prop, cur, cur_lp,
+                       best, best_lp, chain, lps, alphas, nacc, x0, win, step_ptr);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}

@@ -19,9 +19,8 @@ fdt = torch.float32 if len(sys.argv) > 1 and sys.argv[1] == "f32" else torch.flo
 tadapt = int(os.environ.get("TADAPT", "300"))
 res = {}
 # phase A: no adaptation inside the run
-eng = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=10 ** 6, seed=1)
-eng.tadapt = 64                       # window buffer size only (never adapts: the check uses i % tadapt with i > t0)
-eng.t0 = 10 ** 9
+UG = os.environ.get("USE_GRAPH", "1") == "1"
+eng = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=1000, seed=1, use_graph=UG)      # 300 steps: no adaptation yet
 eng.run(20, ini, store_chain=True)                      # warm-up (allocator, RNG, first launches)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 r = eng.run(300, ini, store_chain=True)
@@ -32,19 +31,20 @@ res["phaseA_accrate"] = float(r["accrate"].mean())
 del r, eng
 torch.cuda.empty_cache()
 # phase B: adaptation at step tadapt, then draws through the full factor
-eng = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=tadapt, seed=1, factor_dtype=fdt, chol_chunk=4)
+eng = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=tadapt, seed=1, factor_dtype=fdt, chol_chunk=4, use_graph=UG)
 n1 = tadapt + 1
 eng.run(n1, ini, store_chain=False)                     # warm-up incl. rocSOLVER / rocBLAS handles
-eng = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=tadapt, seed=1, factor_dtype=fdt, chol_chunk=4)
+eng = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=tadapt, seed=1, factor_dtype=fdt, chol_chunk=4, use_graph=UG)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 r = eng.run(n1, ini, store_chain=False)
 torch.cuda.synchronize(); t1 = time.perf_counter() - t0
-eng2 = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=tadapt, seed=1, factor_dtype=fdt, chol_chunk=4)
+eng2 = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=tadapt, seed=1, factor_dtype=fdt, chol_chunk=4, use_graph=UG)
 n2 = tadapt + 41
 torch.cuda.synchronize(); t0 = time.perf_counter()
 r2 = eng2.run(n2, ini, store_chain=False)
 torch.cuda.synchronize(); t2 = time.perf_counter() - t0
 res["factor_dtype"] = str(fdt)
+res["use_graph"] = UG
 res["tadapt"] = tadapt
 res["adaptation_seconds_incl_%d_steps" % n1] = t1
 res["phaseB_ms_per_step"] = 1e3 * (t2 - t1) / (n2 - n1)
