@@ -71,6 +71,42 @@ def cpu_baseline(arch, x, y, budget_s=16.0):
             "host_cpus": os.cpu_count()}
 
 
+def extras(op, arch, batches, args):
+    """Secondary measurements on the same resident workload (not part of `value`): the other kind of
+    eval (gradient <-> log-posterior) and the end-to-end device-resident AMCMC loop (proposal draw +
+    log-posterior + accept + history write per step, before the first adaptation)."""
+    out = {}
+    dev = op.device
+    other = "logpost" if args.kind == "grad" else "grad"
+    fn = (lambda W: op.sse(W)) if other == "logpost" else (lambda W: op.sse_grad(W))
+    for i in range(5):
+        fn(batches[i % NBATCH])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    n = 50
+    for i in range(n):
+        fn(batches[i % NBATCH])
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    flops = arch.flops_fwd(N) if other == "logpost" else arch.flops_fwdbwd(N)
+    out[other + "_evals_per_s"] = CHAINS * n / el
+    out[other + "_tflops"] = CHAINS * n * flops / el / 1e12
+    if args.dtype == "f64":
+        from quinn_amd.mcmc.device_amcmc import DeviceAMCMC
+        ini = np.stack([np.random.RandomState(1000 + c).rand(arch.nparams) for c in range(CHAINS)])
+        eng = DeviceAMCMC(op, SIGMA, gamma=0.01, t0=100, tadapt=1000, seed=1)
+        eng.run(20, ini, store_chain=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        r = eng.run(300, ini, store_chain=True)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        out["amcmc_end_to_end_steps_per_s"] = 300 / el
+        out["amcmc_end_to_end_logpost_evals_per_s"] = 300 * CHAINS / el
+        out["amcmc_accrate"] = float(r["accrate"].mean())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +115,7 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--kind", default="logpost", choices=["logpost", "grad"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (N=1 only)")
     ap.add_argument("--path", default="auto", choices=["auto", "generic", "fused"])
     args = ap.parse_args()
 
@@ -174,6 +211,8 @@ def main():
                          "traffic": traffic, "flops_per_eval": flops, "evals_per_launch": CHAINS,
                          "kernel_ms": kern_ms},
         }
+        if world == 1 and not args.no_extras:
+            res["extras"] = extras(op, arch, batches, args)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(arch, x, y)
         print(json.dumps(res), flush=True)
