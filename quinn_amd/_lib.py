@@ -38,7 +38,10 @@ def build(force=False, verbose=False):
             return LIBPATH
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", LIBPATH] + srcs
+    # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has one unified register file);
+    # without it hipcc copies every loop-carried accumulator VGPR<->AGPR per iteration (25 % of the GEMM loop)
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC", "-shared",
+           "-o", LIBPATH] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(BLK) void k_dW(LayerArgs a, const T* __restrict__ d
 // K-step's global loads are issued before the MFMAs of the current one.
 typedef double gv4d __attribute__((ext_vector_type(4)));
 enum { GEMM_FWD = 0, GEMM_DA = 1, GEMM_DW = 2 };
-constexpr int GSP = 18, GSQ = 80, GKB = 16;
+constexpr int GKB = 16, GSP = GKB + 2, GSQ = 80;   // K-step 32 halves the residency (76 KB LDS) and measured 18 % slower
 
 struct GemmArgs {
     int64_t p, offW, offB, out_stride_b, out_stride_k;
@@ -254,53 +254,60 @@ __global__ __launch_bounds__(BLK) void k_gemm64_f64(GemmArgs g, const double* __
     const double* I0 = in0 + (int64_t)b * (MODE == GEMM_FWD ? g.h_in : g.h_out) * Nb;
     const double* I1 = in1 ? in1 + (int64_t)b * g.h_in * Nb : nullptr;
 
-    double pr[4], qr[4];
+    // Each thread moves 8 + 8 doubles per K-step.  FWD / DA read out-of-range data columns (n >= Nb)
+    // from a clamped, valid address instead of masking: those output columns are never stored.
+    constexpr int NE = GKB / 4;                 // doubles per thread and operand per K-step
+    double pr[NE], qr[NE];
+    const int ncl = Nb - 1;
     auto gload = [&](int k0) {
         if (MODE == GEMM_FWD) {          // P[m][k] = W[j0+m][k0+k];  Q[k][n] = in[k0+k][n0+n]
-            const int m = tid >> 2, kq = (tid & 3) * 4;
+            const int m = tid >> 2, kq = (tid & 3) * NE;
+            const double* src = Wl + (int64_t)(m0 + m) * g.h_in + k0 + kq;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) pr[u] = Wl[(int64_t)(m0 + m) * g.h_in + k0 + kq + u];
-            const int k = tid >> 4, nq = (tid & 15) * 4;
+            for (int u = 0; u < NE; ++u) pr[u] = src[u];
+            const int k = tid / (64 / NE), nq = (tid % (64 / NE)) * NE;
+            const double* qs = I0 + (int64_t)(k0 + k) * Nb;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) qr[u] = n0 + nq + u < Nb ? I0[(int64_t)(k0 + k) * Nb + n0 + nq + u] : 0.0;
+            for (int u = 0; u < NE; ++u) { const int n = n0 + nq + u; qr[u] = qs[n < Nb ? n : ncl]; }
         } else if (MODE == GEMM_DA) {    // P[m][k] = W[k0+k][i0+m];  Q[k][n] = dz[k0+k][n0+n]
-            const int m = tid & 63, kq = (tid >> 6) * 4;
+            const int m = tid & 63, kq = (tid >> 6) * NE;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) pr[u] = Wl[(int64_t)(k0 + kq + u) * g.h_in + m0 + m];
-            const int k = tid >> 4, nq = (tid & 15) * 4;
+            for (int u = 0; u < NE; ++u) pr[u] = Wl[(int64_t)(k0 + kq + u) * g.h_in + m0 + m];
+            const int k = tid / (64 / NE), nq = (tid % (64 / NE)) * NE;
+            const double* qs = I0 + (int64_t)(k0 + k) * Nb;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) qr[u] = n0 + nq + u < Nb ? I0[(int64_t)(k0 + k) * Nb + n0 + nq + u] : 0.0;
+            for (int u = 0; u < NE; ++u) { const int n = n0 + nq + u; qr[u] = qs[n < Nb ? n : ncl]; }
         } else {                         // P[m][k] = dz[j0+m][k0+k];  Q[k][n] = a[i0+n][k0+k]   (k = data row)
-            const int m = tid >> 2, kq = (tid & 3) * 4;
+            const int m = tid >> 2, kq = (tid & 3) * NE;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) pr[u] = k0 + kq + u < kend ? I0[(int64_t)(m0 + m) * Nb + k0 + kq + u] : 0.0;
-            const int nn = tid & 63, kq2 = (tid >> 6) * 4;
+            for (int u = 0; u < NE; ++u) pr[u] = k0 + kq + u < kend ? I0[(int64_t)(m0 + m) * Nb + k0 + kq + u] : 0.0;
+            const int nn = tid & 63, kq2 = (tid >> 6) * NE;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) qr[u] = k0 + kq2 + u < kend ? I1[(int64_t)(n0 + nn) * Nb + k0 + kq2 + u] : 0.0;
+            for (int u = 0; u < NE; ++u) qr[u] = k0 + kq2 + u < kend ? I1[(int64_t)(n0 + nn) * Nb + k0 + kq2 + u] : 0.0;
         }
     };
     auto lstore = [&](int buf) {
         if (MODE == GEMM_FWD) {
-            const int m = tid >> 2, kq = (tid & 3) * 4;
+            const int m = tid >> 2, kq = (tid & 3) * NE;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) Ps[buf][m * GSP + kq + u] = pr[u];
-            const int k = tid >> 4, nq = (tid & 15) * 4;
+            for (int u = 0; u < NE; ++u) Ps[buf][m * GSP + kq + u] = pr[u];
+            const int k = tid / (64 / NE), nq = (tid % (64 / NE)) * NE;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) Qs[buf][k * GSQ + nq + u] = qr[u];
+            for (int u = 0; u < NE; ++u) Qs[buf][k * GSQ + nq + u] = qr[u];
         } else if (MODE == GEMM_DA) {
-            const int m = tid & 63, kq = (tid >> 6) * 4;
+            const int m = tid & 63, kq = (tid >> 6) * NE;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) Ps[buf][m * GSP + kq + u] = pr[u];
-            const int k = tid >> 4, nq = (tid & 15) * 4;
+            for (int u = 0; u < NE; ++u) Ps[buf][m * GSP + kq + u] = pr[u];
+            const int k = tid / (64 / NE), nq = (tid % (64 / NE)) * NE;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) Qs[buf][k * GSQ + nq + u] = qr[u];
+            for (int u = 0; u < NE; ++u) Qs[buf][k * GSQ + nq + u] = qr[u];
         } else {
-            const int m = tid >> 2, kq = (tid & 3) * 4;
+            const int m = tid >> 2, kq = (tid & 3) * NE;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) Ps[buf][m * GSP + kq + u] = pr[u];
-            const int nn = tid & 63, kq2 = (tid >> 6) * 4;
+            for (int u = 0; u < NE; ++u) Ps[buf][m * GSP + kq + u] = pr[u];
+            const int nn = tid & 63, kq2 = (tid >> 6) * NE;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) Qs[buf][(kq2 + u) * GSQ + nn] = qr[u];
+            for (int u = 0; u < NE; ++u) Qs[buf][(kq2 + u) * GSQ + nn] = qr[u];
         }
     };
 
