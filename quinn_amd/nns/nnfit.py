@@ -61,14 +61,17 @@ def draw_perms(nmembers, nepochs, ntrn):
 
 def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lrate=0.1, wd=0.0,
                 optimizer='adam', loss_fn='mse', datanoise=None, lmbd=None, perm_mode='reference',
-                device=None, dtype='float64', freq_out=100, verbose=True, perms=None):
+                device=None, dtype='float64', freq_out=100, verbose=True, perms=None, anchors=None,
+                prior_sigma=None):
     """Train M members in lock-step.
 
     Args:
         arch (MLPArch); W0 [M,p] initial flat weights; xtrn (N,d), ytrn (N,o): the FULL dataset;
         rows [M, ntrn] int: the dataset rows member j trains on; xval, yval: validation set
         shared by all members; perms: optional precomputed [M, nepochs, ntrn] permutations (a shard of
-        `draw_perms` when members are split over ranks); the rest as in `nnfit`.
+        `draw_perms` when members are split over ranks); anchors [M,p] + prior_sigma: per-member Gaussian
+        prior N(anchor, prior_sigma^2) added to the 'logpost' loss as the reference's NegLogPost does
+        (losses.py:202-204, weight len(batch)/ntrn; used by NN_RMS); the rest as in `nnfit`.
     Returns:
         dict with per-member arrays: 'best_w' [M,p], 'final_w' [M,p], 'best_loss' [M],
         'best_epoch' [M], 'best_fepoch' [M], 'history' [M, nupdates, 4].
@@ -94,6 +97,13 @@ def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lra
     else:
         print(f"Loss function {loss_fn} is unknown. Exiting.")
         sys.exit()
+    prior = None
+    if anchors is not None:
+        if loss_fn != 'logpost':
+            raise ValueError("a prior needs loss_fn='logpost'")
+        A = torch.as_tensor(np.asarray(anchors, dtype=np.float64), device=dev).reshape(M, p)
+        sp = float(prior_sigma)
+        prior = (A, sp, (p / 2) * np.log(2 * np.pi * sp ** 2))
     if optimizer not in ('adam', 'sgd'):
         print(f"Optimizer {optimizer} is unknown. Exiting.")
         sys.exit()
@@ -128,6 +138,16 @@ def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lra
             loss_val = tail(opv.sse(Wc), nval)
             if i == 0:
                 loss_full = tail(op.sse(Wc, row_idx=rows32), ntrn)
+            gextra = None
+            if prior is not None:                                  # NegLogPrior, losses.py:238-256
+                A, sp, cst = prior
+                dev2 = W - A
+                nlp = (dev2 * dev2).sum(dim=1) / 2 / sp ** 2 + cst
+                loss_trn = loss_trn + nb * nlp / ntrn
+                loss_val = loss_val + nval * nlp / ntrn
+                if i == 0:
+                    loss_full = loss_full + ntrn * nlp / ntrn
+                gextra = (nb / ntrn) * dev2 / sp ** 2
             fepoch += 1. / nsub
             hist[:, upd, 0] = fepoch
             hist[:, upd, 1] = loss_trn
@@ -139,10 +159,15 @@ def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lra
             best_epoch = torch.where(better, torch.full_like(best_epoch, t), best_epoch)
             best_fepoch = torch.where(better, torch.full_like(best_fepoch, fepoch), best_fepoch)
             step += 1
-            if optimizer == 'adam':
-                adam_step(W, g, m, v, lr, step, gscale=gscale(nb), wd=wd)
+            if gextra is not None:
+                g = g.double() * gscale(nb) + gextra
+                gs = 1.0
             else:
-                W.sub_(lr[:, None] * (g.double() * gscale(nb) + wd * W))
+                gs = gscale(nb)
+            if optimizer == 'adam':
+                adam_step(W, g, m, v, lr, step, gscale=gs, wd=wd)
+            else:
+                W.sub_(lr[:, None] * (g.double() * gs + wd * W))
             upd += 1
         if verbose and (t == 0 or (t + 1) % freq_out == 0 or t == nepochs - 1):
             if t == 0:

@@ -352,3 +352,29 @@ def timing_ratio():
 
 if __name__ == "__main__" and "timing" in sys.argv[1:]:
     timing_ratio()
+
+
+# ---------------------------------------------------------------- G9: NN_RMS (anchored ensemble)
+def g9():
+    from quinn.solvers.nn_rms import NN_RMS
+    d, o, hls, act, N = 1, 1, (8, 8), "tanh", 30
+    torch.manual_seed(80)
+    net = MLP(d, o, hls, activ=act)
+    w0 = NNWrap(net).p_flatten().detach().numpy().flatten()
+    x, y = data(N, d, o, 0.05, 37)
+    xv, yv = data(8, d, o, 0.05, 38)
+    rms = NN_RMS(net, nens=3, dfrac=0.8, verbose=False, datanoise=0.1, priorsigma=0.5)
+    np.random.seed(81)
+    torch.manual_seed(82)
+    rms.fit(x, y, val=[xv, yv], lrate=0.01, batch_size=8, nepochs=15, freq_out=1000)
+    hist = np.array([np.array(l.nnmodel.history) for l in rms.learners])
+    best = np.array([NNWrap(l.best_model).p_flatten().detach().numpy().flatten() for l in rms.learners])
+    final = np.array([np.concatenate([p.detach().flatten().numpy() for p in l.nnmodel.nnmodel.parameters()])
+                      for l in rms.learners])
+    save("g9_rms.npz", dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y, xval=xv, yval=yv, w0=w0,
+         nens=3, dfrac=0.8, lrate=0.01, batch_size=8, nepochs=15, np_seed=81, torch_seed=82, datanoise=0.1,
+         priorsigma=0.5, history=hist, best=best, final=final)
+
+
+if __name__ == "__main__" and "rms" in sys.argv[1:]:
+    g9()

@@ -139,3 +139,21 @@ def test_ensemble_shapes_two_outputs_device_rng():
     assert ens.predict_sample(x).shape == (40, 2)
     h = np.array([l.history for l in ens.learners])
     assert h.shape == (4, 30 * 2, 4) and (h[:, -1, 3] < h[:, 0, 3]).all()
+
+
+def test_g9_rms_anchored_ensemble_trajectories():
+    from quinn_amd.solvers.nn_rms import NN_RMS
+    g = load_golden("g9_rms.npz")
+    net = _net(g)
+    load_flat_into(net, g["w0"])
+    rms = NN_RMS(net, nens=int(g["nens"]), dfrac=float(g["dfrac"]), verbose=False, datanoise=float(g["datanoise"]),
+                 priorsigma=float(g["priorsigma"]))
+    np.random.seed(int(g["np_seed"]))
+    torch.manual_seed(int(g["torch_seed"]))
+    rms.fit(g["x"], g["y"], val=[g["xval"], g["yval"]], lrate=float(g["lrate"]), batch_size=int(g["batch_size"]),
+            nepochs=int(g["nepochs"]), freq_out=1000)
+    hist = np.array([l.history for l in rms.learners])
+    np.testing.assert_allclose(hist, g["history"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(rms.fit_results["best_w"], g["best"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(rms.fit_results["final_w"], g["final"], rtol=1e-9, atol=1e-11)
+    assert rms.predict_ens(g["x"]).shape == (3, g["x"].shape[0], 1)
