@@ -93,7 +93,7 @@ class NN_MCMC(QUiNNBase):
         Build-only: nchains (C independent chains in lock-step), seeds (C ints; chain c then
             equals a reference run preceded by np.random.seed(seeds[c])).  With nchains=1 and
             seeds=None the global numpy RNG is used, exactly like the reference.
-            engine='device' (sampler 'amcmc' only): states, proposal factors and history stay on the
+            engine='device' (samplers 'amcmc' and 'hmc'): states, proposal factors and history stay on the
             GPU, no host synchronisation per step (`quinn_amd.mcmc.device_amcmc`); same target and
             adaptation schedule, chains equal the host engine in distribution, not bit for bit.
         """
@@ -123,11 +123,15 @@ class NN_MCMC(QUiNNBase):
 
         sampler_params = dict(sampler_params)      # None raises, as in the reference
         if engine == 'device':
-            if sampler != 'amcmc':
-                raise ValueError("engine='device' is implemented for sampler='amcmc'")
-            from ..mcmc.device_amcmc import DeviceAMCMC
             op = self._operator(self.lpinfo)
-            eng = DeviceAMCMC(op, datanoise, seed=(seeds[0] if seeds else 0), **sampler_params)
+            if sampler == 'amcmc':
+                from ..mcmc.device_amcmc import DeviceAMCMC
+                eng = DeviceAMCMC(op, datanoise, seed=(seeds[0] if seeds else 0), **sampler_params)
+            elif sampler == 'hmc':
+                from ..mcmc.device_hmc import DeviceHMC
+                eng = DeviceHMC(op, datanoise, seed=(seeds[0] if seeds else 0), **sampler_params)
+            else:
+                raise ValueError("engine='device' is implemented for sampler='amcmc' and 'hmc'")
             res = eng.run(nmcmc, np.atleast_2d(param_ini), verbose=self.verbose)
             self.mcmc_results = {k: (v.cpu().numpy() if v is not None else None) for k, v in res.items()}
             if np.ndim(param_ini) == 1:

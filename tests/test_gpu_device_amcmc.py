@@ -66,3 +66,26 @@ def test_device_engine_matches_host_sampler_in_distribution():
     se = np.sqrt(mh.var(ddof=1) / C + md.var(ddof=1) / C)
     assert abs(mh.mean() - md.mean()) < 5 * se + 0.5, (mh.mean(), md.mean(), se)
     assert abs(lh.std(axis=1).mean() - ld.std(axis=1).mean()) < 0.5 * lh.std(axis=1).mean() + 0.5
+
+
+def test_device_hmc_matches_host_hmc_in_distribution():
+    """The leapfrog with the cached-gradient / reused-SSE shortcuts samples the same posterior as the
+    host HMC (which is bit-exact to the reference): acceptance rate and stationary log-posterior."""
+    x, y = _problem(2)
+    torch.manual_seed(2)
+    net = MLP(1, 1, (4,), activ='tanh')
+    C, nmcmc = 24, 600
+    ini = np.stack([0.3 * np.random.RandomState(400 + c).randn(13) for c in range(C)])
+    out = {}
+    for engine in ('host', 'device'):
+        solver = NN_MCMC(net, verbose=False)
+        solver.fit(x, y, zflag=False, datanoise=0.3, nmcmc=nmcmc, param_ini=ini, sampler='hmc',
+                   sampler_params={'epsilon': 0.02, 'L': 5}, seeds=list(range(500, 500 + C)), engine=engine)
+        r = solver.mcmc_results
+        assert np.asarray(r['chain']).shape == (C, nmcmc + 1, 13)
+        out[engine] = (np.asarray(r['accrate']), np.asarray(r['logpost'])[:, nmcmc // 2:])
+    (ah, lh), (ad, ld) = out['host'], out['device']
+    assert ah.mean() > 0.5 and abs(ah.mean() - ad.mean()) < 0.08, (ah.mean(), ad.mean())
+    mh, md = lh.mean(axis=1), ld.mean(axis=1)
+    se = np.sqrt(mh.var(ddof=1) / C + md.var(ddof=1) / C)
+    assert abs(mh.mean() - md.mean()) < 5 * se + 0.5, (mh.mean(), md.mean(), se)
