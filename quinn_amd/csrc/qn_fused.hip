@@ -23,6 +23,7 @@
 // data row).  SSE partials are reduced in a fixed order (bitwise reproducible).
 #include "qn_common.h"
 #include "qn_math.h"
+#include <cstdlib>
 #include <mutex>
 #include <unordered_set>
 
@@ -65,11 +66,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Copy weight vector `Wb` into the LDS image.  Loads are issued in batches (all of a layer's
 // loads in flight before the first LDS write): a load->wait->write loop costs one memory round
 // trip per 2 KB and was ~15 % of the kernel.
-template <int H, int DP>
+template <int H, int DP, int NT = WG>
 __device__ __forceinline__ void stage_weights(double* __restrict__ lds, const double* __restrict__ Wb,
                                               const FusedArgs& a) {
     constexpr int S = stride_of(H);
-    constexpr int PER = (H * H + WG - 1) / WG;
+    constexpr int PER = (H * H + NT - 1) / NT;
     const int tid = threadIdx.x;
     const int d = a.d, o = a.o;
     const int nb = a.has_bias ? 1 : 0;
@@ -81,17 +82,17 @@ __device__ __forceinline__ void stage_weights(double* __restrict__ lds, const do
         const int64_t gbl = gWl + (int64_t)o * H;
         const int lW0 = 0, lb0 = H * DP, lHH = lb0 + H;
         const int lWl = lHH + (a.nhid - 1) * (H * S + H), lbl = lWl + o * H;
-        for (int e = tid; e < H * DP; e += WG) {
+        for (int e = tid; e < H * DP; e += NT) {
             const int j = e / DP, k = e % DP;
             lds[lW0 + e] = k < d ? Wb[gW0 + j * d + k] : 0.0;
         }
-        for (int e = tid; e < H; e += WG) lds[lb0 + e] = nb ? Wb[gb0 + e] : 0.0;
+        for (int e = tid; e < H; e += NT) lds[lb0 + e] = nb ? Wb[gb0 + e] : 0.0;
         for (int layer = 1; layer < a.nhid; ++layer)
-            for (int e = tid; e < H; e += WG)
+            for (int e = tid; e < H; e += NT)
                 lds[lHH + (layer - 1) * (H * S + H) + H * S + e] =
                     nb ? Wb[gHH + (int64_t)(layer - 1) * (H * H + H) + H * H + e] : 0.0;
-        for (int e = tid; e < o * H; e += WG) lds[lWl + e] = Wb[gWl + e];
-        for (int e = tid; e < o; e += WG) lds[lbl + e] = nb ? Wb[gbl + e] : 0.0;
+        for (int e = tid; e < o * H; e += NT) lds[lWl + e] = Wb[gWl + e];
+        for (int e = tid; e < o; e += NT) lds[lbl + e] = nb ? Wb[gbl + e] : 0.0;
     }
     // hidden->hidden matrices, swizzled
     int64_t g = (int64_t)H * d + nb * H;
@@ -100,13 +101,13 @@ __device__ __forceinline__ void stage_weights(double* __restrict__ lds, const do
         double v[PER];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int e = tid + u * WG;
-            v[u] = (H * H % WG == 0 || e < H * H) ? Wb[g + e] : 0.0;
+            const int e = tid + u * NT;
+            v[u] = (H * H % NT == 0 || e < H * H) ? Wb[g + e] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int e = tid + u * WG;
-            if (H * H % WG == 0 || e < H * H) {
+            const int e = tid + u * NT;
+            if (H * H % NT == 0 || e < H * H) {
                 const int j = e / H, i = e % H;
                 lds[l + j * S + (i ^ swz(j))] = v[u];
             }
@@ -116,8 +117,8 @@ __device__ __forceinline__ void stage_weights(double* __restrict__ lds, const do
     }
 }
 
-template <int H, int G, int ACT, int DP>
-__global__ __launch_bounds__(WG, 2) void k_fused_fwd_f64(FusedArgs a, const double* __restrict__ W,
+template <int H, int G, int ACT, int DP, int NT>
+__global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, const double* __restrict__ W,
                                                       const double* __restrict__ X, const double* __restrict__ Y,
                                                       const int32_t* __restrict__ row_idx,
                                                       double* __restrict__ pred_out, double* __restrict__ partial) {
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(WG, 2) void k_fused_fwd_f64(FusedArgs a, const doub
     const int offWl = offHH + (NH - 1) * (H * S + H), offbl = offWl + o * H;
     double* red = lds + ((offbl + o + 1) & ~1);      // 4 doubles behind the weight image
 
-    stage_weights<H, DP>(lds, W + (int64_t)b * a.p, a);
+    stage_weights<H, DP, NT>(lds, W + (int64_t)b * a.p, a);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(WG, 2) void k_fused_fwd_f64(FusedArgs a, const doub
     int nrow_n[G];
     bool valid_n[G];
     auto fetch = [&](int it) {
-        const int nbase = split * a.rows_per_split + (it * (WG / 64) + wave) * 16 * G;
+        const int nbase = split * a.rows_per_split + (it * (NT / 64) + wave) * 16 * G;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int n = nbase + 16 * g + c;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(WG, 2) void k_fused_fwd_f64(FusedArgs a, const doub
     __syncthreads();
     if (threadIdx.x == 0) {
         double s = 0.0;
-        for (int w = 0; w < WG / 64; ++w) s += red[w];
+        for (int w = 0; w < NT / 64; ++w) s += red[w];
         partial[(int64_t)b * a.nsplit + split] = s;
     }
 }
@@ -756,8 +757,13 @@ using fwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, 
 using bwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*,
                         double*);
 
+// Forward geometry: 4 waves x 2 row groups per workgroup (2 workgroups / CU, 2 waves / SIMD).  The
+// alternative 8 waves x 1 row group (4 waves / SIMD, same 128 rows per iteration) measured 3.5 % slower
+// at cfg2 (462 k vs 480 k evals/s): occupancy is not the lever on a serial DP pipe.
 fwd_fn pick_fwd(int H, int act, int dp) {
-#define QN_PICK(HH, AA, DD) if (H == HH && act == AA && dp == DD) return k_fused_fwd_f64<HH, G_FWD, AA, DD>;
+#define QN_PICK(HH, AA, DD)                                                                    \
+    if (H == HH && act == AA && dp == DD)                                                      \
+        return k_fused_fwd_f64<HH, G_FWD, AA, DD, WG>;
 #define QN_PICK_H(HH)                                                                          \
     QN_PICK(HH, QN_ACT_TANH, 2) QN_PICK(HH, QN_ACT_TANH, 4) QN_PICK(HH, QN_ACT_RELU, 2)        \
     QN_PICK(HH, QN_ACT_RELU, 4) QN_PICK(HH, QN_ACT_IDENTITY, 2) QN_PICK(HH, QN_ACT_IDENTITY, 4)
@@ -840,8 +846,8 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
             return QN_EUNSUPPORTED;
         }
         if (int rc = arm_lds(reinterpret_cast<const void*>(kern))) return rc;
-        hipLaunchKernelGGL(kern, grid, dim3(WG), lds_bytes, st, a, (const double*)W, (const double*)X,
-                           (const double*)Y, row_idx, (double*)pred, partial);
+        hipLaunchKernelGGL(kern, grid, dim3(WG), lds_bytes, st, a, (const double*)W,
+                           (const double*)X, (const double*)Y, row_idx, (double*)pred, partial);
     } else {
         bwd_fn kern = pick_bwd(H, nhid);
         if (!kern) {
