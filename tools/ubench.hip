@@ -10,11 +10,14 @@
 #include <algorithm>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 constexpr int ITER = 512;
 
-// role: 0 = MFMA f64, 1 = VALU f64 fma, 2 = VALU f32 fma, 3 = idle
+// role: 0 = MFMA f64, 1 = VALU f64 fma, 2 = VALU f32 fma, 3 = idle, 4 = MFMA f32 16x16x4, 5 = MFMA f32 32x32x2,
+//       6 = f32 transcendental mix (exp2 + rcp + fma)
 template <int ROLE_A, int ROLE_B>
 __global__ void k_roles(double* out, long long* cyc, int waves_a) {
     const int wave = threadIdx.x >> 6;
@@ -41,6 +44,30 @@ __global__ void k_roles(double* out, long long* cyc, int waves_a) {
         for (int it = 0; it < ITER * 16; ++it) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) g[i] = fmaf(g[i], 0.999f, 0.001f);
+        }
+    } else if (role == 4) {
+        v4f fa[8];
+        for (int i = 0; i < 8; ++i) fa[i] = (v4f){(float)x, 0.f, 0.f, 0.f};
+        for (int it = 0; it < ITER * 2; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)x, (float)x, fa[i], 0, 0, 0);
+        }
+        for (int i = 0; i < 8; ++i) g[i] += fa[i][0] + fa[i][3];
+    } else if (role == 5) {
+        v16f fb[4];
+        for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) fb[i][k] = (float)x;
+        for (int it = 0; it < ITER * 2; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fb[i] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)x, (float)x, fb[i], 0, 0, 0);
+        }
+        for (int i = 0; i < 4; ++i) g[i] += fb[i][0] + fb[i][15];
+    } else if (role == 6) {
+        for (int it = 0; it < ITER * 4; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f(g[i] * 0.01f);
+                g[i] = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f) + g[i] * 0.5f;
+            }
         }
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
@@ -143,6 +170,12 @@ int main() {
     hipLaunchKernelGGL((k_roles<0, 1>), dim3(NB), dim3(512), 0, 0, out, cyc, 4);  report("A=MFMAf64  B=FMAf64 (same SIMD)", 8, 4, NM);
     hipLaunchKernelGGL((k_roles<0, 2>), dim3(NB), dim3(512), 0, 0, out, cyc, 4);  report("A=MFMAf64  B=FMAf32 (same SIMD)", 8, 4, NM);
     hipLaunchKernelGGL((k_roles<1, 2>), dim3(NB), dim3(512), 0, 0, out, cyc, 4);  report("A=FMAf64   B=FMAf32 (same SIMD)", 8, 4, ITER * 8.0 * 16);
+    hipLaunchKernelGGL((k_roles<4, 3>), dim3(NB), dim3(256), 0, 0, out, cyc, 4);  report("MFMAf32 16x16x4 alone       [per MFMA]", 4, 4, ITER * 16.0);
+    hipLaunchKernelGGL((k_roles<5, 3>), dim3(NB), dim3(256), 0, 0, out, cyc, 4);  report("MFMAf32 32x32x2 alone       [per MFMA]", 4, 4, ITER * 8.0);
+    hipLaunchKernelGGL((k_roles<4, 2>), dim3(NB), dim3(512), 0, 0, out, cyc, 4);  report("A=MFMAf32 16x16x4 B=FMAf32 (B alone 385804)", 8, 4, ITER * 16.0);
+    hipLaunchKernelGGL((k_roles<5, 2>), dim3(NB), dim3(512), 0, 0, out, cyc, 4);  report("A=MFMAf32 32x32x2 B=FMAf32 (B alone 385804)", 8, 4, ITER * 8.0);
+    hipLaunchKernelGGL((k_roles<6, 3>), dim3(NB), dim3(256), 0, 0, out, cyc, 4);  report("f32 tanh-like mix alone      [per element]", 4, 4, ITER * 4.0 * 16);
+    hipLaunchKernelGGL((k_roles<4, 6>), dim3(NB), dim3(512), 0, 0, out, cyc, 4);  report("A=MFMAf32 16x16x4 B=f32 tanh mix", 8, 4, ITER * 16.0);
     const double NI = ITER * 4.0;
 #define IL(K, F) hipLaunchKernelGGL((k_interleave<K, F>), dim3(NB), dim3(256), 0, 0, out, cyc); report(F ? "1 wave: MFMA + " #K " f32 FMA [per MFMA]" : "1 wave: MFMA + " #K " f64 FMA [per MFMA]", 4, 4, NI);
     IL(0, 0) IL(2, 0) IL(4, 0) IL(8, 0) IL(12, 0) IL(16, 0) IL(4, 1) IL(8, 1) IL(16, 1)
