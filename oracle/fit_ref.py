@@ -156,3 +156,30 @@ def _viloss_attached(spec, mu_t, rho_t, eps, x_t, y_t, datanoise, nb, shapes,
     nll = (B * torch.log(dsig) + 0.5 * B * torch.log(2.0 * torch.tensor(math.pi, dtype=F64))
            + 0.5 * B * ((outputs - y_t) ** 2).mean() / dsig ** 2)
     return ((lqs.mean() - lps.mean()) / nb + nll).squeeze()
+
+
+def fit_member_plateau(spec, w0, xtrn, ytrn, xval, yval, nepochs, batch_size, lrate, gen, cooldown, factor):
+    """fit_member_mse with torch's ReduceLROnPlateau stepped once per epoch on the epoch's last
+    validation loss (nnfit.py:91-92, 170-172)."""
+    mod = build_module(spec)
+    load_flat(mod, w0)
+    xt, yt = torch.as_tensor(xtrn, dtype=F64), torch.as_tensor(ytrn, dtype=F64)
+    xv, yv = torch.as_tensor(xval, dtype=F64), torch.as_tensor(yval, dtype=F64)
+    mse = torch.nn.MSELoss(reduction="mean")
+    opt = torch.optim.Adam(mod.parameters(), lr=lrate)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode='min', cooldown=cooldown, factor=factor)
+    ntrn = xt.shape[0]
+    bs = ntrn if batch_size is None or batch_size > ntrn else batch_size
+    hist, lrs = [], []
+    for t in range(nepochs):
+        perm = torch.randperm(ntrn, generator=gen)
+        for i in range(0, ntrn, bs):
+            idx = perm[i:i + bs]
+            loss = mse(mod(xt[idx]), yt[idx])
+            with torch.no_grad():
+                lv = mse(mod(xv), yv)
+            hist.append([loss.item(), lv.item()])
+            opt.zero_grad(); loss.backward(); opt.step()
+        sched.step(hist[-1][1])
+        lrs.append(opt.param_groups[0]['lr'])
+    return {"history": np.array(hist), "lrs": np.array(lrs), "final": flat_params(mod)}

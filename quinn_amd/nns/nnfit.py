@@ -62,7 +62,7 @@ def draw_perms(nmembers, nepochs, ntrn):
 def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lrate=0.1, wd=0.0,
                 optimizer='adam', loss_fn='mse', datanoise=None, lmbd=None, perm_mode='reference',
                 device=None, dtype='float64', freq_out=100, verbose=True, perms=None, anchors=None,
-                prior_sigma=None):
+                prior_sigma=None, scheduler_lr=None, cooldown=100, factor=0.95):
     """Train M members in lock-step.
 
     Args:
@@ -126,8 +126,13 @@ def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lra
     rows32 = rows_d.to(torch.int32)
     fepoch, upd, step = 0.0, 0, 0
     loss_full = None
+    plateau = None
+    if scheduler_lr == "ReduceLROnPlateau":
+        plateau = PlateauLR(M, lrate, factor, cooldown, dev)
+    elif scheduler_lr is not None:
+        raise NotImplementedError(f"scheduler {scheduler_lr!r}")
     for t in range(nepochs):
-        lr = torch.full((M,), lrate * lmbd(t), dtype=torch.float64, device=dev)
+        lr = plateau.lr if plateau is not None else torch.full((M,), lrate * lmbd(t), dtype=torch.float64, device=dev)
         perm = perms[:, t] if perm_mode == 'reference' else torch.rand(M, ntrn, device=dev).argsort(dim=1)
         for i in range(0, ntrn, batch_size):
             idx = torch.gather(rows_d, 1, perm[:, i:i + batch_size]).to(torch.int32)
@@ -169,6 +174,8 @@ def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lra
             else:
                 W.sub_(lr[:, None] * (g.double() * gs + wd * W))
             upd += 1
+        if plateau is not None:
+            plateau.step(hist[:, upd - 1, 3])                   # scheduler.step(curr_state[3]), nnfit.py:170-172
         if verbose and (t == 0 or (t + 1) % freq_out == 0 or t == nepochs - 1):
             if t == 0:
                 print('{:>10} {:>10} {:>12} {:>12} {:>12} {:>18} {:>10}'.format(
@@ -179,6 +186,34 @@ def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lra
     return {'best_w': best_w.cpu().numpy(), 'final_w': W.cpu().numpy(), 'best_loss': best_loss.cpu().numpy(),
             'best_epoch': best_epoch.cpu().numpy(), 'best_fepoch': best_fepoch.cpu().numpy(),
             'history': hist.cpu().numpy()}
+
+
+class PlateauLR:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', factor, cooldown) with torch's other defaults
+    (patience 10, relative threshold 1e-4, min_lr 0, eps 1e-8), vectorised over M members on the device
+    (the reference builds one per member, nnfit.py:91-92)."""
+
+    def __init__(self, M, lr0, factor, cooldown, device, patience=10, threshold=1e-4, eps=1e-8):
+        f64 = torch.float64
+        self.lr = torch.full((M,), float(lr0), dtype=f64, device=device)
+        self.best = torch.full((M,), float('inf'), dtype=f64, device=device)
+        self.bad = torch.zeros(M, dtype=torch.int64, device=device)
+        self.cool = torch.zeros(M, dtype=torch.int64, device=device)
+        self.factor, self.cooldown, self.patience, self.threshold, self.eps = factor, cooldown, patience, threshold, eps
+
+    def step(self, metric):
+        better = metric < self.best * (1.0 - self.threshold)
+        self.best = torch.where(better, metric, self.best)
+        self.bad = torch.where(better, torch.zeros_like(self.bad), self.bad + 1)
+        in_cool = self.cool > 0
+        self.cool = torch.where(in_cool, self.cool - 1, self.cool)
+        self.bad = torch.where(in_cool, torch.zeros_like(self.bad), self.bad)
+        reduce = self.bad > self.patience
+        new_lr = self.lr * self.factor
+        apply = reduce & ((self.lr - new_lr) > self.eps)
+        self.lr = torch.where(apply, new_lr, self.lr)
+        self.cool = torch.where(reduce, torch.full_like(self.cool, self.cooldown), self.cool)
+        self.bad = torch.where(reduce, torch.zeros_like(self.bad), self.bad)
 
 
 class _FlatAdam:
@@ -209,11 +244,9 @@ def nnfit(nnmodel, xtrn, ytrn, val=None, loss_fn='mse', loss_xy=None, datanoise=
           *, device=None, dtype='float64', perm_mode='reference'):
     """Train `nnmodel` (reference signature and result keys: 'best_fepoch', 'best_epoch',
     'best_loss', 'best_nnmodel', 'history').  `nnmodel` is trained in place, as in the reference."""
-    if scheduler_lr == "ReduceLROnPlateau":
-        if lmbd is not None:
-            print("Trying to use two schedulers. Exiting.")
-            sys.exit()
-        raise NotImplementedError("ReduceLROnPlateau is not part of the accelerated path yet")
+    if scheduler_lr == "ReduceLROnPlateau" and lmbd is not None:
+        print("Trying to use two schedulers. Exiting.")
+        sys.exit()
     if priorparams is not None:
         raise NotImplementedError("prior terms (NegLogPrior / NN_RMS) are not part of the accelerated path yet")
     ntrn = xtrn.shape[0]
@@ -227,7 +260,7 @@ def nnfit(nnmodel, xtrn, ytrn, val=None, loss_fn='mse', loss_xy=None, datanoise=
         res = fit_members(arch, flatten_module(nnmodel)[None, :], xtrn, ytrn, np.arange(ntrn)[None, :], xval, yval,
                           nepochs, batch_size, lrate=lrate, wd=wd, optimizer=optimizer, loss_fn=loss_fn,
                           datanoise=datanoise, lmbd=lmbd, perm_mode=perm_mode, device=device, dtype=dtype,
-                          freq_out=freq_out)
+                          freq_out=freq_out, scheduler_lr=scheduler_lr, cooldown=cooldown, factor=factor)
         load_flat_into(nnmodel, res['final_w'][0])
         best = copy.deepcopy(nnmodel)
         load_flat_into(best, res['best_w'][0])
@@ -250,8 +283,9 @@ def nnfit(nnmodel, xtrn, ytrn, val=None, loss_fn='mse', loss_xy=None, datanoise=
     yv = torch.as_tensor(np.asarray(yval), dtype=torch.float64, device=dev)
     fit_info = {'best_fepoch': 0, 'best_epoch': 0, 'best_loss': 1.e+100, 'best_nnmodel': nnmodel, 'history': []}
     fepoch = 0
+    plateau = PlateauLR(1, lrate, factor, cooldown, dev) if scheduler_lr == "ReduceLROnPlateau" else None
     for t in range(nepochs):
-        opt.param_groups[0]['lr'] = lrate * lmbd(t)
+        opt.param_groups[0]['lr'] = float(plateau.lr[0]) if plateau is not None else lrate * lmbd(t)
         permutation = torch.randperm(ntrn)
         nsub = len(range(0, ntrn, batch_size))
         for i in range(0, ntrn, batch_size):
@@ -273,6 +307,8 @@ def nnfit(nnmodel, xtrn, ytrn, val=None, loss_fn='mse', loss_xy=None, datanoise=
             opt.zero_grad()
             loss_trn.backward()
             opt.step()
+        if plateau is not None:
+            plateau.step(torch.tensor([fit_info['history'][-1][3]], dtype=torch.float64, device=dev))
         if t == 0:
             print('{:>10} {:>10} {:>12} {:>12} {:>12} {:>18} {:>10}'.format(
                 "NEpochs", "NUpdates", "BatchLoss", "TrnLoss", "ValLoss", "BestLoss (Epoch)", "LrnRate"), flush=True)

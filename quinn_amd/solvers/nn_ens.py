@@ -44,10 +44,10 @@ class NN_Ens(QUiNNBase):
         # sees xtrn[ind_this]); a shared explicit validation set is the common case
         if val is None and self.dfrac < 1.0:
             raise NotImplementedError("dfrac < 1 without an explicit val=[xval, yval] set")
-        for k in ('freq_plot', 'lhist_suffix', 'gradcheck', 'cooldown', 'factor', 'lossparams'):
+        for k in ('freq_plot', 'lhist_suffix', 'gradcheck', 'lossparams'):
             kwargs.pop(k, None)
-        if kwargs.pop('scheduler_lr', None) is not None or kwargs.pop('priorparams', None) is not None:
-            raise NotImplementedError("schedulers / priors are not part of the accelerated path yet")
+        if kwargs.pop('priorparams', None) is not None:
+            raise NotImplementedError("use NN_RMS for a Gaussian prior")
         w0 = flatten_module(self.learners[0].nnmodel)
         nepochs = kwargs.pop('nepochs', 5000)
         # members shard over ranks (torch.distributed); every rank consumes the random streams of ALL

@@ -31,11 +31,8 @@ class NN_RMS(NN_Ens):
         if val is None:
             raise NotImplementedError("NN_RMS on the accelerated path needs an explicit val=[xval, yval] set")
         xval, yval = val
-        for k in ('freq_plot', 'lhist_suffix', 'gradcheck', 'cooldown', 'factor', 'lossparams', 'loss_fn',
-                  'datanoise', 'priorparams'):
+        for k in ('freq_plot', 'lhist_suffix', 'gradcheck', 'lossparams', 'loss_fn', 'datanoise', 'priorparams'):
             kwargs.pop(k, None)
-        if kwargs.pop('scheduler_lr', None) is not None:
-            raise NotImplementedError("schedulers are not part of the accelerated path yet")
         nepochs = kwargs.pop('nepochs', 5000)
         nsub = rows.shape[1]
         anchors = np.empty((self.nens, self.nparams))

@@ -157,3 +157,22 @@ def test_g9_rms_anchored_ensemble_trajectories():
     np.testing.assert_allclose(rms.fit_results["best_w"], g["best"], rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(rms.fit_results["final_w"], g["final"], rtol=1e-9, atol=1e-11)
     assert rms.predict_ens(g["x"]).shape == (3, g["x"].shape[0], 1)
+
+
+def test_reduce_lr_on_plateau_matches_torch_scheduler():
+    g = load_golden("g6_ens.npz")
+    spec = spec_of(g)
+    net = _net(g)
+    load_flat_into(net, g["w0"])
+    x, y, xv, yv = g["x"][:24], g["y"][:24], g["xval"], g["yval"]
+    gen = torch.Generator(); gen.manual_seed(9)
+    ref = fit_ref.fit_member_plateau(spec, g["w0"], x, y, xv, yv, 60, 12, 0.05, gen, cooldown=3, factor=0.5)
+    assert ref["lrs"][-1] < 0.05                                        # the schedule actually fired
+    torch.manual_seed(9)
+    info = nnfit(net, x, y, val=[xv, yv], lrate=0.05, batch_size=12, nepochs=60, scheduler_lr="ReduceLROnPlateau",
+                 cooldown=3, factor=0.5, freq_out=1000)
+    h = np.array(info["history"])
+    np.testing.assert_allclose(h[:, 1], ref["history"][:, 0], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(h[:, 3], ref["history"][:, 1], rtol=1e-8, atol=1e-11)
+    fin = np.concatenate([q.detach().flatten().numpy() for q in net.parameters()])
+    np.testing.assert_allclose(fin, ref["final"], rtol=1e-8, atol=1e-10)
