@@ -368,6 +368,15 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
     for (int k = 0; k < NH; ++k) dbacc[k] = 0.0;
     double dW0acc[DP], dWlacc[OMAX], dblacc[OMAX] = {0.0, 0.0, 0.0, 0.0};
+    // o == 1 and d == 1 (every BASELINE config): the thin layers' gradients are accumulated lane-locally in the
+    // accumulator layout over all iterations and reduced across lanes / waves ONCE at the end, instead of two
+    // stash round trips (4 barriers + column sums) per iteration
+    const bool thin_fast = (o == 1 && d == 1);
+    double accWl[T][4], accW0[T][4], accB0[T][4], accBl = 0.0;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accWl[t][i] = accW0[t][i] = accB0[t][i] = 0.0;
 #pragma unroll
     for (int k = 0; k < DP; ++k) dW0acc[k] = 0.0;
 #pragma unroll
@@ -455,37 +464,45 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
         }
         QN_STAMP(2);                                       // 2: last layer + residual
         // ------------------------------------------------------------------ backward: last layer
-        __syncthreads();                                   // previous iteration's stash readers are done
-        QN_STAMP(3);                                       // 3: barrier A (last stage)
+        if (thin_fast) {
 #pragma unroll
-        for (int t = 0; t < T; ++t)
+            for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) SA[(16 * t + q + 4 * i) * NSP + wrow] = alast[t][i];
-        if (q == 0) {
-#pragma unroll
-            for (int qo = 0; qo < OMAX; ++qo) Sdl[wrow * OMAX + qo] = delta[qo];
-#pragma unroll
-            for (int k = 0; k < DP; ++k) Sx[wrow * DP + k] = xk[k];
-        }
-        __syncthreads();
-        QN_STAMP(4);                                       // 4: stash write + barrier B (last stage)
-        {
-            double sum[OMAX] = {0.0, 0.0, 0.0, 0.0}, sdl[OMAX] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-            for (int rr = 0; rr < RPT; ++rr) {
-                const int row = part + TPF * rr;          // interleaved rows: conflict-free Sdl / Sx reads
-                const double av = SA[fj * NSP + row];
-#pragma unroll
-                for (int qo = 0; qo < OMAX; ++qo) {
-                    const double dv = Sdl[row * OMAX + qo];
-                    sum[qo] = fma(av, dv, sum[qo]);
-                    sdl[qo] += dv;                        // every feature's threads see all deltas: feature 0 keeps the bias sum
-                }
+                for (int i = 0; i < 4; ++i) accWl[t][i] = fma(delta[0], alast[t][i], accWl[t][i]);
+            if (q == 0) accBl += delta[0];
+        } else {
+            __syncthreads();                                   // previous iteration's stash readers are done
+            QN_STAMP(3);                                       // 3: barrier A (last stage)
+    #pragma unroll
+            for (int t = 0; t < T; ++t)
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) SA[(16 * t + q + 4 * i) * NSP + wrow] = alast[t][i];
+            if (q == 0) {
+    #pragma unroll
+                for (int qo = 0; qo < OMAX; ++qo) Sdl[wrow * OMAX + qo] = delta[qo];
+    #pragma unroll
+                for (int k = 0; k < DP; ++k) Sx[wrow * DP + k] = xk[k];
             }
-#pragma unroll
-            for (int qo = 0; qo < OMAX; ++qo) {
-                dWlacc[qo] += sum[qo];
-                dblacc[qo] += sdl[qo];
+            __syncthreads();
+            QN_STAMP(4);                                       // 4: stash write + barrier B (last stage)
+            {
+                double sum[OMAX] = {0.0, 0.0, 0.0, 0.0}, sdl[OMAX] = {0.0, 0.0, 0.0, 0.0};
+    #pragma unroll 4
+                for (int rr = 0; rr < RPT; ++rr) {
+                    const int row = part + TPF * rr;          // interleaved rows: conflict-free Sdl / Sx reads
+                    const double av = SA[fj * NSP + row];
+    #pragma unroll
+                    for (int qo = 0; qo < OMAX; ++qo) {
+                        const double dv = Sdl[row * OMAX + qo];
+                        sum[qo] = fma(av, dv, sum[qo]);
+                        sdl[qo] += dv;                        // every feature's threads see all deltas: feature 0 keeps the bias sum
+                    }
+                }
+    #pragma unroll
+                for (int qo = 0; qo < OMAX; ++qo) {
+                    dWlacc[qo] += sum[qo];
+                    dblacc[qo] += sdl[qo];
+                }
             }
         }
         double dz[T][4];
@@ -609,27 +626,37 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
             }
         }
         // ------------------------------------------------------------------ backward: first layer
-        __syncthreads();
+        if (thin_fast) {
 #pragma unroll
-        for (int t = 0; t < T; ++t)
+            for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) SD[(16 * t + q + 4 * i) * NSP + wrow] = dz[t][i];
-        __syncthreads();
-        {
-            double sb = 0.0, sw0[DP];
-#pragma unroll
-            for (int k = 0; k < DP; ++k) sw0[k] = 0.0;
-#pragma unroll 4
-            for (int rr = 0; rr < RPT; ++rr) {
-                const int row = part + TPF * rr;
-                const double g = SD[fj * NSP + row];
-                sb += g;
-#pragma unroll
-                for (int k = 0; k < DP; ++k) sw0[k] = fma(g, Sx[row * DP + k], sw0[k]);
+                for (int i = 0; i < 4; ++i) {
+                    accW0[t][i] = fma(dz[t][i], xk[0], accW0[t][i]);
+                    accB0[t][i] += dz[t][i];
+                }
+        } else {
+            __syncthreads();
+    #pragma unroll
+            for (int t = 0; t < T; ++t)
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) SD[(16 * t + q + 4 * i) * NSP + wrow] = dz[t][i];
+            __syncthreads();
+            {
+                double sb = 0.0, sw0[DP];
+    #pragma unroll
+                for (int k = 0; k < DP; ++k) sw0[k] = 0.0;
+    #pragma unroll 4
+                for (int rr = 0; rr < RPT; ++rr) {
+                    const int row = part + TPF * rr;
+                    const double g = SD[fj * NSP + row];
+                    sb += g;
+    #pragma unroll
+                    for (int k = 0; k < DP; ++k) sw0[k] = fma(g, Sx[row * DP + k], sw0[k]);
+                }
+                dbacc[0] += sb;
+    #pragma unroll
+                for (int k = 0; k < DP; ++k) dW0acc[k] += sw0[k];
             }
-            dbacc[0] += sb;
-#pragma unroll
-            for (int k = 0; k < DP; ++k) dW0acc[k] += sw0[k];
         }
         QN_STAMP(10);                                      // 10: first-layer stage (2 barriers + sums)
     }
@@ -658,23 +685,65 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
         }
     }
     if (part == 0) {
+        if (!thin_fast) {
 #pragma unroll
-        for (int k = 0; k < DP; ++k)
-            if (k < d) out[gW0 + (int64_t)fj * d + k] = dW0acc[k];
+            for (int k = 0; k < DP; ++k)
+                if (k < d) out[gW0 + (int64_t)fj * d + k] = dW0acc[k];
+        }
         if (nb) {
-            out[gb0 + fj] = dbacc[0];
+            if (!thin_fast) out[gb0 + fj] = dbacc[0];
 #pragma unroll
             for (int layer = 1; layer < NH; ++layer)
                 out[gHH + (int64_t)(layer - 1) * (H * H + H) + H * H + fj] = dbacc[layer];
         }
+        if (!thin_fast) {
 #pragma unroll
-        for (int qo = 0; qo < OMAX; ++qo)
-            if (qo < o) out[gWl + (int64_t)qo * H + fj] = dWlacc[qo];
+            for (int qo = 0; qo < OMAX; ++qo)
+                if (qo < o) out[gWl + (int64_t)qo * H + fj] = dWlacc[qo];
+        }
     }
-    if (nb && tid == 0) {
+    if (!thin_fast && nb && tid == 0) {
 #pragma unroll
         for (int qo = 0; qo < OMAX; ++qo)
             if (qo < o) out[gbl + qo] = dblacc[qo];
+    }
+    if (thin_fast) {
+        // lane-local partials: sum over the 16 row lanes of each q-group, then over the 4 waves through LDS
+        __syncthreads();                                   // stashes are free now: reuse SA as scratch
+        double* R = SA;                                    // [3][4 waves][H] + [4]
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double v0 = accWl[t][i], v1 = accW0[t][i], v2 = accB0[t][i];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    v0 += __shfl_xor(v0, m, 64);
+                    v1 += __shfl_xor(v1, m, 64);
+                    v2 += __shfl_xor(v2, m, 64);
+                }
+                if (c == 0) {
+                    const int f = 16 * t + q + 4 * i;
+                    R[(0 * 4 + wave) * H + f] = v0;
+                    R[(1 * 4 + wave) * H + f] = v1;
+                    R[(2 * 4 + wave) * H + f] = v2;
+                }
+            }
+        const double bl_w = wave_sum(accBl);
+        if (lane == 0) R[12 * H + wave] = bl_w;
+        __syncthreads();
+        if (tid < H) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+            for (int w = 0; w < 4; ++w) {
+                s0 += R[(0 * 4 + w) * H + tid];
+                s1 += R[(1 * 4 + w) * H + tid];
+                s2 += R[(2 * 4 + w) * H + tid];
+            }
+            out[gWl + tid] = s0;
+            out[gW0 + tid] = s1;
+            if (nb) out[gb0 + tid] = s2;
+        }
+        if (tid == 0 && nb) out[gbl] = R[12 * H] + R[12 * H + 1] + R[12 * H + 2] + R[12 * H + 3];
     }
 #pragma unroll
     for (int layer = 1; layer < NH; ++layer) {
