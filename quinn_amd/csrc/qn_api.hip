@@ -2,11 +2,12 @@
 // families, and the small elementwise kernels of the VI / ensemble trainers.
 #include "qn_common.h"
 #include "qn_math.h"
+#include <atomic>
 #include <cmath>
 #include <cstring>
 
 static thread_local char g_err[512] = "";
-static int g_forced_path = QN_PATH_AUTO;
+static std::atomic<int> g_forced_path{QN_PATH_AUTO};
 
 void qn_set_error(const char* fmt, ...) {
     va_list ap;
@@ -14,13 +15,13 @@ void qn_set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-int qn_forced_path() { return g_forced_path; }
+int qn_forced_path() { return g_forced_path.load(); }
 
 extern "C" const char* qn_last_error(void) { return g_err; }
 extern "C" const char* qn_version(void) { return "quinn_amd 0.1 gfx950"; }
 extern "C" int qn_set_path(int path) {
-    const int old = g_forced_path;
-    if (path == QN_PATH_AUTO || path == QN_PATH_GENERIC || path == QN_PATH_FUSED) g_forced_path = path;
+    const int old = g_forced_path.load();
+    if (path == QN_PATH_AUTO || path == QN_PATH_GENERIC || path == QN_PATH_FUSED) g_forced_path.store(path);
     return old;
 }
 
@@ -67,7 +68,7 @@ extern "C" int qn_mlp_desc_destroy(qn_desc* d) {
 extern "C" int64_t qn_mlp_num_params(const qn_desc* d) { return d ? d->p : -1; }
 
 static bool use_fused(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
-    if (g_forced_path == QN_PATH_GENERIC) return false;
+    if (g_forced_path.load() == QN_PATH_GENERIC) return false;
     return qn_fused_supported(d, B, Nb, want_grad, dtype);
 }
 
@@ -81,7 +82,7 @@ extern "C" size_t qn_workspace_bytes(const qn_desc* d, int B, int Nb, int want_g
     // sized for either family so that qn_set_path never invalidates a caller's buffer
     size_t g = qn_generic_workspace(d, B, Nb, want_grad, dtype);
     size_t f = qn_fused_supported(d, B, Nb, want_grad, dtype) ? qn_fused_workspace(d, B, Nb, want_grad, dtype) : 0;
-    if (g_forced_path == QN_PATH_AUTO && f) return f;
+    if (g_forced_path.load() == QN_PATH_AUTO && f) return f;
     return g > f ? g : f;
 }
 
@@ -113,7 +114,7 @@ static int run(const char* fn, const qn_desc* d, int dtype, const void* W, const
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int want_grad = gradW != nullptr;
-    if (g_forced_path == QN_PATH_FUSED && !qn_fused_supported(d, B, Nb, want_grad, dtype)) {
+    if (g_forced_path.load() == QN_PATH_FUSED && !qn_fused_supported(d, B, Nb, want_grad, dtype)) {
         qn_set_error("%s: fused path forced but not supported for this shape", fn);
         return QN_EUNSUPPORTED;
     }
