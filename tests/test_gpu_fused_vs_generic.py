@@ -1,0 +1,53 @@
+"""GPU: randomized cross-check of the two kernel families (fused MFMA vs layer-wise) over shapes the
+fused family supports: hidden width 16/32/64, 1-4 hidden layers, d, o in 1..4, every activation, with
+and without bias, ragged row counts, per-member row subsets.  float64; SSE 1e-12, gradient 1e-10."""
+import numpy as np
+import pytest
+import torch
+
+from quinn_amd import _lib
+from quinn_amd.ops import MLPArch, BatchedMLP
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(n=36, seed=123):
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        H = int(rs.choice([16, 32, 64]))
+        NH = int(rs.randint(1, 5))
+        if H == 64 and NH > 3:
+            continue
+        d, o = int(rs.randint(1, 5)), int(rs.randint(1, 5))
+        act = str(rs.choice(["tanh", "relu", "identity"]))
+        out.append(((d,) + (H,) * NH + (o,), act, bool(rs.rand() < 0.8), int(rs.choice([1, 7, 64, 65, 200, 513])),
+                    int(rs.randint(1, 7)), bool(rs.rand() < 0.4)))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: f"{c[0]}-{c[1]}-b{int(c[2])}-N{c[3]}-B{c[4]}-idx{int(c[5])}")
+def test_fused_equals_generic(case):
+    dims, act, bias, N, B, use_idx = case
+    rs = np.random.RandomState(sum(dims) * 1000 + N * 7 + B)           # deterministic per case
+    arch = MLPArch(dims, act, bias)
+    x, y = rs.randn(N, dims[0]), rs.randn(N, dims[-1])
+    W = rs.randn(B, arch.nparams) / np.sqrt(max(dims))
+    idx = rs.randint(0, N, size=(B, max(1, N // 2 + 3))) if use_idx else None
+    op = BatchedMLP(arch, x, y)
+    L = _lib.lib()
+    res = {}
+    for path in (_lib.PATH_GENERIC, _lib.PATH_FUSED):
+        old = L.qn_set_path(path)
+        try:
+            s, g = op.sse_grad(W, row_idx=idx)
+            s2, pr = op.sse_pred(W, row_idx=idx)
+        finally:
+            L.qn_set_path(old)
+        res[path] = (s.cpu().numpy(), g.cpu().numpy(), s2.cpu().numpy(), pr.cpu().numpy())
+    a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_FUSED]
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-12)
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-12)
+    np.testing.assert_allclose(b[2], b[0], rtol=1e-12)
+    assert np.abs(b[1] - a[1]).max() <= 1e-10 * max(np.abs(a[1]).max(), 1e-300)
+    np.testing.assert_allclose(b[3], a[3], rtol=1e-11, atol=1e-12)

@@ -77,7 +77,7 @@ CASES = [  # dims, activ, bias, N, B
 @pytest.mark.parametrize("case", CASES, ids=[str(c[0]) + c[1] for c in CASES])
 def test_random_shapes_vs_oracle(case, dtype):
     dims, activ, bias, N, B = case
-    rs = np.random.RandomState(hash(dims) % 1000)
+    rs = np.random.RandomState(sum(dims) % 1000)
     arch = MLPArch(dims, activ, bias)
     spec = mlp_ref.MLPSpec(dims, activ, bias)
     mod = mlp_ref.build_module(spec)
