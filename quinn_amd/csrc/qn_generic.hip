@@ -327,18 +327,30 @@ __global__ __launch_bounds__(BLK) void k_gemm64_f64(GemmArgs g, const double* __
         if (more) gload(k0 + GKB);                       // global loads in flight under the MFMAs
         const double* pa = &Ps[buf][(16 * 2 * wm + c) * GSP + q];
         const double* pb = &Qs[buf][q * GSQ + 16 * 2 * wn + c];
+        // fragments of k-step kk+1 are requested before the MFMAs of k-step kk are issued
+        double af[2], bf[2], an[2], bn[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) an[mi] = pa[mi * 16 * GSP];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bn[ni] = pb[16 * ni];
 #pragma unroll
         for (int kk = 0; kk < GKB / 4; ++kk) {
-            double af[2], bf[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) af[mi] = pa[mi * 16 * GSP + 4 * kk];
+            for (int mi = 0; mi < 2; ++mi) af[mi] = an[mi];
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bf[ni] = pb[4 * kk * GSQ + 16 * ni];
+            for (int ni = 0; ni < 2; ++ni) bf[ni] = bn[ni];
+            if (kk + 1 < GKB / 4) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) an[mi] = pa[mi * 16 * GSP + 4 * (kk + 1)];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) bn[ni] = pb[4 * (kk + 1) * GSQ + 16 * ni];
+            }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) lstore(buf ^ 1);
         __syncthreads();
