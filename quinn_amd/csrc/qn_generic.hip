@@ -218,7 +218,19 @@ __global__ __launch_bounds__(BLK) void k_dW(LayerArgs a, const T* __restrict__ d
 // of 16 through double-buffered LDS tiles Ps[64][16+2], Qs[16][64+16] (strides 18 / 80 doubles make
 // the A-fragment (16 rows x 2 k) and B-fragment (2 k x 16 cols) ds_read_b64 conflict-free); the next
 // K-step's global loads are issued before the MFMAs of the current one.
-typedef double gv4d __attribute__((ext_vector_type(4)));
+template <typename T> struct mfma16;
+template <> struct mfma16<double> {
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    // C/D: reg r of a 16x16 tile = row (lane>>4) + 4 r
+    static __device__ __forceinline__ int row(int q, int r) { return q + 4 * r; }
+    static __device__ __forceinline__ v4 run(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+};
+template <> struct mfma16<float> {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    // v_mfma_f32_16x16x4_f32: reg r = row 4 (lane>>4) + r
+    static __device__ __forceinline__ int row(int q, int r) { return 4 * q + r; }
+    static __device__ __forceinline__ v4 run(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+};
 enum { GEMM_FWD = 0, GEMM_DA = 1, GEMM_DW = 2 };
 constexpr int GKB = 16, GSP = GKB + 2, GSQ = 80;   // K-step 32 halves the residency (76 KB LDS) and measured 18 % slower
 
@@ -227,12 +239,12 @@ struct GemmArgs {
     int h_in, h_out, Nb, act, has_bias, ksplit, kchunk;
 };
 
-template <int MODE>
-__global__ __launch_bounds__(BLK) void k_gemm64_f64(GemmArgs g, const double* __restrict__ W,
-                                                    const double* __restrict__ in0, const double* __restrict__ in1,
-                                                    double* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) double Ps[2][64 * GSP];
-    __shared__ __attribute__((aligned(16))) double Qs[2][GKB * GSQ];
+template <typename T, int MODE>
+__global__ __launch_bounds__(BLK) void k_gemm64(GemmArgs g, const T* __restrict__ W, const T* __restrict__ in0,
+                                                const T* __restrict__ in1, T* __restrict__ out) {
+    typedef typename mfma16<T>::v4 gv4;
+    __shared__ __attribute__((aligned(16))) T Ps[2][64 * GSP];
+    __shared__ __attribute__((aligned(16))) T Qs[2][GKB * GSQ];
     const int b = blockIdx.z, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, c = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
@@ -250,23 +262,23 @@ __global__ __launch_bounds__(BLK) void k_gemm64_f64(GemmArgs g, const double* __
         kbeg = 0;
         kend = MODE == GEMM_FWD ? g.h_in : g.h_out;
     }
-    const double* Wl = W + (int64_t)b * g.p + g.offW;
-    const double* I0 = in0 + (int64_t)b * (MODE == GEMM_FWD ? g.h_in : g.h_out) * Nb;
-    const double* I1 = in1 ? in1 + (int64_t)b * g.h_in * Nb : nullptr;
+    const T* Wl = W + (int64_t)b * g.p + g.offW;
+    const T* I0 = in0 + (int64_t)b * (MODE == GEMM_FWD ? g.h_in : g.h_out) * Nb;
+    const T* I1 = in1 ? in1 + (int64_t)b * g.h_in * Nb : nullptr;
 
     // Each thread moves 8 + 8 doubles per K-step.  FWD / DA read out-of-range data columns (n >= Nb)
     // from a clamped, valid address instead of masking: those output columns are never stored.
     constexpr int NE = GKB / 4;                 // doubles per thread and operand per K-step
-    double pr[NE], qr[NE];
+    T pr[NE], qr[NE];
     const int ncl = Nb - 1;
     auto gload = [&](int k0) {
         if (MODE == GEMM_FWD) {          // P[m][k] = W[j0+m][k0+k];  Q[k][n] = in[k0+k][n0+n]
             const int m = tid >> 2, kq = (tid & 3) * NE;
-            const double* src = Wl + (int64_t)(m0 + m) * g.h_in + k0 + kq;
+            const T* src = Wl + (int64_t)(m0 + m) * g.h_in + k0 + kq;
 #pragma unroll
             for (int u = 0; u < NE; ++u) pr[u] = src[u];
             const int k = tid / (64 / NE), nq = (tid % (64 / NE)) * NE;
-            const double* qs = I0 + (int64_t)(k0 + k) * Nb;
+            const T* qs = I0 + (int64_t)(k0 + k) * Nb;
 #pragma unroll
             for (int u = 0; u < NE; ++u) { const int n = n0 + nq + u; qr[u] = qs[n < Nb ? n : ncl]; }
         } else if (MODE == GEMM_DA) {    // P[m][k] = W[k0+k][i0+m];  Q[k][n] = dz[k0+k][n0+n]
@@ -274,16 +286,16 @@ __global__ __launch_bounds__(BLK) void k_gemm64_f64(GemmArgs g, const double* __
 #pragma unroll
             for (int u = 0; u < NE; ++u) pr[u] = Wl[(int64_t)(k0 + kq + u) * g.h_in + m0 + m];
             const int k = tid / (64 / NE), nq = (tid % (64 / NE)) * NE;
-            const double* qs = I0 + (int64_t)(k0 + k) * Nb;
+            const T* qs = I0 + (int64_t)(k0 + k) * Nb;
 #pragma unroll
             for (int u = 0; u < NE; ++u) { const int n = n0 + nq + u; qr[u] = qs[n < Nb ? n : ncl]; }
         } else {                         // P[m][k] = dz[j0+m][k0+k];  Q[k][n] = a[i0+n][k0+k]   (k = data row)
             const int m = tid >> 2, kq = (tid & 3) * NE;
 #pragma unroll
-            for (int u = 0; u < NE; ++u) pr[u] = k0 + kq + u < kend ? I0[(int64_t)(m0 + m) * Nb + k0 + kq + u] : 0.0;
+            for (int u = 0; u < NE; ++u) pr[u] = k0 + kq + u < kend ? I0[(int64_t)(m0 + m) * Nb + k0 + kq + u] : T(0);
             const int nn = tid & 63, kq2 = (tid >> 6) * NE;
 #pragma unroll
-            for (int u = 0; u < NE; ++u) qr[u] = k0 + kq2 + u < kend ? I1[(int64_t)(n0 + nn) * Nb + k0 + kq2 + u] : 0.0;
+            for (int u = 0; u < NE; ++u) qr[u] = k0 + kq2 + u < kend ? I1[(int64_t)(n0 + nn) * Nb + k0 + kq2 + u] : T(0);
         }
     };
     auto lstore = [&](int buf) {
@@ -311,11 +323,11 @@ __global__ __launch_bounds__(BLK) void k_gemm64_f64(GemmArgs g, const double* __
         }
     };
 
-    gv4d acc[2][2];
+    gv4 acc[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (gv4d){0.0, 0.0, 0.0, 0.0};
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (gv4){T(0), T(0), T(0), T(0)};
     if (kbeg < kend) {
         gload(kbeg);
         lstore(0);
@@ -325,10 +337,10 @@ __global__ __launch_bounds__(BLK) void k_gemm64_f64(GemmArgs g, const double* __
     for (int k0 = kbeg; k0 < kend; k0 += GKB) {
         const bool more = k0 + GKB < kend;
         if (more) gload(k0 + GKB);                       // global loads in flight under the MFMAs
-        const double* pa = &Ps[buf][(16 * 2 * wm + c) * GSP + q];
-        const double* pb = &Qs[buf][q * GSQ + 16 * 2 * wn + c];
+        const T* pa = &Ps[buf][(16 * 2 * wm + c) * GSP + q];
+        const T* pb = &Qs[buf][q * GSQ + 16 * 2 * wn + c];
         // fragments of k-step kk+1 are requested before the MFMAs of k-step kk are issued
-        double af[2], bf[2], an[2], bn[2];
+        T af[2], bf[2], an[2], bn[2];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) an[mi] = pa[mi * 16 * GSP];
 #pragma unroll
@@ -349,23 +361,23 @@ __global__ __launch_bounds__(BLK) void k_gemm64_f64(GemmArgs g, const double* __
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = mfma16<T>::run(af[mi], bf[ni], acc[mi][ni]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (more) lstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
-    // ---- epilogue; C layout: reg r of tile (mi, ni) = row 16*(2wm+mi) + q + 4r, col 16*(2wn+ni) + c
+    // ---- epilogue; C layout: reg r of tile (mi, ni) = row 16*(2wm+mi) + mfma16<T>::row(q, r), col 16*(2wn+ni) + c
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 16 * (2 * wm + mi) + q + 4 * r;
+                const int m = m0 + 16 * (2 * wm + mi) + mfma16<T>::row(q, r);
                 const int n = n0 + 16 * (2 * wn + ni) + c;
-                double v = acc[mi][ni][r];
+                T v = acc[mi][ni][r];
                 if (MODE == GEMM_FWD) {
                     if (n < Nb) {
                         if (g.has_bias) v += W[(int64_t)b * g.p + g.offB + m];
@@ -383,31 +395,33 @@ __global__ __launch_bounds__(BLK) void k_gemm64_f64(GemmArgs g, const double* __
 }
 
 // db[b][j] = sum_n dz[b][j][n]   (one block per (j, b); fixed-order reduction)
-__global__ __launch_bounds__(BLK) void k_rowsum(const double* __restrict__ dz, int h, int Nb, int64_t p, int64_t offB,
-                                                double* __restrict__ gradW) {
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_rowsum(const T* __restrict__ dz, int h, int Nb, int64_t p, int64_t offB,
+                                                T* __restrict__ gradW) {
     __shared__ double red[BLK / 64];
     const int j = blockIdx.x, b = blockIdx.y;
-    const double* row = dz + ((int64_t)b * h + j) * Nb;
+    const T* row = dz + ((int64_t)b * h + j) * Nb;
     double s = 0.0;
-    for (int n = threadIdx.x; n < Nb; n += BLK) s += row[n];
+    for (int n = threadIdx.x; n < Nb; n += BLK) s += (double)row[n];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < BLK / 64; ++w) t += red[w];
-        gradW[(int64_t)b * p + offB + j] = t;
+        gradW[(int64_t)b * p + offB + j] = (T)t;
     }
 }
 
 // gradW[b][off + e] = sum_k slab[b][k][e]
-__global__ __launch_bounds__(BLK) void k_slab_reduce(const double* __restrict__ slab, int ksplit, int64_t n, int64_t p,
-                                                     int64_t off, double* __restrict__ gradW) {
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_slab_reduce(const T* __restrict__ slab, int ksplit, int64_t n, int64_t p,
+                                                     int64_t off, T* __restrict__ gradW) {
     const int b = blockIdx.y;
     for (int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x; e < n; e += (int64_t)gridDim.x * BLK) {
         double s = 0.0;
-        for (int k = 0; k < ksplit; ++k) s += slab[((int64_t)b * ksplit + k) * n + e];
-        gradW[(int64_t)b * p + off + e] = s;
+        for (int k = 0; k < ksplit; ++k) s += (double)slab[((int64_t)b * ksplit + k) * n + e];
+        gradW[(int64_t)b * p + off + e] = (T)s;
     }
 }
 
@@ -449,9 +463,8 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
     const int nblk = (Nb + BLK - 1) / BLK;
     double* partial = c.take<double>((size_t)B * nblk);
     // split-K slabs of the MFMA dW GEMM (float64 hidden->hidden layers with widths % 64 == 0)
-    constexpr bool kF64 = sizeof(T) == 8;
-    double* dwslab = nullptr;
-    if (kF64 && grad) {
+    T* dwslab = nullptr;
+    if (grad) {
         size_t need = 0;
         for (int l = 1; l + 1 < L; ++l)
             if (gemm_layer(d, l)) {
@@ -459,7 +472,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                 const int ks = dw_ksplit(B, tiles, Nb);
                 if (ks > 1) need = std::max(need, (size_t)B * ks * d->dims[l] * d->dims[l + 1]);
             }
-        if (need) dwslab = c.take<double>(need);
+        if (need) dwslab = c.take<T>(need);
     }
     if (c.off > ws_bytes) {
         qn_set_error("workspace too small: need %zu bytes, got %zu", c.off, ws_bytes);
@@ -481,11 +494,11 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         return g;
     };
     for (int l = 0; l + 1 < L; ++l) {
-        if (kF64 && gemm_layer(d, l)) {
+        if (gemm_layer(d, l)) {
             GemmArgs g = gargs(l);
             dim3 grid((Nb + 63) / 64, g.h_out / 64, B);
-            hipLaunchKernelGGL((k_gemm64_f64<GEMM_FWD>), grid, dim3(BLK), 0, st, g, (const double*)W,
-                               (const double*)act[l - 1], (const double*)nullptr, (double*)act[l]);
+            hipLaunchKernelGGL((k_gemm64<T, GEMM_FWD>), grid, dim3(BLK), 0, st, g, W, (const T*)act[l - 1],
+                               (const T*)nullptr, act[l]);
             continue;
         }
         LayerArgs a = largs(l);
@@ -505,31 +518,31 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         const T* dz = dz_last;
         for (int l = L - 1; l >= 0; --l) {
             LayerArgs a = largs(l);
-            if (kF64 && gemm_layer(d, l)) {
+            if (gemm_layer(d, l)) {
                 GemmArgs g = gargs(l);
                 const int tiles = (g.h_in / 64) * (g.h_out / 64);
                 const int ks = dw_ksplit(B, tiles, Nb);
                 const int64_t nW = (int64_t)g.h_in * g.h_out;
                 g.ksplit = ks;
                 g.kchunk = ((Nb + ks - 1) / ks + GKB - 1) / GKB * GKB;
-                double* dst = (double*)gradW + d->offW[l];
+                T* dst = gradW + d->offW[l];
                 g.out_stride_b = d->p; g.out_stride_k = 0;
                 if (ks > 1) { dst = dwslab; g.out_stride_b = (int64_t)ks * nW; g.out_stride_k = nW; }
-                hipLaunchKernelGGL((k_gemm64_f64<GEMM_DW>), dim3(ks, tiles, B), dim3(BLK), 0, st, g, (const double*)W,
-                                   (const double*)dz, (const double*)act[l - 1], dst);
+                hipLaunchKernelGGL((k_gemm64<T, GEMM_DW>), dim3(ks, tiles, B), dim3(BLK), 0, st, g, W, dz,
+                                   (const T*)act[l - 1], dst);
                 if (ks > 1) {
                     int gx = (int)((nW + BLK - 1) / BLK);
                     if (gx > 64) gx = 64;
-                    hipLaunchKernelGGL(k_slab_reduce, dim3(gx, B), dim3(BLK), 0, st, dwslab, ks, nW, d->p, d->offW[l],
-                                       (double*)gradW);
+                    hipLaunchKernelGGL(k_slab_reduce<T>, dim3(gx, B), dim3(BLK), 0, st, (const T*)dwslab, ks, nW, d->p,
+                                       d->offW[l], gradW);
                 }
                 if (d->has_bias)
-                    hipLaunchKernelGGL(k_rowsum, dim3(g.h_out, B), dim3(BLK), 0, st, (const double*)dz, g.h_out, Nb,
-                                       d->p, d->offB[l], (double*)gradW);
+                    hipLaunchKernelGGL(k_rowsum<T>, dim3(g.h_out, B), dim3(BLK), 0, st, dz, g.h_out, Nb, d->p,
+                                       d->offB[l], gradW);
                 T* dzp = dzbuf[l & 1];
                 g.ksplit = 1; g.kchunk = Nb;
-                hipLaunchKernelGGL((k_gemm64_f64<GEMM_DA>), dim3((Nb + 63) / 64, g.h_in / 64, B), dim3(BLK), 0, st, g,
-                                   (const double*)W, (const double*)dz, (const double*)act[l - 1], (double*)dzp);
+                hipLaunchKernelGGL((k_gemm64<T, GEMM_DA>), dim3((Nb + 63) / 64, g.h_in / 64, B), dim3(BLK), 0, st, g, W,
+                                   dz, (const T*)act[l - 1], dzp);
                 dz = dzp;
                 continue;
             }
@@ -560,7 +573,7 @@ size_t qn_generic_workspace(const qn_desc* d, int B, int Nb, int want_grad, int 
         if (L > 1) tot += 2 * qn_align((size_t)B * d->hmax * Nb * e);
     }
     tot += qn_align((size_t)B * ((Nb + BLK - 1) / BLK) * sizeof(double));
-    if (want_grad && dtype == QN_F64) {
+    if (want_grad) {
         size_t need = 0;
         for (int l = 1; l + 1 < L; ++l)
             if (gemm_layer(d, l)) {
@@ -568,7 +581,7 @@ size_t qn_generic_workspace(const qn_desc* d, int B, int Nb, int want_grad, int 
                 const int ks = dw_ksplit(B, tiles, Nb);
                 if (ks > 1) need = std::max(need, (size_t)B * ks * d->dims[l] * d->dims[l + 1]);
             }
-        tot += qn_align(need * sizeof(double));
+        tot += qn_align(need * e);
     }
     return tot + 256;
 }

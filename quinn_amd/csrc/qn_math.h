@@ -55,4 +55,11 @@ __device__ __forceinline__ double qn_tanh_f64(double x) {
     return __hiloint2double(qh, __double2loint(q));
 }
 
-__device__ __forceinline__ float qn_tanh_f32(float x) { return tanhf(x); }
+// tanh for float32: 1 - 2 / (exp(2|x|) + 1) on the hardware exp2 / rcp (7 instructions, absolute error
+// ~2e-7, i.e. float32-level; NaN propagates through v_exp_f32).
+__device__ __forceinline__ float qn_tanh_f32(float x) {
+    const float ax = fminf(fabsf(x), 10.0f);
+    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);
+    const float t = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+    return x != x ? x : __builtin_copysignf(t, x);
+}

@@ -19,11 +19,12 @@ def timeit(fn, n):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n
 out = {}
+DT = "float32" if len(sys.argv) > 1 and sys.argv[1] == "f32" else "float64"
 for name, (dims, N, B) in CFG.items():
     arch = MLPArch(dims, "tanh")
     rs = np.random.RandomState(0)
     x = rs.rand(N, dims[0]) * 6 - 3; y = np.sin(x).sum(axis=1, keepdims=True)
-    op = BatchedMLP(arch, x, y)
+    op = BatchedMLP(arch, x, y, dtype=DT)
     W = op.weights(0.1 * rs.randn(B, arch.nparams))
     tf = timeit(lambda: op.sse(W), 5)
     tg = timeit(lambda: op.sse_grad(W), 3)
