@@ -9,7 +9,6 @@ import copy
 import math
 
 import numpy as np
-import torch
 
 from ..nns.nnfit import nnfit
 from ..nns.tchutils import print_nnparams
@@ -20,10 +19,25 @@ class Learner():
         self.nnmodel = copy.deepcopy(nnmodel)
         self.trained = False
         self.verbose = verbose
-        self.best_model = None
+        self._best_model = None
+        self._best_w = None          # set by the batched ensemble trainer; the module is built on first use
         self.history = None
         if self.verbose:
             self.print_params(names_only=True)
+
+    @property
+    def best_model(self):
+        """The best trained module (a copy of `nnmodel` carrying the best weights)."""
+        if self._best_model is None and self._best_w is not None:
+            from ..nns.nnfit import load_flat_into
+            self._best_model = copy.deepcopy(self.nnmodel)
+            load_flat_into(self._best_model, self._best_w)
+        return self._best_model
+
+    @best_model.setter
+    def best_model(self, module):
+        self._best_model = module
+        self._pred_op = None
 
     def print_params(self, names_only=False):
         print_nnparams(self.best_model if self.trained else self.nnmodel, names_only=names_only)
@@ -49,9 +63,11 @@ class Learner():
         self.trained = True
 
     def predict(self, x):
-        """numpy `(N,d)` -> numpy `(N,o)` with the best model (host evaluation of ONE member;
-        `NN_Ens.predict_ens` batches all members on the device)."""
+        """numpy `(N,d)` -> numpy `(N,o)` with the best model, evaluated by the device operator
+        (`NN_Ens.predict_ens` batches all members into one launch)."""
         assert self.trained
-        with torch.no_grad():
-            xt = torch.as_tensor(np.asarray(x), dtype=torch.float64)
-            return self.best_model.to('cpu')(xt).numpy()
+        from ..ops import MLPArch, BatchedMLP, flatten_module
+        x = np.asarray(x, dtype=np.float64)
+        if getattr(self, "_pred_op", None) is None:
+            self._pred_op = BatchedMLP(MLPArch.from_module(self.best_model), x, None)
+        return self._pred_op.predict(flatten_module(self.best_model)[None, :], x)[0].double().cpu().numpy()

@@ -33,11 +33,13 @@ class MLPBase(torch.nn.Module):
         return sum(p.numel() for p in self.parameters())
 
     def predict(self, x):
-        """numpy `(N,d)` -> numpy `(N,o)` with the best trained weights if any."""
+        """numpy `(N,d)` -> numpy `(N,o)` with the best trained weights if any (nnbase.py:61-85), evaluated
+        by the device operator."""
+        from ..ops import MLPArch, BatchedMLP, flatten_module
         model = self.best_model if self.trained else self
-        with torch.no_grad():
-            xt = torch.as_tensor(np.asarray(x), dtype=torch.float64)
-            return model.forward(xt).cpu().numpy() if model is self else model(xt).cpu().numpy()
+        x = np.asarray(x, dtype=np.float64)
+        op = BatchedMLP(MLPArch.from_module(model), x, None)
+        return op.predict(flatten_module(model)[None, :], x)[0].double().cpu().numpy()
 
 
 class MLP(MLPBase):

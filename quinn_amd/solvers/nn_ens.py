@@ -64,8 +64,7 @@ class NN_Ens(QUiNNBase):
         self._best_w = res['best_w']
         for j, learner in enumerate(self.learners):
             load_flat_into(learner.nnmodel, res['final_w'][j])
-            learner.best_model = copy.deepcopy(learner.nnmodel)
-            load_flat_into(learner.best_model, res['best_w'][j])
+            learner._best_model, learner._best_w, learner._pred_op = None, res['best_w'][j], None
             learner.history = [list(r) for r in res['history'][j]]
             if hasattr(learner.nnmodel, 'history'):
                 learner.nnmodel.history = learner.history

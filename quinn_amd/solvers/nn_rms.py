@@ -55,7 +55,6 @@ class NN_RMS(NN_Ens):
         self.fit_results, self._best_w, self.anchors = res, res['best_w'], anchors
         for j, learner in enumerate(self.learners):
             load_flat_into(learner.nnmodel, res['final_w'][j])
-            learner.best_model = copy.deepcopy(learner.nnmodel)
-            load_flat_into(learner.best_model, res['best_w'][j])
+            learner._best_model, learner._best_w, learner._pred_op = None, res['best_w'][j], None
             learner.history = [list(r) for r in res['history'][j]]
             learner.trained = True
