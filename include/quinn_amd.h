@@ -40,6 +40,18 @@ typedef struct qn_desc qn_desc;
  * one activation between consecutive Linear layers, none after the last
  * (quinn/nns/mlp.py:46-84: 'tanh' | 'relu' | identity). */
 int qn_mlp_desc_create(const int* dims, int ndims, int act, int has_bias, qn_desc** out);
+/* Descriptor of a quinn residual network (quinn/nns/rnet.py:16-165):
+ *   out = act(Wpre x + bpre)                       if layer_pre, else out = x (indim == rdim)
+ *   for i in 0..nsteps-1:  W_i = sum_k coef[i*npar+k] * ww_k,  b_i likewise from bb_k (if has_bias)
+ *       out = mlp ? act(W_i out + b_i) : out + (1/nsteps) * act(W_i out + b_i)
+ *   pred = Wpost out + bpost                       if layer_post, else pred = out (outdim == rdim)
+ * nsteps = nlayers + 1 of the reference; coef[i][k] is the weight-parameterisation function
+ * (rnet.py:217-380) evaluated at t = i / nsteps: t^k for Const/Lin/Quad/Cubic/Poly, a one-hot at
+ * int(t * npar) for NonPar.  act = tanh (nonlin=True) or identity.  Flat layout = the module's
+ * parameters() order: weight_pre, bias_pre, weight_post, bias_post, ww_0.., bb_0.. (rnet.py:90-120).
+ * The descriptor is used with the same qn_mlp_* entry points as an MLP's. */
+int qn_rnet_desc_create(int indim, int rdim, int outdim, int nsteps, int npar, const double* coef, int act,
+                        int has_bias, int layer_pre, int layer_post, int mlp, qn_desc** out);
 int qn_mlp_desc_destroy(qn_desc* desc);
 /* p = number of entries of one flat weight vector. */
 int64_t qn_mlp_num_params(const qn_desc* desc);

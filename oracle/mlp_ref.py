@@ -48,8 +48,11 @@ def _activation(name):
     return torch.nn.Identity()
 
 
-def build_module(spec: MLPSpec) -> torch.nn.Sequential:
-    """Sequential(Linear, act, Linear, ..., act, Linear) in float64 (mlp.py:55-84)."""
+def build_module(spec) -> torch.nn.Module:
+    """Sequential(Linear, act, Linear, ..., act, Linear) in float64 (mlp.py:55-84); a residual
+    network for an rnet_ref.RNetSpec."""
+    if hasattr(spec, "build_module"):
+        return spec.build_module()
     layers = []
     nl = len(spec.dims) - 1
     for i in range(nl):

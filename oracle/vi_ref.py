@@ -23,7 +23,9 @@ from .mlp_ref import F64, MLPSpec, build_module
 
 
 def param_shapes(spec: MLPSpec):
-    """Shapes in named_parameters() order: W_0, b_0, W_1, b_1, ..."""
+    """Shapes in named_parameters() order: W_0, b_0, W_1, b_1, ... (an RNetSpec lists its own)."""
+    if hasattr(spec, "param_shapes"):
+        return spec.param_shapes()
     shapes = []
     for a, b in zip(spec.dims[:-1], spec.dims[1:]):
         shapes.append((b, a))
@@ -59,6 +61,8 @@ def draw_eps(spec, nsam, gen):
 
 
 def _functional_forward(spec, tensors, x):
+    if hasattr(spec, "functional_forward"):
+        return spec.functional_forward(tensors, x)
     h = x
     nl = len(spec.dims) - 1
     k = 0

@@ -18,7 +18,7 @@ ACT_CODES = {"identity": 0, "tanh": 1, "relu": 2}
 PATH_AUTO, PATH_GENERIC, PATH_FUSED = 0, 1, 2
 
 # every symbol include/quinn_amd.h declares (tests check the .so exports all of them)
-SYMBOLS = ["qn_mlp_desc_create", "qn_mlp_desc_destroy", "qn_mlp_num_params", "qn_workspace_bytes",
+SYMBOLS = ["qn_mlp_desc_create", "qn_rnet_desc_create", "qn_mlp_desc_destroy", "qn_mlp_num_params", "qn_workspace_bytes",
            "qn_mlp_path", "qn_set_path", "qn_mlp_sse_fwd", "qn_mlp_sse_fwdbwd", "qn_vi_sample_kl",
            "qn_vi_grad", "qn_adam_batched", "qn_mcmc_propose", "qn_mcmc_accept", "qn_debug_tanh", "qn_last_error",
            "qn_version"]
@@ -67,6 +67,9 @@ def lib():
     vp, i32, i64, f64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_size_t
     L.qn_mlp_desc_create.argtypes = [ctypes.POINTER(i32), i32, i32, i32, ctypes.POINTER(vp)]
     L.qn_mlp_desc_create.restype = i32
+    L.qn_rnet_desc_create.argtypes = [i32, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_double), i32, i32, i32, i32,
+                                      i32, ctypes.POINTER(vp)]
+    L.qn_rnet_desc_create.restype = i32
     L.qn_mlp_desc_destroy.argtypes = [vp]
     L.qn_mlp_desc_destroy.restype = i32
     L.qn_mlp_num_params.argtypes = [vp]

@@ -56,6 +56,46 @@ extern "C" int qn_mlp_desc_create(const int* dims, int ndims, int act, int has_b
         if (d->has_bias) off += d->dims[l + 1];
     }
     d->p = off;
+    d->kind = QN_KIND_MLP;
+    *out = d;
+    return QN_OK;
+}
+
+extern "C" int qn_rnet_desc_create(int indim, int rdim, int outdim, int nsteps, int npar, const double* coef,
+                                   int act, int has_bias, int layer_pre, int layer_post, int mlp, qn_desc** out) {
+    if (!coef || !out || indim <= 0 || rdim <= 0 || outdim <= 0 || nsteps <= 0 || npar <= 0 ||
+        nsteps > QN_MAX_LAYERS || npar > QN_MAX_LAYERS) {
+        qn_set_error("qn_rnet_desc_create: need positive sizes, nsteps <= %d, npar <= %d", QN_MAX_LAYERS,
+                     QN_MAX_LAYERS);
+        return QN_EINVAL;
+    }
+    if (act != QN_ACT_IDENTITY && act != QN_ACT_TANH) {
+        qn_set_error("qn_rnet_desc_create: activation %d (tanh or identity, rnet.py:123-126)", act);
+        return QN_EINVAL;
+    }
+    if ((indim != rdim && !layer_pre) || (outdim != rdim && !layer_post)) {   // rnet.py:85-88
+        qn_set_error("qn_rnet_desc_create: indim/outdim != rdim needs layer_pre/layer_post");
+        return QN_EINVAL;
+    }
+    qn_desc* d = new qn_desc();
+    d->kind = QN_KIND_RNET;
+    d->nlayers = 2;
+    d->dims[0] = indim; d->dims[1] = rdim; d->dims[2] = outdim;
+    d->hmax = rdim > outdim ? rdim : outdim;
+    d->act = act;
+    d->has_bias = has_bias ? 1 : 0;
+    d->rn_r = rdim; d->rn_steps = nsteps; d->rn_npar = npar;
+    d->rn_pre = layer_pre ? 1 : 0; d->rn_post = layer_post ? 1 : 0; d->rn_mlp = mlp ? 1 : 0;
+    for (int i = 0; i < nsteps * npar; ++i) d->rn_coef[i] = coef[i];
+    // parameters() order of the module: weight_pre, bias_pre, weight_post, bias_post, ww_*, bb_*  (rnet.py:90-120)
+    int64_t off = 0;
+    d->rn_offWpre = off; if (layer_pre) off += (int64_t)rdim * indim;
+    d->rn_offBpre = off; if (layer_pre) off += rdim;
+    d->rn_offWpost = off; if (layer_post) off += (int64_t)outdim * rdim;
+    d->rn_offBpost = off; if (layer_post) off += outdim;
+    d->rn_offWW = off; off += (int64_t)npar * rdim * rdim;
+    d->rn_offBB = off; if (has_bias) off += (int64_t)npar * rdim;
+    d->p = off;
     *out = d;
     return QN_OK;
 }
@@ -68,7 +108,7 @@ extern "C" int qn_mlp_desc_destroy(qn_desc* d) {
 extern "C" int64_t qn_mlp_num_params(const qn_desc* d) { return d ? d->p : -1; }
 
 static bool use_fused(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
-    if (g_forced_path.load() == QN_PATH_GENERIC) return false;
+    if (d->kind != QN_KIND_MLP || g_forced_path.load() == QN_PATH_GENERIC) return false;
     return qn_fused_supported(d, B, Nb, want_grad, dtype);
 }
 
@@ -79,6 +119,7 @@ extern "C" int qn_mlp_path(const qn_desc* d, int B, int Nb, int want_grad, int d
 
 extern "C" size_t qn_workspace_bytes(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
     if (!d || B <= 0 || Nb <= 0) return 0;
+    if (d->kind == QN_KIND_RNET) return qn_rnet_workspace(d, B, Nb, want_grad, dtype);
     // sized for either family so that qn_set_path never invalidates a caller's buffer
     size_t g = qn_generic_workspace(d, B, Nb, want_grad, dtype);
     size_t f = qn_fused_supported(d, B, Nb, want_grad, dtype) ? qn_fused_workspace(d, B, Nb, want_grad, dtype) : 0;
@@ -114,6 +155,8 @@ static int run(const char* fn, const qn_desc* d, int dtype, const void* W, const
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int want_grad = gradW != nullptr;
+    if (d->kind == QN_KIND_RNET)
+        return qn_rnet_run(d, dtype, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
     if (g_forced_path.load() == QN_PATH_FUSED && !qn_fused_supported(d, B, Nb, want_grad, dtype)) {
         qn_set_error("%s: fused path forced but not supported for this shape", fn);
         return QN_EUNSUPPORTED;

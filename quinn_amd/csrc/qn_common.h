@@ -18,7 +18,13 @@ struct qn_desc {
     int64_t offW[QN_MAX_LAYERS];    // offset of W_l in the flat vector
     int64_t offB[QN_MAX_LAYERS];    // offset of b_l (valid if has_bias)
     int hmax;                       // widest hidden/output layer
+    // ---- residual network (quinn/nns/rnet.py:16-170); kind == QN_KIND_RNET.  dims[] = {d, r, o}.
+    int kind;
+    int rn_r, rn_steps, rn_npar, rn_pre, rn_post, rn_mlp;
+    int64_t rn_offWpre, rn_offBpre, rn_offWpost, rn_offBpost, rn_offWW, rn_offBB;
+    double rn_coef[QN_MAX_LAYERS * QN_MAX_LAYERS];   // [steps][npar]: W_i = sum_k coef[i][k] * ww_k
 };
+enum { QN_KIND_MLP = 0, QN_KIND_RNET = 1 };
 
 void qn_set_error(const char* fmt, ...);
 int qn_forced_path();
@@ -40,6 +46,12 @@ size_t qn_generic_workspace(const qn_desc* d, int B, int Nb, int want_grad, int 
 int qn_generic_run(const qn_desc* d, int dtype, const void* W, const void* X, const void* Y,
                    const int32_t* row_idx, int B, int N, int Nb, double* sse, void* pred,
                    void* gradW, void* ws, size_t ws_bytes, hipStream_t st);
+
+// ---- residual network, layer-wise: qn_generic.hip
+size_t qn_rnet_workspace(const qn_desc* d, int B, int Nb, int want_grad, int dtype);
+int qn_rnet_run(const qn_desc* d, int dtype, const void* W, const void* X, const void* Y,
+                const int32_t* row_idx, int B, int N, int Nb, double* sse, void* pred,
+                void* gradW, void* ws, size_t ws_bytes, hipStream_t st);
 
 // ---- fused MFMA path with LDS-resident weights: qn_fused.hip
 bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtype);

@@ -561,6 +561,194 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
     return QN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Residual network (quinn/nns/rnet.py:130-165), layer-wise.  Every weight parameterisation of the
+// reference (Const / Lin / Quad / Cubic / Poly / NonPar, rnet.py:217-380) is linear in its
+// parameters, W_i = sum_k coef[i][k] * ww_k, so the per-step weights are expanded once per call
+// into Weff[b][i][r*r + r]; the layer kernels above then run on Weff (stride / offsets through
+// LayerArgs), and the step gradients are contracted back with the same coefficients.
+//   OUT_0 = act(Wpre x + bpre) | x ;  TH_i = act(Weff_i OUT_i + beff_i) ;
+//   OUT_{i+1} = mlp ? TH_i : OUT_i + h * TH_i ;  pred = Wpost OUT_S + bpost | OUT_S.
+struct RnCoef { double c[QN_MAX_LAYERS * QN_MAX_LAYERS]; };
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_rn_expand(RnCoef cf, const T* __restrict__ W, int64_t p, int64_t offWW,
+                                                   int64_t offBB, int r, int steps, int npar, int has_bias,
+                                                   T* __restrict__ Weff) {
+    const int b = blockIdx.y;
+    const int rr = r * r, per = rr + r, tot = steps * per;
+    const T* Wb = W + (int64_t)b * p;
+    for (int e = blockIdx.x * BLK + threadIdx.x; e < tot; e += gridDim.x * BLK) {
+        const int i = e / per, q = e % per;
+        T s = T(0);
+        if (q < rr) {
+            for (int k = 0; k < npar; ++k) s = fma((T)cf.c[i * npar + k], Wb[offWW + (int64_t)k * rr + q], s);
+        } else if (has_bias) {
+            for (int k = 0; k < npar; ++k) s = fma((T)cf.c[i * npar + k], Wb[offBB + (int64_t)k * r + q - rr], s);
+        }
+        Weff[(int64_t)b * tot + e] = s;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_rn_contract(RnCoef cf, const T* __restrict__ dWeff, int r, int steps,
+                                                     int npar, int has_bias, int64_t p, int64_t offWW,
+                                                     int64_t offBB, T* __restrict__ gradW) {
+    const int b = blockIdx.y;
+    const int rr = r * r, per = rr + r, tot = npar * per;
+    for (int e = blockIdx.x * BLK + threadIdx.x; e < tot; e += gridDim.x * BLK) {
+        const int k = e / per, q = e % per;
+        if (q >= rr && !has_bias) continue;
+        double s = 0.0;
+        for (int i = 0; i < steps; ++i)
+            s = fma(cf.c[i * npar + k], (double)dWeff[((int64_t)b * steps + i) * per + q], s);
+        if (q < rr) gradW[(int64_t)b * p + offWW + (int64_t)k * rr + q] = (T)s;
+        else gradW[(int64_t)b * p + offBB + (int64_t)k * r + q - rr] = (T)s;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_rn_eye(int r, T* __restrict__ I) {
+    const int e = blockIdx.x * BLK + threadIdx.x;
+    if (e < r * r) I[e] = (e / r == e % r) ? T(1) : T(0);
+}
+// out = a + h * th
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_rn_axpy(const T* __restrict__ a, const T* __restrict__ th, T h, int64_t n,
+                                                 T* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (e < n) out[e] = a[e] + h * th[e];
+}
+// dz = s * g * act'(th)
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_rn_dz(const T* __restrict__ g, const T* __restrict__ th, T s, int act,
+                                               int64_t n, T* __restrict__ dz) {
+    const int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (e < n) dz[e] = s * g[e] * act_deriv(th[e], act);
+}
+// t += g
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_rn_add(const T* __restrict__ g, int64_t n, T* __restrict__ t) {
+    const int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (e < n) t[e] += g[e];
+}
+
+template <typename T>
+int run_rnet(const qn_desc* d, const T* W, const T* X, const T* Y, const int32_t* row_idx, int B, int N, int Nb,
+             double* sse, T* pred, T* gradW, void* ws, size_t ws_bytes, hipStream_t st) {
+    (void)N;
+    const bool grad = gradW != nullptr;
+    const int r = d->rn_r, S = d->rn_steps, din = d->dims[0], o = d->dims[2];
+    const int per = r * r + r;
+    const int64_t nact = (int64_t)B * r * Nb;
+    (void)hipGetLastError();
+    Carve c{static_cast<char*>(ws), 0, ws_bytes};
+    std::vector<T*> OUT(S + 1), TH(S);
+    OUT[0] = c.take<T>(nact);
+    for (int i = 0; i < S; ++i) {
+        TH[i] = c.take<T>(nact);
+        OUT[i + 1] = d->rn_mlp ? TH[i] : c.take<T>(nact);
+    }
+    T* Weff = c.take<T>((size_t)B * S * per);
+    T* eye = c.take<T>((size_t)r * r);
+    const int nblk = (Nb + BLK - 1) / BLK;
+    double* partial = c.take<double>((size_t)B * nblk);
+    T *dz_last = nullptr, *dWeff = nullptr, *buf[3] = {nullptr, nullptr, nullptr};
+    if (grad) {
+        dz_last = c.take<T>((size_t)B * o * Nb);
+        for (int i = 0; i < 3; ++i) buf[i] = c.take<T>(nact);
+        dWeff = c.take<T>((size_t)B * S * per);
+    }
+    if (c.off > ws_bytes) {
+        qn_set_error("workspace too small: need %zu bytes, got %zu", c.off, ws_bytes);
+        return QN_EWORKSPACE;
+    }
+    RnCoef cf;
+    for (int i = 0; i < S * d->rn_npar; ++i) cf.c[i] = d->rn_coef[i];
+    constexpr int JB = 8, TJ = 8, TK = 8, KB = 8;
+    const int egrid = (int)((nact + BLK - 1) / BLK);
+    auto base = [&]() {
+        LayerArgs a;
+        a.p = d->p; a.offW = 0; a.offB = 0; a.has_bias = d->has_bias; a.h_in = r; a.h_out = r; a.act = d->act;
+        a.Nb = Nb; a.first = 0; a.d = din; a.o = o;
+        return a;
+    };
+    LayerArgs apre = base();     // x -> OUT_0
+    apre.first = 1; apre.h_in = din;
+    const T* Wpre = W;
+    if (d->rn_pre) { apre.offW = d->rn_offWpre; apre.offB = d->rn_offBpre; apre.has_bias = 1; }
+    else { Wpre = eye; apre.p = 0; apre.has_bias = 0; apre.act = QN_ACT_IDENTITY; }
+    LayerArgs apost = base();    // OUT_S -> pred
+    apost.h_out = o;
+    const T* Wpost = W;
+    if (d->rn_post) { apost.offW = d->rn_offWpost; apost.offB = d->rn_offBpost; apost.has_bias = 1; }
+    else { Wpost = eye; apost.p = 0; apost.has_bias = 0; }
+    auto astep = [&](int i) {    // OUT_i -> TH_i on the expanded weights
+        LayerArgs a = base();
+        a.p = (int64_t)S * per; a.offW = (int64_t)i * per; a.offB = a.offW + r * r;
+        return a;
+    };
+    if (!d->rn_pre || !d->rn_post)
+        hipLaunchKernelGGL(k_rn_eye<T>, dim3((r * r + BLK - 1) / BLK), dim3(BLK), 0, st, r, eye);
+    hipLaunchKernelGGL(k_rn_expand<T>, dim3((S * per + BLK - 1) / BLK, B), dim3(BLK), 0, st, cf, W, d->p,
+                       d->rn_offWW, d->rn_offBB, r, S, d->rn_npar, d->has_bias, Weff);
+    const dim3 gridh(nblk, (r + JB - 1) / JB, B);
+    hipLaunchKernelGGL((k_fwd_hidden<T, JB>), gridh, dim3(BLK), 0, st, apre, Wpre, (const T*)nullptr, X, row_idx,
+                       OUT[0]);
+    for (int i = 0; i < S; ++i) {
+        hipLaunchKernelGGL((k_fwd_hidden<T, JB>), gridh, dim3(BLK), 0, st, astep(i), (const T*)Weff,
+                           (const T*)OUT[i], X, row_idx, TH[i]);
+        if (!d->rn_mlp)
+            hipLaunchKernelGGL(k_rn_axpy<T>, dim3(egrid), dim3(BLK), 0, st, (const T*)OUT[i], (const T*)TH[i],
+                               (T)(1.0 / S), nact, OUT[i + 1]);
+    }
+    hipLaunchKernelGGL((k_fwd_last<T>), dim3(nblk, B), dim3(BLK), 0, st, apost, Wpost, (const T*)OUT[S], X, Y,
+                       row_idx, dz_last, pred, partial, nblk);
+    hipLaunchKernelGGL(k_sse_final, dim3((B + 63) / 64), dim3(64), 0, st, partial, nblk, B, sse);
+    if (grad) {
+        const dim3 grida(nblk, (r + KB - 1) / KB, B);
+        const dim3 gridw((r + TK - 1) / TK, (r + TJ - 1) / TJ, B);
+        // G = d SSE / d OUT_S
+        const T* G = dz_last;
+        int nb = 0;              // next free scratch buffer
+        if (d->rn_post) {
+            hipLaunchKernelGGL((k_dW<T, TJ, TK>), dim3((r + TK - 1) / TK, (o + TJ - 1) / TJ, B), dim3(BLK), 0, st,
+                               apost, (const T*)dz_last, (const T*)OUT[S], X, row_idx, gradW);
+            LayerArgs a = apost; a.act = QN_ACT_IDENTITY;
+            hipLaunchKernelGGL((k_bwd_dA<T, KB>), grida, dim3(BLK), 0, st, a, Wpost, (const T*)dz_last,
+                               (const T*)OUT[S], buf[0]);
+            G = buf[0]; nb = 1;
+        }
+        const T sc = d->rn_mlp ? T(1) : (T)(1.0 / S);
+        for (int i = S - 1; i >= 0; --i) {
+            T* dz = buf[nb]; nb = (nb + 1) % 3;
+            hipLaunchKernelGGL(k_rn_dz<T>, dim3(egrid), dim3(BLK), 0, st, G, (const T*)TH[i], sc, d->act, nact, dz);
+            LayerArgs a = astep(i);
+            hipLaunchKernelGGL((k_dW<T, TJ, TK>), gridw, dim3(BLK), 0, st, a, (const T*)dz, (const T*)OUT[i], X,
+                               row_idx, dWeff);
+            if (i > 0 || d->rn_pre) {
+                T* t = buf[nb]; nb = (nb + 1) % 3;
+                a.act = QN_ACT_IDENTITY;
+                hipLaunchKernelGGL((k_bwd_dA<T, KB>), grida, dim3(BLK), 0, st, a, (const T*)Weff, (const T*)dz,
+                                   (const T*)OUT[i], t);
+                if (!d->rn_mlp) hipLaunchKernelGGL(k_rn_add<T>, dim3(egrid), dim3(BLK), 0, st, G, nact, t);
+                G = t;
+            }
+        }
+        if (d->rn_pre) {
+            T* dz = buf[nb];
+            hipLaunchKernelGGL(k_rn_dz<T>, dim3(egrid), dim3(BLK), 0, st, G, (const T*)OUT[0], T(1), d->act, nact, dz);
+            hipLaunchKernelGGL((k_dW<T, TJ, TK>), dim3((din + TK - 1) / TK, (r + TJ - 1) / TJ, B), dim3(BLK), 0, st,
+                               apre, (const T*)dz, (const T*)nullptr, X, row_idx, gradW);
+        }
+        const int tot = d->rn_npar * per;
+        hipLaunchKernelGGL(k_rn_contract<T>, dim3((tot + BLK - 1) / BLK, B), dim3(BLK), 0, st, cf, (const T*)dWeff, r,
+                           S, d->rn_npar, d->has_bias, d->p, d->rn_offWW, d->rn_offBB, gradW);
+    }
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
+
 }  // namespace
 
 size_t qn_generic_workspace(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
@@ -594,4 +782,25 @@ int qn_generic_run(const qn_desc* d, int dtype, const void* W, const void* X, co
                                    (double*)pred, (double*)gradW, ws, ws_bytes, st);
     return run_generic<float>(d, (const float*)W, (const float*)X, (const float*)Y, row_idx, B, N, Nb, sse,
                               (float*)pred, (float*)gradW, ws, ws_bytes, st);
+}
+
+size_t qn_rnet_workspace(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
+    const size_t e = dtype == QN_F64 ? 8 : 4;
+    const int r = d->rn_r, S = d->rn_steps, o = d->dims[2];
+    const size_t nact = qn_align((size_t)B * r * Nb * e);
+    const size_t weff = qn_align((size_t)B * S * (r * r + r) * e);
+    size_t tot = nact * (1 + (d->rn_mlp ? S : 2 * S)) + weff + qn_align((size_t)r * r * e);
+    tot += qn_align((size_t)B * ((Nb + BLK - 1) / BLK) * sizeof(double));
+    if (want_grad) tot += qn_align((size_t)B * o * Nb * e) + 3 * nact + weff;
+    return tot + 256;
+}
+
+int qn_rnet_run(const qn_desc* d, int dtype, const void* W, const void* X, const void* Y, const int32_t* row_idx,
+                int B, int N, int Nb, double* sse, void* pred, void* gradW, void* ws, size_t ws_bytes,
+                hipStream_t st) {
+    if (dtype == QN_F64)
+        return run_rnet<double>(d, (const double*)W, (const double*)X, (const double*)Y, row_idx, B, N, Nb, sse,
+                                (double*)pred, (double*)gradW, ws, ws_bytes, st);
+    return run_rnet<float>(d, (const float*)W, (const float*)X, (const float*)Y, row_idx, B, N, Nb, sse,
+                           (float*)pred, (float*)gradW, ws, ws_bytes, st);
 }

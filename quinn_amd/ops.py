@@ -34,6 +34,22 @@ class MLPArch:
     def nweights(self):
         return sum(a * b for a, b in zip(self.dims[:-1], self.dims[1:]))
 
+    def param_shapes(self):
+        """Shapes of the module's parameter tensors in parameters() order."""
+        shapes = []
+        for a, b in zip(self.dims[:-1], self.dims[1:]):
+            shapes.append((b, a))
+            if self.bias:
+                shapes.append((b,))
+        return shapes
+
+    def create_desc(self, L):
+        dims = (ctypes.c_int * len(self.dims))(*self.dims)
+        h = ctypes.c_void_p()
+        _lib.check(L.qn_mlp_desc_create(dims, len(self.dims), _lib.ACT_CODES[self.activ], int(self.bias),
+                                        ctypes.byref(h)), "qn_mlp_desc_create")
+        return h
+
     def flops_fwd(self, n):
         """2*N*Wn."""
         return 2 * n * self.nweights
@@ -45,7 +61,10 @@ class MLPArch:
     @staticmethod
     def from_module(nnmodel):
         """Pattern-match Sequential(Linear, act, Linear, ..., Linear) -- directly, or as the
-        `.nnmodel` attribute of a quinn-style MLP (reference quinn/nns/mlp.py:86)."""
+        `.nnmodel` attribute of a quinn-style MLP (reference quinn/nns/mlp.py:86).  A quinn-style
+        residual network (attributes of quinn/nns/rnet.py:16-127) yields an `RNetArch`."""
+        if RNetArch.matches(nnmodel):
+            return RNetArch.from_module(nnmodel)
         seq = nnmodel
         if not isinstance(seq, torch.nn.Sequential):
             seq = getattr(nnmodel, "nnmodel", None)
@@ -88,6 +107,108 @@ class MLPArch:
         return MLPArch(tuple(dims), acts.pop() if acts else "identity", bool(bias))
 
 
+@dataclass(frozen=True)
+class RNetArch:
+    """Residual network of the reference (quinn/nns/rnet.py:16-165): optional pre layer (with
+    activation), `nsteps = nlayers + 1` residual steps out += h * act(W_i out + b_i) (or plain
+    layers if `mlp`), optional linear post layer.  `coef[i][k]` expresses the weight
+    parameterisation W_i = sum_k coef[i][k] ww_k (rnet.py:217-380, all linear in the ww_k).
+    Flat layout = parameters() order: weight_pre, bias_pre, weight_post, bias_post, ww_*, bb_*."""
+    indim: int
+    rdim: int
+    outdim: int
+    nsteps: int
+    coef: Tuple[Tuple[float, ...], ...]
+    activ: str = "tanh"
+    bias: bool = True
+    layer_pre: bool = False
+    layer_post: bool = False
+    mlp: bool = False
+
+    @property
+    def dims(self):
+        return (self.indim, self.rdim, self.outdim)
+
+    @property
+    def npar(self):
+        return len(self.coef[0])
+
+    def param_shapes(self):
+        r = self.rdim
+        shapes = []
+        if self.layer_pre:
+            shapes += [(r, self.indim), (r,)]
+        if self.layer_post:
+            shapes += [(self.outdim, r), (self.outdim,)]
+        shapes += [(r, r)] * self.npar
+        if self.bias:
+            shapes += [(r,)] * self.npar
+        return shapes
+
+    @property
+    def nparams(self):
+        return sum(int(np.prod(s)) for s in self.param_shapes())
+
+    @property
+    def nweights(self):
+        """Multiply-accumulates per data row."""
+        r = self.rdim
+        return (r * self.indim if self.layer_pre else 0) + self.nsteps * r * r + \
+            (self.outdim * r if self.layer_post else 0)
+
+    def flops_fwd(self, n):
+        return 2 * n * self.nweights
+
+    def flops_fwdbwd(self, n):
+        return 6 * n * self.nweights - (2 * n * self.rdim * self.indim if self.layer_pre else 0)
+
+    def create_desc(self, L):
+        if self.activ not in ("tanh", "identity"):
+            raise NotImplementedError("RNet activations: tanh (nonlin=True) or identity")
+        flat = [float(c) for row in self.coef for c in row]
+        arr = (ctypes.c_double * len(flat))(*flat)
+        h = ctypes.c_void_p()
+        _lib.check(L.qn_rnet_desc_create(self.indim, self.rdim, self.outdim, self.nsteps, self.npar, arr,
+                                         _lib.ACT_CODES[self.activ], int(self.bias), int(self.layer_pre),
+                                         int(self.layer_post), int(self.mlp), ctypes.byref(h)),
+                   "qn_rnet_desc_create")
+        return h
+
+    @staticmethod
+    def matches(nnmodel):
+        return all(hasattr(nnmodel, a) for a in ("rdim", "nlayers", "wp_function", "step_size", "layer_pre",
+                                                 "layer_post", "biasorno", "mlp"))
+
+    @staticmethod
+    def from_module(nnmodel):
+        """From this package's `RNet` or the reference's (same attributes).  The weight
+        parameterisation is probed with unit 'parameters' to get its coefficients, and checked to
+        be linear."""
+        if getattr(nnmodel, "final_layer", None) is not None:
+            raise NotImplementedError("RNet final_layer is outside the MI355X hot path")
+        wp = nnmodel.wp_function
+        npar, nsteps = int(wp.npar), int(nnmodel.nlayers) + 1
+        coef = []
+        for i in range(nsteps):
+            t = nnmodel.step_size * i                                  # rnet.py:146
+            row = []
+            for k in range(npar):
+                e = [1.0 if q == k else 0.0 for q in range(npar)]
+                c = float(wp(e, t))
+                if float(wp([2.0 * v for v in e], t)) != 2.0 * c or float(wp([0.0] * npar, t)) != 0.0:
+                    raise NotImplementedError("weight parameterisation must be linear in its parameters")
+                row.append(c)
+            coef.append(tuple(row))
+        act = nnmodel.activ
+        activ = "tanh" if isinstance(act, torch.nn.Tanh) else "identity" if isinstance(act, torch.nn.Identity) \
+            else None
+        if activ is None:
+            raise NotImplementedError(f"RNet activation {type(act).__name__}")
+        return RNetArch(int(nnmodel.indim), int(nnmodel.rdim), int(nnmodel.outdim), nsteps, tuple(coef), activ,
+                        bool(nnmodel.biasorno), bool(nnmodel.layer_pre), bool(nnmodel.layer_post),
+                        bool(nnmodel.mlp))
+
+
 def flatten_module(nnmodel):
     """Flat float64 numpy vector of module.parameters() (reference nnwrap.py:70-77)."""
     return np.concatenate([p.detach().cpu().double().flatten().numpy() for p in nnmodel.parameters()])
@@ -116,11 +237,7 @@ class BatchedMLP:
         self.qdt = _QN_DT[dtype]
         self.max_ws = int(max_workspace_bytes)
         self._L = _lib.lib()
-        dims = (ctypes.c_int * len(arch.dims))(*arch.dims)
-        h = ctypes.c_void_p()
-        _lib.check(self._L.qn_mlp_desc_create(dims, len(arch.dims), _lib.ACT_CODES[arch.activ],
-                                              int(arch.bias), ctypes.byref(h)), "qn_mlp_desc_create")
-        self._desc = h
+        self._desc = h = arch.create_desc(self._L)
         self.p = int(self._L.qn_mlp_num_params(h))
         assert self.p == arch.nparams
         self._ws = None

@@ -25,12 +25,7 @@ from ..ops import MLPArch, BatchedMLP
 
 
 def _param_shapes(arch):
-    shapes = []
-    for a, b in zip(arch.dims[:-1], arch.dims[1:]):
-        shapes.append((b, a))
-        if arch.bias:
-            shapes.append((b,))
-    return shapes
+    return arch.param_shapes()
 
 
 class _ViLoss(torch.autograd.Function):

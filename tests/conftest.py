@@ -26,6 +26,9 @@ def golden():
 
 def spec_of(g):
     from oracle.mlp_ref import MLPSpec
+    if "rdim" in g:
+        from oracle.rnet_ref import spec_from_fixture
+        return spec_from_fixture(g)
     return MLPSpec(tuple(int(v) for v in g["dims"]), str(g["activ"]))
 
 

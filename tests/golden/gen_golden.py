@@ -378,3 +378,124 @@ def g9():
 
 if __name__ == "__main__" and "rms" in sys.argv[1:]:
     g9()
+
+
+# ---------------------------------------------------------------- G10: residual network (RNet)
+def _rnet_fields(kw, wp_kind, wp_arg):
+    return dict(rdim=kw["rdim"], nlayers=kw["nlayers"], wp_kind=np.array(wp_kind), wp_arg=wp_arg,
+                indim=kw.get("indim") or 0, outdim=kw.get("outdim") or 0, biasorno=kw.get("biasorno", True),
+                nonlin=kw.get("nonlin", True), mlp=kw.get("mlp", False), layer_pre=kw.get("layer_pre", False),
+                layer_post=kw.get("layer_post", False))
+
+
+def _rnet(kw, wp_kind, wp_arg):
+    from quinn.nns import rnet as R
+    wp = {"const": lambda: R.Const(), "lin": lambda: R.Lin(), "quad": lambda: R.Quad(), "cubic": lambda: R.Cubic(),
+          "poly": lambda: R.Poly(wp_arg), "nonpar": lambda: (R.NonPar(wp_arg) if wp_arg else None)}[wp_kind]()
+    return R.RNet(kw["rdim"], kw["nlayers"], wp_function=wp, **{k: v for k, v in kw.items()
+                                                                if k not in ("rdim", "nlayers")})
+
+
+RNET_CASES = [
+    # the network of examples/ex_ufit.py:72-77
+    (dict(rdim=3, nlayers=3, indim=1, outdim=1, layer_pre=True, layer_post=True), "poly", 0),
+    # tests/test_mlp.py:135-145 (default NonPar(nlayers+1))
+    (dict(rdim=5, nlayers=3, indim=2, outdim=1, layer_pre=True, layer_post=True), "nonpar", 0),
+    # same width everywhere, no pre / post layer (tests/test_mlp.py:147-156)
+    (dict(rdim=3, nlayers=4), "lin", 0),
+    (dict(rdim=4, nlayers=3, indim=2, outdim=1, mlp=True, layer_pre=True, layer_post=True), "quad", 0),
+    (dict(rdim=6, nlayers=2, indim=2, outdim=2, layer_pre=True, layer_post=True, biasorno=False, nonlin=False),
+     "cubic", 0),
+    (dict(rdim=12, nlayers=5, indim=3, outdim=2, layer_pre=True, layer_post=True), "poly", 2),
+]
+
+
+def g10():
+    for ci, (kw, wk, wa) in enumerate(RNET_CASES):
+        torch.manual_seed(90 + ci)
+        net = _rnet(kw, wk, wa)
+        w_init = np.concatenate([p.detach().flatten().numpy() for p in net.parameters()])
+        solver = NN_MCMC(net, verbose=False)
+        p = solver.pdim
+        d, o = net.indim, net.outdim
+        N = 37 + 5 * ci
+        x, y = data(N, d, o, 0.05, 110 + ci)
+        sigma = 0.3
+        lpinfo = {"model": nn_p, "xd": x, "yd": [yy for yy in y], "ltype": "classical",
+                  "lparams": {"sigma": sigma}}
+        W = 0.5 * np.random.RandomState(120 + ci).randn(8, p)
+        lp = np.array([solver.logpost(w, lpinfo) for w in W])
+        gr = np.array([solver.logpostgrad(w, lpinfo) for w in W])
+        pred = np.array([nn_p(w, x, solver.nnmodel) for w in W])
+        save(f"g10_rnet_logpost_{ci}.npz", x=x, y=y, sigma=sigma, W=W, logpost=lp, grad=gr, pred=pred,
+             torch_seed=90 + ci, w_init=w_init, **_rnet_fields(kw, wk, wa))
+    # chains on the ex_ufit network: adaptive Metropolis through NN_MCMC.fit, HMC through the sampler class
+    kw, wk, wa = RNET_CASES[0]
+    x, y = data(14, 1, 1, 0.02, 130)
+    torch.manual_seed(96)
+    solver = NN_MCMC(_rnet(kw, wk, wa), verbose=False)
+    sp = {"gamma": 0.05, "t0": 20, "tadapt": 50}
+    u = run_fit(solver, x, y, 0.2, 300, "amcmc", sp, 17)
+    np.random.seed(17)
+    ini = np.random.rand(solver.pdim)
+    mc = AMCMC(**sp)
+    mc.setLogPost(solver.logpost, None, lpinfo=solver.lpinfo)
+    res = mc.run(param_ini=ini, nmcmc=300)
+    assert np.array_equal(res["chain"], solver.samples)
+    save("g10_rnet_amcmc.npz", x=x, y=y, sigma=0.2, seed=17, nmcmc=300, gamma=0.05, t0=20, tadapt=50,
+         chain=res["chain"], logpost=res["logpost"], alphas=res["alphas"], accrate=res["accrate"],
+         mapparams=res["mapparams"], maxpost=res["maxpost"], uniforms=u, **_rnet_fields(kw, wk, wa))
+    kw, wk, wa = RNET_CASES[1]
+    x, y = data(25, 2, 1, 0.05, 131)
+    solver = NN_MCMC(_rnet(kw, wk, wa), verbose=False)
+    np.random.seed(18)
+    ini = np.random.rand(solver.pdim)
+    solver.lpinfo = {"model": nn_p, "xd": x, "yd": [yy for yy in y], "ltype": "classical",
+                     "lparams": {"sigma": 0.2}}
+    mc = HMC(epsilon=0.002, L=3)
+    mc.setLogPost(solver.logpost, solver.logpostgrad, lpinfo=solver.lpinfo)
+    res = mc.run(param_ini=ini, nmcmc=80)
+    save("g10_rnet_hmc.npz", x=x, y=y, sigma=0.2, seed=18, nmcmc=80, L=3, epsilon=0.002, chain=res["chain"],
+         logpost=res["logpost"], alphas=res["alphas"], accrate=res["accrate"], mapparams=res["mapparams"],
+         maxpost=res["maxpost"], **_rnet_fields(kw, wk, wa))
+    # deep ensemble and VI fits on the ex_ufit network (call pattern of examples/ex_ufit.py:107-113)
+    kw, wk, wa = RNET_CASES[0]
+    torch.manual_seed(97)
+    net = _rnet(kw, wk, wa)
+    w0 = np.concatenate([p.detach().flatten().numpy() for p in net.parameters()])
+    x, y = data(30, 1, 1, 0.05, 132)
+    xv, yv = data(8, 1, 1, 0.05, 133)
+    ens = NN_Ens(net, nens=3, dfrac=0.8, verbose=False)
+    np.random.seed(98)
+    torch.manual_seed(99)
+    ens.fit(x, y, val=[xv, yv], lrate=0.01, batch_size=8, nepochs=20, freq_out=1000)
+    hist = np.array([np.array(l.nnmodel.history) for l in ens.learners])
+    best = np.array([NNWrap(l.best_model).p_flatten().detach().numpy().flatten() for l in ens.learners])
+    final = np.array([np.concatenate([p.detach().flatten().numpy() for p in l.nnmodel.parameters()])
+                      for l in ens.learners])
+    xg = np.linspace(-3, 3, 11)[:, None]
+    np.random.seed(100)
+    yens = ens.predict_ens(xg)
+    save("g10_rnet_ens.npz", x=x, y=y, xval=xv, yval=yv, w0=w0, nens=3, dfrac=0.8, lrate=0.01, batch_size=8,
+         nepochs=20, np_seed=98, torch_seed=99, history=hist, best=best, final=final, xg=xg, predict_seed=100,
+         yens=yens, **_rnet_fields(kw, wk, wa))
+    torch.manual_seed(101)
+    net = _rnet(kw, wk, wa)
+    w_net = np.concatenate([p.detach().flatten().numpy() for p in net.parameters()])
+    vi = NN_VI(net, verbose=False)
+    mu0, rho0 = _bnet_flat(vi.bmodel)
+    gen_state = torch.get_rng_state().numpy().copy()
+    from quinn.nns.nnfit import nnfit
+    vi.bmodel.loss_params = [0.1, 2, (30 + 1) // 10]
+    info = nnfit(vi.bmodel, x, y, val=[xv, yv], loss_xy=vi.bmodel.viloss, lrate=0.01, batch_size=10,
+                 nepochs=20, freq_out=1000)
+    mu1, rho1 = _bnet_flat(vi.bmodel)
+    mub, rhob = _bnet_flat(info["best_nnmodel"])
+    save("g10_rnet_vifit.npz", x=x, y=y, xval=xv, yval=yv, mu0=mu0, rho0=rho0, gen_state=gen_state, datanoise=0.1,
+         lrate=0.01, batch_size=10, nsam=2, nepochs=20, mu_final=mu1, rho_final=rho1, mu_best=mub, rho_best=rhob,
+         history=np.array(info["history"]), best_loss=info["best_loss"], best_epoch=info["best_epoch"],
+         torch_seed=101, w_net=w_net, **_rnet_fields(kw, wk, wa))
+
+
+if __name__ == "__main__" and "rnet" in sys.argv[1:]:
+    g10()

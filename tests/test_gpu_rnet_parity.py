@@ -1,0 +1,205 @@
+"""GPU: the residual network of the reference (quinn/nns/rnet.py) through the HIP path -- the
+operator against the reference's fixtures and the live oracle, and the solvers (NN_MCMC / NN_Ens /
+NN_VI) on the network of examples/ex_ufit.py against the reference's own runs.
+float64: rtol 1e-11 on SSE / log-posterior, 1e-10 (of max |grad|) on gradients; float32: 2e-4 / 2e-3."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, spec_of
+from oracle import mlp_ref, mcmc_ref
+from oracle.rnet_ref import RNetSpec
+from quinn_amd.nns import rnet as R
+from quinn_amd.nns.nnfit import load_flat_into
+from quinn_amd.ops import MLPArch, RNetArch, BatchedMLP, neg_log_post_from_sse
+from quinn_amd.solvers.nn_ens import NN_Ens
+from quinn_amd.solvers.nn_mcmc import NN_MCMC
+from quinn_amd.solvers.nn_vi import NN_VI
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"float64": (1e-11, 1e-10), "float32": (2e-4, 2e-3)}
+
+
+@pytest.fixture(autouse=True)
+def _double_default():
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.double)              # examples/ex_ufit.py:25
+    yield
+    torch.set_default_dtype(old)
+
+
+def _net_from_spec(s):
+    wp = {"const": R.Const, "lin": R.Lin, "quad": R.Quad, "cubic": R.Cubic}.get(s.wp_kind)
+    wp = wp() if wp else R.Poly(s.wp_arg) if s.wp_kind == "poly" else (R.NonPar(s.wp_arg) if s.wp_arg else None)
+    return R.RNet(s.rdim, s.nlayers, wp_function=wp, indim=s.indim or None, outdim=s.outdim or None,
+                  biasorno=s.bias, nonlin=s.nonlin, mlp=s.mlp, layer_pre=s.layer_pre, layer_post=s.layer_post)
+
+
+def _net(g):
+    return _net_from_spec(spec_of(g))
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("ci", range(6))
+def test_g10_golden_logpost_grad_pred(ci, dtype):
+    g = load_golden(f"g10_rnet_logpost_{ci}.npz")
+    arch = MLPArch.from_module(_net(g))
+    assert isinstance(arch, RNetArch)
+    op = BatchedMLP(arch, g["x"], g["y"], dtype=dtype)
+    rt, gt = TOL[dtype]
+    n, sigma = g["x"].shape[0], float(g["sigma"])
+    sse, grad = op.sse_grad(g["W"])
+    sse2, pred = op.sse_pred(g["W"])
+    lp = -neg_log_post_from_sse(sse.cpu().numpy(), n, sigma)
+    np.testing.assert_allclose(lp, g["logpost"], rtol=rt)
+    np.testing.assert_allclose(sse2.cpu().numpy(), sse.cpu().numpy(), rtol=rt)
+    gl = -(0.5 * grad.double().cpu().numpy() / sigma ** 2)
+    scale = np.abs(g["grad"]).max(axis=1, keepdims=True)
+    assert np.max(np.abs(gl - g["grad"]) / scale) < gt
+    np.testing.assert_allclose(pred.double().cpu().numpy(), g["pred"], rtol=gt, atol=gt)
+
+
+SPECS = [  # spec, N, B
+    (RNetSpec(64, 2, "nonpar", 0, 3, 2, layer_pre=True, layer_post=True), 700, 3),     # wide, ragged rows
+    (RNetSpec(20, 7, "poly", 3, 1, 1, layer_pre=True, layer_post=True), 1000, 5),
+    (RNetSpec(9, 15, "nonpar", 0), 257, 2),                                            # 16 steps, d = r = o
+    (RNetSpec(3, 3, "poly", 0, 1, 1, layer_pre=True, layer_post=True), 1, 4),          # one data row
+    (RNetSpec(7, 1, "const", 0, 7, 2, layer_post=True, bias=False), 90, 2),            # post only
+    (RNetSpec(5, 2, "lin", 0, 2, 5, layer_pre=True, mlp=True), 64, 3),                 # pre only, plain layers
+]
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("case", SPECS, ids=[f"r{c[0].rdim}L{c[0].nlayers}{c[0].wp_kind}" for c in SPECS])
+def test_random_rnets_vs_oracle(case, dtype):
+    spec, N, B = case
+    rs = np.random.RandomState(spec.rdim * 31 + spec.nlayers)
+    x = rs.uniform(-2, 2, (N, spec.d))
+    y = rs.randn(N, spec.o)
+    W = 0.4 * rs.randn(B, spec.nparams)
+    arch = MLPArch.from_module(_net_from_spec(spec))
+    assert arch.nparams == spec.nparams
+    op = BatchedMLP(arch, x, y, dtype=dtype)
+    mod = mlp_ref.build_module(spec)
+    rt, gt = TOL[dtype]
+    sse, grad = op.sse_grad(W)
+    _, pred = op.sse_pred(W)
+    for b in range(B):
+        ref_g = -mlp_ref.logpostgrad(mod, W[b], x, [v for v in y], 1.0) * 2.0      # d SSE / dw at sigma = 1
+        np.testing.assert_allclose(float(sse[b]), mlp_ref.sse(mod, W[b], x, y), rtol=rt)
+        assert np.max(np.abs(grad[b].double().cpu().numpy() - ref_g)) / np.abs(ref_g).max() < gt
+        np.testing.assert_allclose(pred[b].double().cpu().numpy(), mlp_ref.forward_flat(mod, W[b], x), rtol=gt,
+                                   atol=gt)
+
+
+def test_minibatch_rows_per_member():
+    """row_idx gathers (the ensemble trainer's minibatches) on an RNet."""
+    spec = RNetSpec(6, 2, "quad", 0, 2, 1, layer_pre=True, layer_post=True)
+    rs = np.random.RandomState(5)
+    x, y = rs.uniform(-2, 2, (50, 2)), rs.randn(50, 1)
+    W = 0.4 * rs.randn(3, spec.nparams)
+    rows = np.stack([rs.permutation(50)[:13] for _ in range(3)]).astype(np.int32)
+    op = BatchedMLP(MLPArch.from_module(_net_from_spec(spec)), x, y)
+    sse, grad = op.sse_grad(W, row_idx=rows)
+    mod = mlp_ref.build_module(spec)
+    for b in range(3):
+        xb, yb = x[rows[b]], y[rows[b]]
+        np.testing.assert_allclose(float(sse[b]), mlp_ref.sse(mod, W[b], xb, yb), rtol=1e-11)
+        ref_g = -mlp_ref.logpostgrad(mod, W[b], xb, [v for v in yb], 1.0) * 2.0
+        assert np.max(np.abs(grad[b].cpu().numpy() - ref_g)) / np.abs(ref_g).max() < 1e-10
+
+
+def test_amcmc_chain_on_ex_ufit_network():
+    g = load_golden("g10_rnet_amcmc.npz")
+    solver = NN_MCMC(_net(g), verbose=False)
+    np.random.seed(int(g["seed"]))
+    solver.fit(g["x"], g["y"], zflag=False, datanoise=float(g["sigma"]), nmcmc=int(g["nmcmc"]), sampler='amcmc',
+               sampler_params={'gamma': float(g["gamma"]), 't0': int(g["t0"]), 'tadapt': int(g["tadapt"])})
+    acc = (solver.samples[1:] != solver.samples[:-1]).any(axis=1)
+    assert np.array_equal(acc, (g["chain"][1:] != g["chain"][:-1]).any(axis=1))     # acceptance indices: exact
+    assert solver.mcmc_results["accrate"] == float(g["accrate"])
+    np.testing.assert_allclose(solver.samples, g["chain"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(solver.mcmc_results["logpost"], g["logpost"], rtol=1e-9)
+    # bit-exact against the oracle stepping the same chain on this host (host LAPACK in the proposal)
+    spec = spec_of(g)
+    mod = mlp_ref.build_module(spec)
+    yd = [v for v in g["y"]]
+    rng = np.random.RandomState(int(g["seed"]))
+    ini = rng.rand(spec.nparams)
+    ref = mcmc_ref.run_chain(lambda w: mlp_ref.logpost(mod, w, g["x"], yd, float(g["sigma"])),
+                             mcmc_ref.AmcmcState(gamma=float(g["gamma"]), t0=int(g["t0"]), tadapt=int(g["tadapt"])),
+                             int(g["nmcmc"]), ini, rng)
+    assert np.array_equal(solver.samples, ref["chain"])
+    ymap = solver.predict_MAP(g["x"])
+    np.testing.assert_allclose(ymap, mlp_ref.forward_flat(mod, ref["mapparams"], g["x"]), rtol=1e-10, atol=1e-12)
+
+
+def test_hmc_chain_and_multichain():
+    g = load_golden("g10_rnet_hmc.npz")
+    solver = NN_MCMC(_net(g), verbose=False)
+    sp = {'epsilon': float(g["epsilon"]), 'L': int(g["L"])}
+    solver.fit(g["x"], g["y"], zflag=False, datanoise=float(g["sigma"]), nmcmc=int(g["nmcmc"]), sampler='hmc',
+               sampler_params=sp, seeds=[int(g["seed"]), 5, 6])
+    chain = solver.samples[0]
+    acc = (chain[1:] != chain[:-1]).any(axis=1)
+    assert np.array_equal(acc, (g["chain"][1:] != g["chain"][:-1]).any(axis=1))
+    np.testing.assert_allclose(chain, g["chain"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(solver.mcmc_results["logpost"][0], g["logpost"], rtol=1e-9)
+    assert solver.samples.shape == (3,) + g["chain"].shape
+
+
+def test_ensemble_trajectories():
+    g = load_golden("g10_rnet_ens.npz")
+    net = _net(g)
+    load_flat_into(net, g["w0"])
+    ens = NN_Ens(net, nens=int(g["nens"]), dfrac=float(g["dfrac"]), verbose=False)
+    np.random.seed(int(g["np_seed"]))
+    torch.manual_seed(int(g["torch_seed"]))
+    ens.fit(g["x"], g["y"], val=[g["xval"], g["yval"]], lrate=float(g["lrate"]), batch_size=int(g["batch_size"]),
+            nepochs=int(g["nepochs"]), freq_out=1000)
+    hist = np.array([l.history for l in ens.learners])
+    np.testing.assert_allclose(hist, g["history"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(ens.fit_results["best_w"], g["best"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(ens.fit_results["final_w"], g["final"], rtol=1e-9, atol=1e-11)
+    np.random.seed(int(g["predict_seed"]))
+    np.testing.assert_allclose(ens.predict_ens(g["xg"]), g["yens"], rtol=1e-9, atol=1e-11)
+
+
+def test_vi_fit_trajectory_and_init_order():
+    g = load_golden("g10_rnet_vifit.npz")
+    torch.manual_seed(int(g["torch_seed"]))
+    net = _net(g)                                      # consumes the generator like the reference's RNet()
+    from quinn_amd.ops import flatten_module
+    assert np.array_equal(flatten_module(net), g["w_net"])
+    vi = NN_VI(net, verbose=False)
+    np.testing.assert_array_equal(vi.bmodel.mu.cpu().numpy(), g["mu0"])
+    np.testing.assert_array_equal(vi.bmodel.rho.cpu().numpy(), g["rho0"])
+    torch.set_rng_state(torch.from_numpy(g["gen_state"]))
+    vi.fit(g["x"], g["y"], val=[g["xval"], g["yval"]], datanoise=float(g["datanoise"]), lrate=float(g["lrate"]),
+           batch_size=int(g["batch_size"]), nsam=int(g["nsam"]), nepochs=int(g["nepochs"]), freq_out=1000)
+    np.testing.assert_allclose(np.array(vi.fit_info["history"]), g["history"], rtol=1e-8, atol=1e-9)
+    p = vi.bmodel.p
+    th = vi.bmodel.theta.detach().cpu().numpy()
+    np.testing.assert_allclose(th[:p], g["mu_final"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(th[p:], g["rho_final"], rtol=1e-8, atol=1e-10)
+    assert vi.fit_info["best_epoch"] == int(g["best_epoch"])
+
+
+def test_module_predict_and_fit_api():
+    """RNet.predict / RNet.fit (nnbase.py:61-115; tests/test_mlp.py:159-170) run on the device operator."""
+    torch.manual_seed(3)
+    net = R.RNet(4, 3, indim=2, outdim=1, layer_pre=True, layer_post=True)
+    x = np.random.RandomState(0).rand(10, 2)
+    y = net.predict(x)
+    assert isinstance(y, np.ndarray) and y.shape == (10, 1)
+    with torch.no_grad():
+        np.testing.assert_allclose(y, net(torch.from_numpy(x)).numpy(), rtol=1e-12, atol=1e-14)
+    assert net.numpar() == 2 * 4 + 4 + 4 + 1 + 4 * 16 + 4 * 4
+
+
+def test_descriptor_argument_checks():
+    with pytest.raises(Exception):
+        BatchedMLP(RNetArch(2, 3, 1, 2, ((1.0,), (1.0,)), layer_pre=False, layer_post=True), np.zeros((1, 2)), None)
+    with pytest.raises(Exception):
+        BatchedMLP(RNetArch(3, 3, 3, 17, tuple((1.0,) for _ in range(17))), np.zeros((1, 3)), None)
