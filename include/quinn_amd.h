@@ -146,6 +146,9 @@ int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int
 
 /* Diagnostic: y[i] = device tanh(x[i]) in float64 (the activation used by every kernel). */
 int qn_debug_tanh(const double* x, double* y, int64_t n, void* stream);
+/* Diagnostic: the variant the fused kernels use when all weights and inputs are finite and bounded
+ * (no NaN handling; same values for every non-NaN input). */
+int qn_debug_tanh_finite(const double* x, double* y, int64_t n, void* stream);
 
 const char* qn_last_error(void);
 /* "quinn_amd <version> gfx950" */

@@ -356,20 +356,29 @@ extern "C" int qn_adam_batched(double* W, const void* G, double* m, double* v, c
 // ------------------------------------------------------------------------------------------
 // Diagnostic: the device tanh on an array (accuracy tests of qn_math.h).
 namespace {
+template <bool NANSAFE>
 __global__ void k_tanh_f64(const double* __restrict__ x, double* __restrict__ y, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] = qn_tanh_f64(x[i]);
+    if (i < n) y[i] = qn_tanh_f64_impl<NANSAFE>(x[i]);
+}
+int debug_tanh(const char* fn, bool nansafe, const double* x, double* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0) {
+        qn_set_error("%s: bad argument", fn);
+        return QN_EINVAL;
+    }
+    (void)hipGetLastError();
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (nansafe) hipLaunchKernelGGL(k_tanh_f64<true>, grid, dim3(256), 0, st, x, y, n);
+    else hipLaunchKernelGGL(k_tanh_f64<false>, grid, dim3(256), 0, st, x, y, n);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
 }
 }  // namespace
 
 extern "C" int qn_debug_tanh(const double* x, double* y, int64_t n, void* stream) {
-    if (!x || !y || n <= 0) {
-        qn_set_error("qn_debug_tanh: bad argument");
-        return QN_EINVAL;
-    }
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(k_tanh_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                       y, n);
-    QN_HIP_CHECK(hipGetLastError());
-    return QN_OK;
+    return debug_tanh("qn_debug_tanh", true, x, y, n, stream);
+}
+extern "C" int qn_debug_tanh_finite(const double* x, double* y, int64_t n, void* stream) {
+    return debug_tanh("qn_debug_tanh_finite", false, x, y, n, stream);
 }

@@ -24,6 +24,7 @@
 #include "qn_common.h"
 #include "qn_math.h"
 #include <cstdlib>
+#include <type_traits>
 #include <mutex>
 #include <unordered_set>
 
@@ -51,8 +52,8 @@ __host__ __device__ inline int lds_doubles(int H, int dp, int o, int nhid) {
 }
 inline int padded_d(int d) { return d <= 2 ? 2 : 4; }
 
-template <int ACT> __device__ __forceinline__ double act_apply(double z) {
-    if constexpr (ACT == QN_ACT_TANH) return qn_tanh_f64(z);
+template <int ACT, bool NANSAFE = true> __device__ __forceinline__ double act_apply(double z) {
+    if constexpr (ACT == QN_ACT_TANH) return qn_tanh_f64_impl<NANSAFE>(z);
     else if constexpr (ACT == QN_ACT_RELU) return z > 0.0 ? z : 0.0;
     else return z;
 }
@@ -63,12 +64,27 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Workgroup-wide OR through a word of the kernel's dynamic LDS (__syncthreads_or would add a static
+// LDS variable on top of the 160 KB the backward kernel asks for).  Ends with a barrier.
+__device__ __forceinline__ bool block_or(int mine, double* slot) {
+    int* flag = reinterpret_cast<int*>(slot);
+    if (threadIdx.x == 0) *flag = 0;
+    __syncthreads();
+    if (mine) *flag = 1;
+    __syncthreads();
+    return *flag != 0;
+}
+
 // Copy weight vector `Wb` into the LDS image.  Loads are issued in batches (all of a layer's
 // loads in flight before the first LDS write): a load->wait->write loop costs one memory round
 // trip per 2 KB and was ~15 % of the kernel.
+// Returns (per thread) whether any weight it copied is NaN / inf / >= 2^500 in magnitude: the caller ORs
+// this over the workgroup and then knows whether the NaN-free tanh may be used (qn_math.h).
 template <int H, int DP, int NT = WG>
-__device__ __forceinline__ void stage_weights(double* __restrict__ lds, const double* __restrict__ Wb,
-                                              const FusedArgs& a) {
+__device__ __forceinline__ int stage_weights(double* __restrict__ lds, const double* __restrict__ Wb,
+                                             const FusedArgs& a) {
+    int bad = 0;
+    auto chk = [&](double v) { bad |= !qn_bounded(v); return v; };
     constexpr int S = stride_of(H);
     constexpr int PER = (H * H + NT - 1) / NT;
     const int tid = threadIdx.x;
@@ -84,15 +100,15 @@ __device__ __forceinline__ void stage_weights(double* __restrict__ lds, const do
         const int lWl = lHH + (a.nhid - 1) * (H * S + H), lbl = lWl + o * H;
         for (int e = tid; e < H * DP; e += NT) {
             const int j = e / DP, k = e % DP;
-            lds[lW0 + e] = k < d ? Wb[gW0 + j * d + k] : 0.0;
+            lds[lW0 + e] = k < d ? chk(Wb[gW0 + j * d + k]) : 0.0;
         }
-        for (int e = tid; e < H; e += NT) lds[lb0 + e] = nb ? Wb[gb0 + e] : 0.0;
+        for (int e = tid; e < H; e += NT) lds[lb0 + e] = nb ? chk(Wb[gb0 + e]) : 0.0;
         for (int layer = 1; layer < a.nhid; ++layer)
             for (int e = tid; e < H; e += NT)
                 lds[lHH + (layer - 1) * (H * S + H) + H * S + e] =
-                    nb ? Wb[gHH + (int64_t)(layer - 1) * (H * H + H) + H * H + e] : 0.0;
-        for (int e = tid; e < o * H; e += NT) lds[lWl + e] = Wb[gWl + e];
-        for (int e = tid; e < o; e += NT) lds[lbl + e] = nb ? Wb[gbl + e] : 0.0;
+                    nb ? chk(Wb[gHH + (int64_t)(layer - 1) * (H * H + H) + H * H + e]) : 0.0;
+        for (int e = tid; e < o * H; e += NT) lds[lWl + e] = chk(Wb[gWl + e]);
+        for (int e = tid; e < o; e += NT) lds[lbl + e] = nb ? chk(Wb[gbl + e]) : 0.0;
     }
     // hidden->hidden matrices, swizzled
     int64_t g = (int64_t)H * d + nb * H;
@@ -109,12 +125,13 @@ __device__ __forceinline__ void stage_weights(double* __restrict__ lds, const do
             const int e = tid + u * NT;
             if (H * H % NT == 0 || e < H * H) {
                 const int j = e / H, i = e % H;
-                lds[l + j * S + (i ^ swz(j))] = v[u];
+                lds[l + j * S + (i ^ swz(j))] = chk(v[u]);
             }
         }
         g += H * H + nb * H;
         l += H * S + H;
     }
+    return bad;
 }
 
 template <int H, int G, int ACT, int DP, int NT>
@@ -132,8 +149,9 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
     const int offWl = offHH + (NH - 1) * (H * S + H), offbl = offWl + o * H;
     double* red = lds + ((offbl + o + 1) & ~1);      // 4 doubles behind the weight image
 
-    stage_weights<H, DP, NT>(lds, W + (int64_t)b * a.p, a);
-    __syncthreads();
+    // NaN-free tanh only if nothing can produce a NaN: all weights of this chain bounded (checked while
+    // staging) and, per wave iteration, all inputs of its rows bounded (checked in fetch)
+    const bool w_unbounded = block_or(stage_weights<H, DP, NT>(lds, W + (int64_t)b * a.p, a), red + 6);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
@@ -145,7 +163,9 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
     double xn[G][DP], yn[G][OMAX];
     int nrow_n[G];
     bool valid_n[G];
+    int xbad_n = 0;
     auto fetch = [&](int it) {
+        xbad_n = 0;
         const int nbase = split * a.rows_per_split + (it * (NT / 64) + wave) * 16 * G;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -155,13 +175,15 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
             const int nn = valid_n[g] ? n : 0;
             const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
 #pragma unroll
-            for (int k = 0; k < DP; ++k) xn[g][k] = k < d ? X[rr * d + k] : 0.0;
+            for (int k = 0; k < DP; ++k) {
+                xn[g][k] = k < d ? X[rr * d + k] : 0.0;
+                xbad_n |= !qn_bounded(xn[g][k]);
+            }
 #pragma unroll
             for (int qo = 0; qo < OMAX; ++qo) yn[g][qo] = qo < o ? Y[rr * o + qo] : 0.0;
         }
     };
     fetch(0);
-
     for (int it = 0; it < a.iters; ++it) {
         double act[G][T][4];
         double yk[G][OMAX];
@@ -177,21 +199,27 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
 #pragma unroll
             for (int qo = 0; qo < OMAX; ++qo) yk[g][qo] = yn[g][qo];
         }
+        const bool nan_possible = w_unbounded || __any(xbad_n);
         if (it + 1 < a.iters) fetch(it + 1);
         // ---- first layer (VALU): a_1 = act(W0 x + b0)
+        auto first_layer = [&](auto tag) {
+            constexpr bool NS = decltype(tag)::value;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
+            for (int g = 0; g < G; ++g) {
 #pragma unroll
-            for (int t = 0; t < T; ++t)
+                for (int t = 0; t < T; ++t)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int j = 16 * t + q + 4 * i;
-                    double z = lds[offb0 + j];
+                    for (int i = 0; i < 4; ++i) {
+                        const int j = 16 * t + q + 4 * i;
+                        double z = lds[offb0 + j];
 #pragma unroll
-                    for (int k = 0; k < DP; ++k) z = fma(lds[offW0 + j * DP + k], xk[g][k], z);
-                    act[g][t][i] = act_apply<ACT>(z);
-                }
-        }
+                        for (int k = 0; k < DP; ++k) z = fma(lds[offW0 + j * DP + k], xk[g][k], z);
+                        act[g][t][i] = act_apply<ACT, NS>(z);
+                    }
+            }
+        };
+        if (ACT == QN_ACT_TANH && !nan_possible) first_layer(std::false_type{});
+        else first_layer(std::true_type{});
         // ---- hidden -> hidden layers on the matrix cores
         for (int layer = 1; layer < NH; ++layer) {
             const double* Wl = lds + offHH + (layer - 1) * (H * S + H);
@@ -216,12 +244,17 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
                         acc[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, act[g][s >> 2][s & 3], acc[g][t], 0, 0, 0);
                 }
             }
+            auto epilogue = [&](auto tag) {
+                constexpr bool NS = decltype(tag)::value;
 #pragma unroll
-            for (int g = 0; g < G; ++g)
+                for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int t = 0; t < T; ++t)
+                    for (int t = 0; t < T; ++t)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) act[g][t][i] = act_apply<ACT>(acc[g][t][i]);
+                        for (int i = 0; i < 4; ++i) act[g][t][i] = act_apply<ACT, NS>(acc[g][t][i]);
+            };
+            if (ACT == QN_ACT_TANH && !nan_possible) epilogue(std::false_type{});
+            else epilogue(std::true_type{});
         }
         // ---- last layer (VALU + 2 cross-lane adds), residual, SSE
 #pragma unroll
@@ -299,10 +332,15 @@ __host__ __device__ inline int bwd_lds_doubles(int H, int dp, int o, int nhid) {
 // activation of one 16x16 tile (4 values per lane); the switch is wave-uniform and sits OUTSIDE the
 // element loop, the sched_barrier keeps the scheduler from interleaving more than one tile's tanh
 // chains (register pressure)
-__device__ __forceinline__ void act_tile(const v4d& z, double (&out)[4], int act) {
+__device__ __forceinline__ void act_tile(const v4d& z, double (&out)[4], int act, bool nan_possible) {
     if (act == QN_ACT_TANH) {
+        if (nan_possible) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) out[i] = qn_tanh_f64(z[i]);
+            for (int i = 0; i < 4; ++i) out[i] = qn_tanh_f64(z[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[i] = qn_tanh_f64_finite(z[i]);
+        }
     } else if (act == QN_ACT_RELU) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) out[i] = z[i] > 0.0 ? z[i] : 0.0;
@@ -342,8 +380,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
     double* Sdl = Sx + ROWS_IT * DP;
     double* red = Sdl + ROWS_IT * OMAX;
 
-    stage_weights<H, DP>(lds, W + (int64_t)b * a.p, a);
-    __syncthreads();
+    const bool w_unbounded = block_or(stage_weights<H, DP>(lds, W + (int64_t)b * a.p, a), red + 6);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, c = lane & 15;
@@ -388,8 +425,13 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
         const int nn = valid ? n : 0;
         const int64_t rrow = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
         double xk[DP];
+        int xbad = 0;
 #pragma unroll
-        for (int k = 0; k < DP; ++k) xk[k] = k < d ? X[rrow * d + k] : 0.0;
+        for (int k = 0; k < DP; ++k) {
+            xk[k] = k < d ? X[rrow * d + k] : 0.0;
+            xbad |= !qn_bounded(xk[k]);
+        }
+        const bool nan_possible = w_unbounded || __any(xbad);
         QN_STAMP(0);                                       // 0: loop top + x load
         // ------------------------------------------------------------------ forward
         double act[NH][T][4];
@@ -403,7 +445,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
                 for (int k = 0; k < DP; ++k) z[i] = fma(lds[offW0 + j * DP + k], xk[k], z[i]);
             }
-            act_tile(z, act[0][t], act_kind);
+            act_tile(z, act[0][t], act_kind, nan_possible);
         }
 #pragma unroll
         for (int layer = 1; layer < NH; ++layer) {
@@ -433,7 +475,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int t = 0; t < T; ++t) act_tile(acc[t], act[layer][t], act_kind);
+                for (int t = 0; t < T; ++t) act_tile(acc[t], act[layer][t], act_kind, nan_possible);
             }
         }
         double (&alast)[T][4] = act[NH - 1];

@@ -51,3 +51,51 @@ def test_fused_equals_generic(case):
     np.testing.assert_allclose(b[2], b[0], rtol=1e-12)
     assert np.abs(b[1] - a[1]).max() <= 1e-10 * max(np.abs(a[1]).max(), 1e-300)
     np.testing.assert_allclose(b[3], a[3], rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("where", ["weight_nan", "weight_inf", "weight_huge", "bias_nan", "x_nan", "x_inf", "y_nan"])
+@pytest.mark.parametrize("grad", [False, True])
+def test_non_finite_inputs_follow_the_reference(where, grad):
+    """The fused kernels switch to the NaN-propagating tanh when a chain's weights or a tile's inputs are
+    not bounded: results equal the layer-wise kernels' and the oracle's (NaN where torch gives NaN)."""
+    from oracle import mlp_ref
+    dims, N, B = (1, 64, 64, 64, 1), 200, 3
+    rs = np.random.RandomState(11)
+    x = rs.uniform(-3, 3, (N, 1)); y = np.sin(x) + 0.1 * rs.randn(N, 1)
+    arch = MLPArch(dims, "tanh")
+    W = 0.3 * rs.randn(B, arch.nparams)
+    off_w1 = 64 + 64 + 5 * 64 + 7           # an entry of the first hidden->hidden matrix
+    if where == "weight_nan": W[1, off_w1] = np.nan
+    if where == "weight_inf": W[1, off_w1] = np.inf
+    if where == "weight_huge": W[1, off_w1] = 1e200
+    if where == "bias_nan": W[1, 64 + 3] = np.nan
+    if where == "x_nan": x[17, 0] = np.nan
+    if where == "x_inf": x[17, 0] = -np.inf
+    if where == "y_nan": y[17, 0] = np.nan
+    op = BatchedMLP(arch, x, y)
+    out = {}
+    for path in (_lib.PATH_GENERIC, _lib.PATH_FUSED):
+        old = _lib.lib().qn_set_path(path)
+        try:
+            if grad:
+                s, g = op.sse_grad(W)
+                out[path] = (s.cpu().numpy(), g.cpu().numpy())
+            else:
+                s, pr = op.sse_pred(W)
+                out[path] = (s.cpu().numpy(), pr.cpu().numpy())
+        finally:
+            _lib.lib().qn_set_path(old)
+    sg, ag = out[_lib.PATH_GENERIC]
+    sf, af = out[_lib.PATH_FUSED]
+    assert np.array_equal(np.isnan(sg), np.isnan(sf))
+    np.testing.assert_allclose(sf, sg, rtol=1e-11)
+    assert np.array_equal(np.isnan(ag), np.isnan(af))
+    fin = np.isfinite(ag)
+    if fin.any():
+        np.testing.assert_allclose(af[fin], ag[fin], rtol=1e-8, atol=1e-9 * max(1.0, np.abs(ag[fin]).max()))
+    mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, "tanh"))
+    for b in range(B):
+        ref = mlp_ref.sse(mod, W[b], x, y)
+        assert np.isnan(ref) == np.isnan(sf[b])
+        if np.isfinite(ref):
+            np.testing.assert_allclose(sf[b], ref, rtol=1e-11)

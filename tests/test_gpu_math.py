@@ -17,7 +17,10 @@ def _ref_tanh(x):
     return (np.sign(xl) * (-e / (2 + e))).astype(np.longdouble)
 
 
-def test_tanh_f64_ulp_error():
+@pytest.mark.parametrize("fn", ["qn_debug_tanh", "qn_debug_tanh_finite"])
+def test_tanh_f64_ulp_error(fn):
+    """Both variants (qn_math.h): the NaN-propagating one and the one the fused kernels use when every weight
+    and input is bounded.  Identical values for every non-NaN input."""
     rs = np.random.RandomState(0)
     xs = np.concatenate([rs.uniform(-20, 20, 200000), rs.uniform(-1, 1, 200000), rs.uniform(-1e-3, 1e-3, 50000),
                          10.0 ** rs.uniform(-300, -3, 20000), np.array([0.0, -0.0, 19.0, 19.07, 25.0, -40.0, 1e300,
@@ -25,8 +28,11 @@ def test_tanh_f64_ulp_error():
     x = torch.tensor(xs, device="cuda")
     y = torch.empty_like(x)
     L = _lib.lib()
-    _lib.check(L.qn_debug_tanh(x.data_ptr(), y.data_ptr(), x.numel(), None), "qn_debug_tanh")
+    _lib.check(getattr(L, fn)(x.data_ptr(), y.data_ptr(), x.numel(), None), fn)
     torch.cuda.synchronize()
+    y2 = torch.empty_like(x)
+    _lib.check(L.qn_debug_tanh(x.data_ptr(), y2.data_ptr(), x.numel(), None), "qn_debug_tanh")
+    assert torch.equal(y, y2)
     got = y.cpu().numpy()
     ref = _ref_tanh(xs)
     ulp = np.spacing(np.abs(ref.astype(np.float64)))
@@ -35,10 +41,11 @@ def test_tanh_f64_ulp_error():
     assert np.mean(err) < 0.7
     assert got[np.where(xs == np.inf)[0][0]] == 1.0 and got[np.where(xs == -np.inf)[0][0]] == -1.0
     assert np.signbit(got[np.where(xs == 0.0)[0][1]])          # tanh(-0.0) = -0.0
-    z = torch.tensor([np.nan], device="cuda", dtype=torch.float64)
-    w = torch.empty_like(z)
-    _lib.check(L.qn_debug_tanh(z.data_ptr(), w.data_ptr(), 1, None), "qn_debug_tanh")
-    assert torch.isnan(w).all()
+    if fn == "qn_debug_tanh":
+        z = torch.tensor([np.nan], device="cuda", dtype=torch.float64)
+        w = torch.empty_like(z)
+        _lib.check(L.qn_debug_tanh(z.data_ptr(), w.data_ptr(), 1, None), "qn_debug_tanh")
+        assert torch.isnan(w).all()
     # against torch's CPU tanh (what the reference computes with): a few ulp at most
     tref = torch.tanh(torch.tensor(xs)).numpy()
     fin = np.isfinite(xs)
