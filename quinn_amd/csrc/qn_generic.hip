@@ -19,6 +19,10 @@ constexpr int BLK = 256;
 template <typename T> __device__ __forceinline__ T qn_tanh(T x);
 template <> __device__ __forceinline__ double qn_tanh<double>(double x) { return qn_tanh_f64(x); }
 template <> __device__ __forceinline__ float qn_tanh<float>(float x) { return qn_tanh_f32(x); }
+// valid for every non-NaN argument (qn_math.h)
+template <typename T> __device__ __forceinline__ T qn_tanh_finite(T x);
+template <> __device__ __forceinline__ double qn_tanh_finite<double>(double x) { return qn_tanh_f64_finite(x); }
+template <> __device__ __forceinline__ float qn_tanh_finite<float>(float x) { return qn_tanh_f32(x); }
 
 template <typename T> __device__ __forceinline__ T apply_act(T z, int act) {
     if (act == QN_ACT_TANH) return qn_tanh<T>(z);
@@ -223,12 +227,14 @@ template <> struct mfma16<double> {
     typedef double v4 __attribute__((ext_vector_type(4)));
     // C/D: reg r of a 16x16 tile = row (lane>>4) + 4 r
     static __device__ __forceinline__ int row(int q, int r) { return q + 4 * r; }
+    static constexpr int RSTEP = 4;
     static __device__ __forceinline__ v4 run(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 };
 template <> struct mfma16<float> {
     typedef float v4 __attribute__((ext_vector_type(4)));
     // v_mfma_f32_16x16x4_f32: reg r = row 4 (lane>>4) + r
     static __device__ __forceinline__ int row(int q, int r) { return 4 * q + r; }
+    static constexpr int RSTEP = 1;
     static __device__ __forceinline__ v4 run(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 };
 enum { GEMM_FWD = 0, GEMM_DA = 1, GEMM_DW = 2 };
@@ -237,7 +243,17 @@ constexpr int GKB = 16, GSP = GKB + 2, GSQ = 80;   // K-step 32 halves the resid
 struct GemmArgs {
     int64_t p, offW, offB, out_stride_b, out_stride_k;
     int h_in, h_out, Nb, act, has_bias, ksplit, kchunk;
+    int inner, outer_total, per_b;      // XCD-aware 1-D grid, see gemm_grid()
 };
+// Workgroups are dealt round-robin to the 8 XCDs (workgroup L runs on XCD L % 8, each with its own L2).
+// Output tiles that read the same operand slab -- FWD / DA: the M-tiles of one column block (same
+// activations in[K][64]); DW: the (j, i) tiles of one row chunk (same dz / a rows) -- form an "inner"
+// group that is laid out on ONE XCD, back to back in its dispatch order, so the slab comes from HBM once
+// and from that XCD's L2 afterwards.  outer = which slab (column block or row chunk, times chain).
+inline unsigned gemm_grid(GemmArgs& g, int inner, int per_b, int B) {
+    g.inner = inner; g.per_b = per_b; g.outer_total = per_b * B;
+    return (unsigned)(((g.outer_total + 7) / 8) * 8 * inner);
+}
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(BLK) void k_gemm64(GemmArgs g, const T* __restrict__ W, const T* __restrict__ in0,
@@ -245,20 +261,25 @@ __global__ __launch_bounds__(BLK) void k_gemm64(GemmArgs g, const T* __restrict_
     typedef typename mfma16<T>::v4 gv4;
     __shared__ __attribute__((aligned(16))) T Ps[2][64 * GSP];
     __shared__ __attribute__((aligned(16))) T Qs[2][GKB * GSQ];
-    const int b = blockIdx.z, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, c = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
     const int Nb = g.Nb;
+    // XCD-aware decode of the 1-D grid (gemm_grid)
+    const int seq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int inner_i = seq % g.inner, outer = (seq / g.inner) * 8 + xcd;
+    if (outer >= g.outer_total) return;
+    const int b = outer / g.per_b, slab = outer % g.per_b;
     int m0, n0, kbeg, kend;
     if (MODE == GEMM_DW) {
         const int tiles_i = g.h_in / 64;
-        m0 = (blockIdx.y / tiles_i) * 64;          // j0
-        n0 = (blockIdx.y % tiles_i) * 64;          // i0
-        kbeg = blockIdx.x * g.kchunk;
+        m0 = (inner_i / tiles_i) * 64;             // j0
+        n0 = (inner_i % tiles_i) * 64;             // i0
+        kbeg = slab * g.kchunk;
         kend = kbeg + g.kchunk < Nb ? kbeg + g.kchunk : Nb;
     } else {
-        m0 = blockIdx.y * 64;
-        n0 = blockIdx.x * 64;
+        m0 = inner_i * 64;
+        n0 = slab * 64;
         kbeg = 0;
         kend = MODE == GEMM_FWD ? g.h_in : g.h_out;
     }
@@ -291,11 +312,20 @@ __global__ __launch_bounds__(BLK) void k_gemm64(GemmArgs g, const T* __restrict_
             for (int u = 0; u < NE; ++u) { const int n = n0 + nq + u; qr[u] = qs[n < Nb ? n : ncl]; }
         } else {                         // P[m][k] = dz[j0+m][k0+k];  Q[k][n] = a[i0+n][k0+k]   (k = data row)
             const int m = tid >> 2, kq = (tid & 3) * NE;
-#pragma unroll
-            for (int u = 0; u < NE; ++u) pr[u] = k0 + kq + u < kend ? I0[(int64_t)(m0 + m) * Nb + k0 + kq + u] : T(0);
             const int nn = tid & 63, kq2 = (tid >> 6) * NE;
+            const T* ps = I0 + (int64_t)(m0 + m) * Nb + k0 + kq;
+            const T* qs = I1 + (int64_t)(n0 + nn) * Nb + k0 + kq2;
+            if (k0 + GKB <= kend) {      // wave-uniform: only the last K-step of the last chunk is ragged
 #pragma unroll
-            for (int u = 0; u < NE; ++u) qr[u] = k0 + kq2 + u < kend ? I1[(int64_t)(n0 + nn) * Nb + k0 + kq2 + u] : T(0);
+                for (int u = 0; u < NE; ++u) pr[u] = ps[u];
+#pragma unroll
+                for (int u = 0; u < NE; ++u) qr[u] = qs[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < NE; ++u) pr[u] = k0 + kq + u < kend ? ps[u] : T(0);
+#pragma unroll
+                for (int u = 0; u < NE; ++u) qr[u] = k0 + kq2 + u < kend ? qs[u] : T(0);
+            }
         }
     };
     auto lstore = [&](int buf) {
@@ -368,30 +398,94 @@ __global__ __launch_bounds__(BLK) void k_gemm64(GemmArgs g, const T* __restrict_
         __syncthreads();
         buf ^= 1;
     }
-    // ---- epilogue; C layout: reg r of tile (mi, ni) = row 16*(2wm+mi) + mfma16<T>::row(q, r), col 16*(2wn+ni) + c
+    // ---- epilogue; C layout: reg r of tile (mi, ni) = row 16*(2wm+mi) + mfma16<T>::row(q, r), col 16*(2wn+ni) + c.
+    // Every VALU instruction here competes with the MFMAs for the same pipe, so row pointers are
+    // formed once per (mi, r) from one vector base plus wave-uniform offsets, and the activation is chosen per wave.
+    constexpr int RS = mfma16<T>::RSTEP;
+    const int mrow = m0 + 32 * wm + mfma16<T>::row(q, 0);          // row of (mi = 0, r = 0)
+    const int ncol = n0 + 32 * wn + c;                             // column of ni = 0
+    if (MODE == GEMM_DW) {
+        T* o = out + (int64_t)b * g.out_stride_b + (int64_t)slab * g.out_stride_k + (int64_t)mrow * g.h_in + ncol;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 16 * (2 * wm + mi) + mfma16<T>::row(q, r);
-                const int n = n0 + 16 * (2 * wn + ni) + c;
-                T v = acc[mi][ni][r];
-                if (MODE == GEMM_FWD) {
-                    if (n < Nb) {
-                        if (g.has_bias) v += W[(int64_t)b * g.p + g.offB + m];
-                        out[((int64_t)b * g.h_out + m) * Nb + n] = apply_act(v, g.act);
-                    }
-                } else if (MODE == GEMM_DA) {
-                    if (n < Nb) {
-                        const int64_t idx = ((int64_t)b * g.h_in + m) * Nb + n;
-                        out[idx] = v * act_deriv(in1[idx], g.act);
-                    }
-                } else {
-                    out[(int64_t)b * g.out_stride_b + (int64_t)blockIdx.x * g.out_stride_k + (int64_t)m * g.h_in + n] = v;
-                }
+                T* orow = o + (int64_t)(16 * mi + RS * r) * g.h_in;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) orow[16 * ni] = acc[mi][ni][r];
             }
+        return;
+    }
+    const int hrows = MODE == GEMM_FWD ? g.h_out : g.h_in;
+    const int64_t base = ((int64_t)b * hrows + mrow) * Nb + ncol;
+    const bool ok[2] = {ncol < Nb, ncol + 16 < Nb};
+    if (MODE == GEMM_FWD) {
+        T v[2][2][4];
+        const T* bias = W + (int64_t)b * g.p + g.offB + mrow;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const T bj = g.has_bias ? bias[16 * mi + RS * r] : T(0);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) v[mi][ni][r] = acc[mi][ni][r] + bj;
+            }
+        if (g.act == QN_ACT_TANH) {
+            // a NaN pre-activation makes the sum NaN (so does inf - inf, which only costs the slower variant):
+            // one wave-uniform test instead of a NaN mask per element (qn_math.h)
+            T sum = T(0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sum += v[mi][ni][r];
+            if (__any(sum != sum)) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[mi][ni][r] = qn_tanh<T>(v[mi][ni][r]);
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[mi][ni][r] = qn_tanh_finite<T>(v[mi][ni][r]);
+            }
+        } else if (g.act == QN_ACT_RELU) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[mi][ni][r] = v[mi][ni][r] > T(0) ? v[mi][ni][r] : T(0);
+        }
+        T* o = out + base;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                T* orow = o + (int64_t)(16 * mi + RS * r) * Nb;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    if (ok[ni]) orow[16 * ni] = v[mi][ni][r];
+            }
+    } else {
+        const T* a = in1 + base;
+        T* o = out + base;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t ro = (int64_t)(16 * mi + RS * r) * Nb;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    if (ok[ni]) o[ro + 16 * ni] = acc[mi][ni][r] * act_deriv(a[ro + 16 * ni], g.act);
+            }
+    }
 }
 
 // db[b][j] = sum_n dz[b][j][n]   (one block per (j, b); fixed-order reduction)
@@ -428,8 +522,9 @@ __global__ __launch_bounds__(BLK) void k_slab_reduce(const T* __restrict__ slab,
 inline bool gemm_layer(const qn_desc* d, int l) {
     return l >= 1 && l + 1 < d->nlayers && d->dims[l] % 64 == 0 && d->dims[l + 1] % 64 == 0;
 }
+// split-K factor of the dW GEMM: enough workgroups for ~4 resident per CU (LDS-limited) over several rounds
 inline int dw_ksplit(int B, int tiles, int Nb) {
-    int ks = (512 + B * tiles - 1) / (B * tiles);
+    int ks = (4096 + B * tiles - 1) / (B * tiles);
     const int kmax = (Nb + 255) / 256;
     if (ks > kmax) ks = kmax;
     if (ks > 16) ks = 16;
@@ -496,8 +591,8 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
     for (int l = 0; l + 1 < L; ++l) {
         if (gemm_layer(d, l)) {
             GemmArgs g = gargs(l);
-            dim3 grid((Nb + 63) / 64, g.h_out / 64, B);
-            hipLaunchKernelGGL((k_gemm64<T, GEMM_FWD>), grid, dim3(BLK), 0, st, g, W, (const T*)act[l - 1],
+            const unsigned grid = gemm_grid(g, g.h_out / 64, (Nb + 63) / 64, B);
+            hipLaunchKernelGGL((k_gemm64<T, GEMM_FWD>), dim3(grid), dim3(BLK), 0, st, g, W, (const T*)act[l - 1],
                                (const T*)nullptr, act[l]);
             continue;
         }
@@ -528,7 +623,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                 T* dst = gradW + d->offW[l];
                 g.out_stride_b = d->p; g.out_stride_k = 0;
                 if (ks > 1) { dst = dwslab; g.out_stride_b = (int64_t)ks * nW; g.out_stride_k = nW; }
-                hipLaunchKernelGGL((k_gemm64<T, GEMM_DW>), dim3(ks, tiles, B), dim3(BLK), 0, st, g, W, dz,
+                hipLaunchKernelGGL((k_gemm64<T, GEMM_DW>), dim3(gemm_grid(g, tiles, ks, B)), dim3(BLK), 0, st, g, W, dz,
                                    (const T*)act[l - 1], dst);
                 if (ks > 1) {
                     int gx = (int)((nW + BLK - 1) / BLK);
@@ -541,8 +636,8 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                                        d->offB[l], gradW);
                 T* dzp = dzbuf[l & 1];
                 g.ksplit = 1; g.kchunk = Nb;
-                hipLaunchKernelGGL((k_gemm64<T, GEMM_DA>), dim3((Nb + 63) / 64, g.h_in / 64, B), dim3(BLK), 0, st, g, W,
-                                   dz, (const T*)act[l - 1], dzp);
+                hipLaunchKernelGGL((k_gemm64<T, GEMM_DA>), dim3(gemm_grid(g, g.h_in / 64, (Nb + 63) / 64, B)), dim3(BLK), 0,
+                                   st, g, W, dz, (const T*)act[l - 1], dzp);
                 dz = dzp;
                 continue;
             }
