@@ -78,10 +78,15 @@ def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lra
     """
     W0 = np.atleast_2d(np.asarray(W0, dtype=np.float64))
     M, p = W0.shape
-    rows = np.asarray(rows).reshape(M, -1)
-    ntrn = rows.shape[1]
+    ntrn = np.asarray(rows).shape[-1]
     if batch_size is None or batch_size > ntrn:
         batch_size = ntrn
+    if M == 0:      # this rank owns no member (more ranks than members): empty shard for the all_gather
+        nupd = nepochs * len(range(0, ntrn, batch_size))
+        return {'best_w': np.zeros((0, p)), 'final_w': np.zeros((0, p)), 'best_loss': np.zeros(0),
+                'best_epoch': np.zeros(0, dtype=np.int64), 'best_fepoch': np.zeros(0),
+                'history': np.zeros((0, nupd, 4))}
+    rows = np.asarray(rows).reshape(M, -1)
     o = arch.dims[-1]
     op = BatchedMLP(arch, xtrn, ytrn, device=device, dtype=dtype)
     opv = BatchedMLP(arch, xval, yval, device=device, dtype=dtype)

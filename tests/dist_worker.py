@@ -53,6 +53,13 @@ def main():
         single = make().run(int(g["nmcmc"]), ini, rngs=rngs, verbose=False)
         for k in ("chain", "logpost", "alphas", "accrate", "mapparams", "maxpost"):
             assert np.array_equal(res[k], single[k], equal_nan=True), k
+    # 3. fewer units than ranks: rank 1 owns an empty shard and still takes part in the gather
+    lo, hi = shard_bounds(1)
+    one = all_gather_rows(np.full((hi - lo, 2), 7.0), 1)
+    assert one.shape == (1, 2) and (one == 7.0).all()
+    res1 = run_chains_sharded(make, 25, None, seeds[:1])
+    assert res1["chain"].shape == (1, 26, spec.nparams)
+    np.testing.assert_allclose(res1["chain"][0], g["chain"][0][:26], rtol=1e-9, atol=1e-11)
     dist.barrier()
     with open(os.path.join(os.environ["QN_DIST_OUT"], f"ok_{rank}"), "w") as f:
         f.write("ok")
