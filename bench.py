@@ -104,6 +104,17 @@ def extras(op, arch, batches, args):
         out["amcmc_end_to_end_steps_per_s"] = 300 / el
         out["amcmc_end_to_end_logpost_evals_per_s"] = 300 * CHAINS / el
         out["amcmc_accrate"] = float(r["accrate"].mean())
+        # with adaptation switched on early (t0=100, tadapt=200): adapted proposals are drawn in sample
+        # space from the stored distinct states (qn_mcmc_propose_hist); cost grows with accepted moves
+        eng = DeviceAMCMC(op, SIGMA, gamma=0.01, t0=100, tadapt=200, seed=1)
+        eng.run(1000, ini, store_chain=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        r = eng.run(1000, ini, store_chain=True)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        out["amcmc_adapting_steps_per_s"] = 1000 / el
+        out["amcmc_adapting_accrate"] = float(r["accrate"].mean())
     return out
 
 

@@ -137,12 +137,30 @@ int qn_mcmc_propose(const double* cur, const double* sd, double c1, int C, int64
 /* qn_mcmc_accept: for every chain c: log-posterior of the proposal from its SSE,
  *   lp = -(0.5 sse/sigma^2 + (n_rows/2) log 2pi + n_rows log sigma); mh = exp(lp - cur_lp[c]);
  *   accept iff u_c < mh (mcmc.py:72-75); updates cur, cur_lp, best / best_lp (MAP, mcmc.py:79-81),
- *   nacc, writes chain[c, step+1, :] (optional), lps[c, step+1], alphas[c, step+1] and the next row
- *   (cur - x0) of the adaptation window win [C, win_len, p] (optional); then advances the counter. */
+ *   nacc, writes chain[c, step+1, :] (optional), lps[c, step+1], alphas[c, step+1]; then advances the
+ *   counter.  With hist != NULL it also maintains what the adapted proposal is drawn from
+ *   (qn_mcmc_propose_hist): hist [C, kcap, pstride] float32 = the DISTINCT states visited, minus x0
+ *   (row 0 = the start, a new row per accepted move), mult [C, kcap] their multiplicities in the
+ *   chain so far, kcur [C] the index of the current state's row, sumx [C, p] the running sum of
+ *   (x_i - x0) over all samples.  kcur[c] >= kcap means the history is full (rows are not stored). */
 int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int64_t p,
                    int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
-                   double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0, double* win,
-                   int win_len, int64_t* step_ptr, void* stream);
+                   double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0, float* hist,
+                   int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride, int64_t* step_ptr,
+                   void* stream);
+
+/* qn_mcmc_propose_hist: the ADAPTED proposal of adaptive Metropolis (admcmc.py:52-70), drawn in sample
+ *   space.  After an adaptation at step i the reference proposes from N(x, c (cov_i + 1e-8 I)) with
+ *   cov_i the unbiased sample covariance of x_0..x_i and c = gamma 2.4^2 / p.  With the K distinct
+ *   states x_k of that history, multiplicities w_k, mean m and n = i + 1,
+ *       out[c,:] = cur[c,:] + s_lr * sum_k wsnap[c,k] u_k (hist[c,k,:] - msnap[c,:]) + s_iso * v,
+ *   u_k, v_j iid N(0,1), wsnap = sqrt(w), s_lr = sqrt(c/(n-1)), s_iso = sqrt(c 1e-8), has exactly that
+ *   covariance: a K x p GEMV over the stored states instead of a p x p factor (cfg2: K ~ 10^2..10^3
+ *   rows of 34 KB per chain and step instead of 290-580 MB).  ksnap [C] = K per chain, msnap [C, p] =
+ *   mean of (x - x0) at the adaptation, both frozen until the next adaptation.  pstride even, >= p. */
+int qn_mcmc_propose_hist(const double* cur, const float* hist, const float* wsnap, const int32_t* ksnap,
+                         const double* msnap, double s_lr, double s_iso, int C, int64_t p, int64_t pstride,
+                         int kcap, uint64_t seed, const int64_t* step_ptr, double* out, void* stream);
 
 /* Diagnostic: y[i] = device tanh(x[i]) in float64 (the activation used by every kernel). */
 int qn_debug_tanh(const double* x, double* y, int64_t n, void* stream);

@@ -77,10 +77,82 @@ __global__ __launch_bounds__(BLK) void k_propose(const double* __restrict__ cur,
     }
 }
 
+// Adapted proposal drawn in SAMPLE SPACE.  The reference's proposal covariance after an adaptation at step i
+// is c (cov_i + 1e-8 I), cov_i = unbiased sample covariance of x_0..x_i (admcmc.py:52-67).  With the distinct
+// states x_k of that history, their multiplicities w_k, the mean m and n = i + 1,
+//     delta = sqrt(c / (n-1)) * sum_k sqrt(w_k) u_k (x_k - m)  +  sqrt(c 1e-8) v,    u_k, v_j iid N(0, 1)
+// has exactly that covariance -- no p x p matrix, no factorisation: a K x p GEMV over the stored states
+// (K = accepted moves so far; float32, shifted by x_0).  One chain per blockIdx.y, 2 columns per thread;
+// the coefficients sqrt(w_k) u_k are generated per block into LDS, KC at a time.
+constexpr int KC = 2048;
+struct HistArgs {
+    int C, kcap;
+    int64_t p, pstride;
+    double s_lr, s_iso;
+    uint64_t seed;
+};
+__global__ __launch_bounds__(BLK) void k_propose_hist(HistArgs a, const double* __restrict__ cur,
+                                                      const float* __restrict__ hist, const float* __restrict__ wsnap,
+                                                      const int32_t* __restrict__ ksnap,
+                                                      const double* __restrict__ msnap,
+                                                      const int64_t* __restrict__ step_ptr, double* __restrict__ out) {
+    __shared__ float coef[KC];
+    const int b = blockIdx.y;
+    const uint64_t step = (uint64_t)*step_ptr;
+    const int K = ksnap[b] < a.kcap ? ksnap[b] : a.kcap;
+    const int64_t j = 2 * ((int64_t)blockIdx.x * BLK + threadIdx.x);          // first of this thread's 2 columns
+    const bool live = j < a.p;
+    const float* hcol = hist + (int64_t)b * a.kcap * a.pstride + (live ? j : 0);
+    const float* wrow = wsnap + (int64_t)b * a.kcap;
+    const uint64_t kpairs = ((uint64_t)a.kcap + 1) / 2;
+    double acc0 = 0.0, acc1 = 0.0, sA = 0.0;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        const int kn = K - k0 < KC ? K - k0 : KC;
+        for (int kk = 2 * threadIdx.x; kk < kn; kk += 2 * BLK) {
+            Philox ph;
+            ph.gen(a.seed, 2 * step + 1, 2 * (uint64_t)a.C + (uint64_t)b * kpairs + (uint64_t)((k0 + kk) >> 1));
+            double za, zb;
+            normal2(ph, za, zb);
+            coef[kk] = wrow[k0 + kk] * (float)za;
+            if (kk + 1 < kn) coef[kk + 1] = wrow[k0 + kk + 1] * (float)zb;
+        }
+        __syncthreads();
+        const float* h = hcol + (int64_t)k0 * a.pstride;
+        int kk = 0;
+        for (; kk + 4 <= kn; kk += 4) {                             // 4 independent 8-byte loads in flight
+            const float2 h0 = *reinterpret_cast<const float2*>(h + (int64_t)(kk + 0) * a.pstride);
+            const float2 h1 = *reinterpret_cast<const float2*>(h + (int64_t)(kk + 1) * a.pstride);
+            const float2 h2 = *reinterpret_cast<const float2*>(h + (int64_t)(kk + 2) * a.pstride);
+            const float2 h3 = *reinterpret_cast<const float2*>(h + (int64_t)(kk + 3) * a.pstride);
+            const double c0 = coef[kk], c1 = coef[kk + 1], c2 = coef[kk + 2], c3 = coef[kk + 3];
+            acc0 = fma(c0, (double)h0.x, acc0); acc1 = fma(c0, (double)h0.y, acc1);
+            acc0 = fma(c1, (double)h1.x, acc0); acc1 = fma(c1, (double)h1.y, acc1);
+            acc0 = fma(c2, (double)h2.x, acc0); acc1 = fma(c2, (double)h2.y, acc1);
+            acc0 = fma(c3, (double)h3.x, acc0); acc1 = fma(c3, (double)h3.y, acc1);
+            sA += (c0 + c1) + (c2 + c3);
+        }
+        for (; kk < kn; ++kk) {
+            const float2 h0 = *reinterpret_cast<const float2*>(h + (int64_t)kk * a.pstride);
+            const double c0 = coef[kk];
+            acc0 = fma(c0, (double)h0.x, acc0); acc1 = fma(c0, (double)h0.y, acc1);
+            sA += c0;
+        }
+        __syncthreads();
+    }
+    if (!live) return;
+    Philox ph;
+    ph.gen(a.seed, 2 * step, (uint64_t)b * (uint64_t)((a.p + 1) / 2) + (uint64_t)(j >> 1));
+    double za, zb;
+    normal2(ph, za, zb);
+    const int64_t e0 = (int64_t)b * a.p + j;
+    out[e0] = cur[e0] + a.s_lr * (acc0 - sA * msnap[e0]) + a.s_iso * za;
+    if (j + 1 < a.p) out[e0 + 1] = cur[e0 + 1] + a.s_lr * (acc1 - sA * msnap[e0 + 1]) + a.s_iso * zb;
+}
+
 struct AcceptArgs {
     double half_inv_sig2, lp_const;       // log-posterior = -(half_inv_sig2 * sse + lp_const)
-    int C, nmcmc, win_len;
-    int64_t p;
+    int C, nmcmc, kcap;
+    int64_t p, pstride;
     uint64_t seed;
 };
 
@@ -91,7 +163,9 @@ __global__ __launch_bounds__(BLK) void k_accept(AcceptArgs a, const double* __re
                                                 double* __restrict__ best_lp, double* __restrict__ chain,
                                                 double* __restrict__ lps, double* __restrict__ alphas,
                                                 int64_t* __restrict__ nacc, const double* __restrict__ x0,
-                                                double* __restrict__ win, int64_t* __restrict__ step_ptr) {
+                                                float* __restrict__ hist, int32_t* __restrict__ mult,
+                                                int32_t* __restrict__ kcur, double* __restrict__ sumx,
+                                                int64_t* __restrict__ step_ptr) {
     const int b = blockIdx.x;
     const int64_t step = *step_ptr;
     const double plp = -(a.half_inv_sig2 * sse_prop[b] + a.lp_const);
@@ -105,16 +179,32 @@ __global__ __launch_bounds__(BLK) void k_accept(AcceptArgs a, const double* __re
     const bool better = take && nlp >= best_lp[b];
     const int64_t base = (int64_t)b * a.p;
     double* crow = chain ? chain + ((int64_t)b * (a.nmcmc + 1) + step + 1) * a.p : nullptr;
-    double* wrow = win ? win + ((int64_t)b * a.win_len + (step + 1) % a.win_len) * a.p : nullptr;
+    // history of DISTINCT states (shifted by x0, float32) with multiplicities, and the running sum of all
+    // samples: what the adapted proposal is drawn from (k_propose_hist)
+    const int kc = hist ? kcur[b] : 0;
+    const int knew = take ? kc + 1 : kc;
+    float* hrow = (hist && take && knew < a.kcap) ? hist + ((int64_t)b * a.kcap + knew) * a.pstride : nullptr;
     for (int64_t e = threadIdx.x; e < a.p; e += BLK) {
         const double v = take ? prop[base + e] : cur[base + e];
         if (take) cur[base + e] = v;
         if (better) best[base + e] = v;
         if (crow) crow[e] = v;
-        if (wrow) wrow[e] = v - x0[base + e];                       // next sample of the adaptation window
+        if (hist) {
+            const double dv = v - x0[base + e];
+            if (hrow) hrow[e] = (float)dv;
+            sumx[base + e] += dv;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (hist) {
+            if (take) {
+                kcur[b] = knew;                                     // knew >= kcap: history full, the host checks
+                if (knew < a.kcap) mult[(int64_t)b * a.kcap + knew] = 1;
+            } else if (kc < a.kcap) {
+                mult[(int64_t)b * a.kcap + kc] += 1;
+            }
+        }
         cur_lp[b] = nlp;
         if (better) best_lp[b] = nlp;
         lps[(int64_t)b * (a.nmcmc + 1) + step + 1] = nlp;
@@ -152,22 +242,42 @@ extern "C" int qn_mcmc_propose(const double* cur, const double* sd, double c1, i
     return QN_OK;
 }
 
+extern "C" int qn_mcmc_propose_hist(const double* cur, const float* hist, const float* wsnap, const int32_t* ksnap,
+                                    const double* msnap, double s_lr, double s_iso, int C, int64_t p,
+                                    int64_t pstride, int kcap, uint64_t seed, const int64_t* step_ptr, double* out,
+                                    void* stream) {
+    if (!cur || !hist || !wsnap || !ksnap || !msnap || !step_ptr || !out || C <= 0 || C > 65535 || p <= 0 ||
+        kcap <= 0 || pstride < p || (pstride & 1)) {
+        qn_set_error("qn_mcmc_propose_hist: bad argument (pstride must be even and >= p)");
+        return QN_EINVAL;
+    }
+    HistArgs a;
+    a.C = C; a.kcap = kcap; a.p = p; a.pstride = pstride; a.s_lr = s_lr; a.s_iso = s_iso; a.seed = seed;
+    const int gx = (int)(((p + 1) / 2 + BLK - 1) / BLK);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_propose_hist, dim3(gx, C), dim3(BLK), 0, static_cast<hipStream_t>(stream), a, cur, hist, wsnap,
+                       ksnap, msnap, step_ptr, out);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
+
 extern "C" int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int64_t p,
                               int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
                               double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0,
-                              double* win, int win_len, int64_t* step_ptr, void* stream) {
+                              float* hist, int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride,
+                              int64_t* step_ptr, void* stream) {
     if (!prop || !sse_prop || !cur || !cur_lp || !best || !best_lp || !lps || !alphas || !nacc || !step_ptr ||
-        C <= 0 || p <= 0 || sigma <= 0.0 || (win && (!x0 || win_len <= 0))) {
+        C <= 0 || p <= 0 || sigma <= 0.0 || (hist && (!x0 || !mult || !kcur || !sumx || kcap <= 0 || pstride < p))) {
         qn_set_error("qn_mcmc_accept: bad argument");
         return QN_EINVAL;
     }
     AcceptArgs a;
     a.half_inv_sig2 = 0.5 / (sigma * sigma);
     a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
-    a.C = C; a.nmcmc = nmcmc; a.win_len = win_len > 0 ? win_len : 1; a.p = p; a.seed = seed;
+    a.C = C; a.nmcmc = nmcmc; a.kcap = kcap; a.p = p; a.pstride = pstride; a.seed = seed;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_accept, dim3(C), dim3(BLK), 0, static_cast<hipStream_t>(stream), a, prop, sse_prop, cur, cur_lp,
-                       best, best_lp, chain, lps, alphas, nacc, x0, win, step_ptr);
+                       best, best_lp, chain, lps, alphas, nacc, x0, hist, mult, kcur, sumx, step_ptr);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }

@@ -2,28 +2,30 @@
 
 The reference-exact host sampler (`AMCMC`) keeps a p x p covariance per chain and draws through an
 SVD; at the headline configuration (64 chains, p = 8513) that is 74 GB of host state and minutes of
-LAPACK per adaptation -- the reference itself cannot run there.  This engine keeps states, proposal
-factors and the chain history in HBM and never synchronises with the host inside a window:
+LAPACK per adaptation -- the reference itself cannot run there.  This engine keeps states, the
+proposal's ingredients and the chain history in HBM and never synchronises with the host:
 
-  * one MH step = `qn_mcmc_propose` (in-kernel Philox normals) -> batched log-posterior kernel ->
-    `qn_mcmc_accept` (accept test, state / MAP / history / window update); the step counter lives in
-    device memory, so the step is a static launch sequence that can also be captured in ONE HIP graph
-    (`use_graph=True`); measured at cfg2: 5.9 k steps/s with direct launches (4 launches, ~3 us of
-    host time each), 5.2 k steps/s replayed as a graph (replay floor ~10-16 us), so direct launch is
-    the default;
-  * the reference's covariance recursion (admcmc.py:52-59) is, in closed form, the unbiased sample
-    covariance of x_0..x_i (tests/test_amcmc_math.py); it is only USED every `tadapt` steps
-    (admcmc.py:66-67), so it is accumulated per window as one batched SYRK (Gram matrix of the
-    window, shifted by x_0 against cancellation) instead of a rank-1 update of 580 MB per chain
-    and step;
+  * one MH step = proposal kernel (in-kernel Philox normals) -> batched log-posterior kernel ->
+    `qn_mcmc_accept` (accept test, state / MAP / history update); the step counter lives in device
+    memory, so the step is a static launch sequence that can also be captured in ONE HIP graph
+    (`use_graph=True`; direct launches are faster at cfg2 and the default);
   * initial proposal covariance 0.01 + diag(0.09|x0|) (admcmc.py:65) = diagonal + rank one:
-    drawn exactly as sqrt(0.09|x0|) * z + 0.1 * z0 without forming a p x p matrix;
-  * adapted proposals: batched Cholesky factor L of (gamma 2.4^2/p)(cov + 1e-8 I), draw = L z
-    (one batched GEMV per step; HBM-bound: p^2 * 8 B per chain and step).
+    drawn exactly as sqrt(0.09|x0|) * z + 0.1 * z0 without forming a p x p matrix (`qn_mcmc_propose`);
+  * adapted proposals are drawn in SAMPLE SPACE (`qn_mcmc_propose_hist`).  The reference's covariance
+    recursion (admcmc.py:52-59) is, in closed form, the unbiased sample covariance of x_0..x_i
+    (tests/test_amcmc_math.py), and an adaptation at step i sets the proposal covariance to
+    c (cov_i + 1e-8 I), c = gamma 2.4^2 / p (admcmc.py:66-67).  A chain of n = i + 1 samples has only
+    K = 1 + (accepted moves) DISTINCT states x_k with multiplicities w_k, and
+        delta = sqrt(c/(n-1)) sum_k sqrt(w_k) u_k (x_k - mean) + sqrt(c 1e-8) v,   u, v iid N(0,1)
+    has exactly that covariance.  So the engine stores the distinct states (float32, shifted by x_0:
+    `qn_mcmc_accept` appends a row per accepted move and counts multiplicities) and a proposal is a
+    K x p GEMV over them: at cfg2 K ~ 10^2..10^3 rows of 34 KB per chain and step, where a p x p factor
+    is 290-580 MB per chain and step plus an O(p^3) factorisation per adaptation.  An adaptation is a
+    snapshot of (K, sqrt(w), mean): a few elementwise torch ops, no SYRK, no Cholesky.
 
 Same target distribution and the same adaptation schedule as the reference; the random streams
-differ (Philox instead of numpy MT19937, Cholesky instead of SVD factor), so chains agree with the
-host sampler in distribution, not bit for bit.  Use `AMCMC` for bit-exact parity.
+differ (Philox instead of numpy MT19937, sample-space draw instead of an SVD factor), so chains agree
+with the host sampler in distribution, not bit for bit.  Use `AMCMC` for bit-exact parity.
 """
 import ctypes
 
@@ -36,7 +38,7 @@ from ..ops import BatchedMLP
 
 class DeviceAMCMC:
     def __init__(self, op: BatchedMLP, sigma, gamma=0.1, t0=100, tadapt=1000, cov_ini=None, seed=0,
-                 factor_dtype=torch.float64, chol_chunk=8, use_graph=False):
+                 use_graph=False, max_history_bytes=64 << 30):
         if op.dtype != "float64":
             raise NotImplementedError("the device AMCMC engine runs the float64 operator")
         self.op, self.sigma = op, float(sigma)
@@ -44,28 +46,36 @@ class DeviceAMCMC:
         self.cov_ini = cov_ini
         self.dev = op.device
         self.seed = int(seed) & (2 ** 63 - 1)
-        self.factor_dtype = factor_dtype
-        self.chol_chunk = chol_chunk
         self.use_graph = use_graph
+        self.max_history_bytes = int(max_history_bytes)
         self._L = _lib.lib()
 
     # -- kernel wrappers (enqueue on the current stream) ---------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
     def _propose(self, cur, sd, c1, step_ptr, out):
-        st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         C, p = out.shape
         _lib.check(self._L.qn_mcmc_propose(cur.data_ptr() if cur is not None else None,
                                            sd.data_ptr() if sd is not None else None, c1, C, p, self.seed,
-                                           step_ptr.data_ptr(), out.data_ptr(), st), "qn_mcmc_propose")
+                                           step_ptr.data_ptr(), out.data_ptr(), self._stream()), "qn_mcmc_propose")
+
+    def _propose_hist(self, s, snap, out):
+        C, p = out.shape
+        _lib.check(self._L.qn_mcmc_propose_hist(
+            s['cur'].data_ptr(), s['hist'].data_ptr(), snap['w'].data_ptr(), snap['k'].data_ptr(),
+            snap['mean'].data_ptr(), snap['s_lr'], snap['s_iso'], C, p, s['hist'].shape[2], s['hist'].shape[1],
+            self.seed, s['step'].data_ptr(), out.data_ptr(), self._stream()), "qn_mcmc_propose_hist")
 
     def _accept(self, s, prop, sse, nmcmc):
-        st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         C, p = prop.shape
         _lib.check(self._L.qn_mcmc_accept(
             prop.data_ptr(), sse.data_ptr(), self.sigma, self.op.N, C, p, nmcmc, self.seed, s['cur'].data_ptr(),
             s['cur_lp'].data_ptr(), s['best'].data_ptr(), s['best_lp'].data_ptr(),
             s['chain'].data_ptr() if s['chain'] is not None else None, s['lps'].data_ptr(), s['alphas'].data_ptr(),
-            s['nacc'].data_ptr(), s['x0'].data_ptr(), s['win'].data_ptr(), self.tadapt, s['step'].data_ptr(), st),
-            "qn_mcmc_accept")
+            s['nacc'].data_ptr(), s['x0'].data_ptr(), s['hist'].data_ptr(), s['mult'].data_ptr(),
+            s['kcur'].data_ptr(), s['sumx'].data_ptr(), s['hist'].shape[1], s['hist'].shape[2],
+            s['step'].data_ptr(), self._stream()), "qn_mcmc_accept")
 
     def run(self, nmcmc, param_ini, store_chain=True, verbose=False):
         dev, f64 = self.dev, torch.float64
@@ -74,35 +84,41 @@ class DeviceAMCMC:
         n = self.op.N
         const = (n / 2) * np.log(2 * np.pi) + n * np.log(self.sigma)
         cur_lp = -(0.5 * self.op.sse(cur) / self.sigma ** 2 + const)
+        # history of distinct states: one row per accepted move at most -> nmcmc + 1 rows always suffice
+        kcap, pstride = nmcmc + 1, (p + 3) // 4 * 4
+        if C * kcap * pstride * 4 > self.max_history_bytes:
+            raise MemoryError(f"state history {C} x {kcap} x {pstride} float32 exceeds max_history_bytes="
+                              f"{self.max_history_bytes}: run fewer steps per call or raise the limit")
         s = {'cur': cur, 'cur_lp': cur_lp, 'best': cur.clone(), 'best_lp': cur_lp.clone(), 'x0': cur.clone(),
              'chain': torch.empty(C, nmcmc + 1, p, dtype=f64, device=dev) if store_chain else None,
              'lps': torch.empty(C, nmcmc + 1, dtype=f64, device=dev),
              'alphas': torch.zeros(C, nmcmc + 1, dtype=f64, device=dev),
              'nacc': torch.zeros(C, dtype=torch.int64, device=dev),
-             'win': torch.zeros(C, self.tadapt, p, dtype=f64, device=dev),     # slot 0 = x_0 - x_0 = 0
+             'hist': torch.empty(C, kcap, pstride, dtype=torch.float32, device=dev),
+             'mult': torch.zeros(C, kcap, dtype=torch.int32, device=dev),
+             'kcur': torch.zeros(C, dtype=torch.int32, device=dev),
+             'sumx': torch.zeros(C, p, dtype=f64, device=dev),
              'step': torch.zeros(2, dtype=torch.int64, device=dev)}
+        s['hist'][:, 0] = 0.0                                               # row 0 = x_0 - x_0
+        s['mult'][:, 0] = 1
         if store_chain:
             s['chain'][:, 0] = cur
         s['lps'][:, 0] = cur_lp
         std0 = torch.sqrt(0.09 * s['x0'].abs())
         prop = torch.empty(C, p, dtype=f64, device=dev)
-        z = torch.empty(C, p, dtype=f64, device=dev)
-        state = {'L': None}
+        state = {'snap': None, 'L': None}
         if self.cov_ini is not None:
-            state['L'] = torch.linalg.cholesky(torch.as_tensor(np.asarray(self.cov_ini), dtype=f64, device=dev))[None].to(self.factor_dtype)
-        S2, s1 = None, torch.zeros(C, p, dtype=f64, device=dev)
-        nabs = 1                                                           # sample 0 (zero after the shift)
+            state['L'] = torch.linalg.cholesky(torch.as_tensor(np.asarray(self.cov_ini), dtype=f64, device=dev))
+            z = torch.empty(C, p, dtype=f64, device=dev)
 
         def one_step():
-            L = state['L']
-            if L is None:
-                self._propose(s['cur'], std0, 0.1, s['step'], prop)
-            else:
+            if state['snap'] is not None:
+                self._propose_hist(s, state['snap'], prop)
+            elif state['L'] is not None:                                    # user-supplied initial covariance
                 self._propose(None, None, 0.0, s['step'], z)
-                if L.shape[0] == 1:
-                    prop.copy_(s['cur'] + (z.to(L.dtype) @ L[0].T).to(f64))
-                else:
-                    prop.copy_(s['cur'] + torch.bmm(L, z.to(L.dtype)[:, :, None])[:, :, 0].to(f64))
+                prop.copy_(s['cur'] + z @ state['L'].T)
+            else:
+                self._propose(s['cur'], std0, 0.1, s['step'], prop)
             sse = self.op.sse(prop)
             self._accept(s, prop, sse, nmcmc)
 
@@ -111,10 +127,10 @@ class DeviceAMCMC:
         def make_graph():
             if not self.use_graph:
                 return None
-            # warm-up on a side stream (allocator / library handles), then capture one step.
-            # The warm-up steps are real steps: rewind the counter and every piece of state afterwards.
-            # (chain row / window slot written by the warm-up step are rewritten by the real step)
-            snap = {k: v.clone() for k, v in s.items() if k not in ('chain', 'win') and isinstance(v, torch.Tensor)}
+            # warm-up on a side stream (allocator / library handles), then capture one step.  The warm-up
+            # step is a real step: rewind the counter and every piece of state afterwards (the chain /
+            # history rows it wrote are rewritten by the real step).
+            snap = {k: v.clone() for k, v in s.items() if k not in ('chain', 'hist') and isinstance(v, torch.Tensor)}
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
@@ -125,35 +141,21 @@ class DeviceAMCMC:
                 one_step()
             torch.cuda.synchronize(dev)
             for k, v in snap.items():                                      # capture itself does not execute
-                if isinstance(v, torch.Tensor):
-                    s[k].copy_(v)
+                s[k].copy_(v)
             return g
 
         i = 0
         while i < nmcmc:
-            if i > 0 and i % self.tadapt == 0:
-                # the window holds samples i-tadapt+1 .. i (slot i % tadapt = 0 is sample i)
-                Y = s['win']
-                G = torch.bmm(Y.transpose(1, 2), Y)
-                S2 = G if S2 is None else S2.add_(G)
-                del G
-                s1 += Y.sum(dim=1)
-                nabs += self.tadapt
-                if i > self.t0:
-                    scale = self.gamma * 2.4 ** 2 / p
-                    if state['L'] is None or state['L'].shape[0] != C:
-                        state['L'] = torch.empty(C, p, p, dtype=self.factor_dtype, device=dev)
-                        graph = None                                       # the step changes shape: recapture
-                    for c0 in range(0, C, self.chol_chunk):
-                        sl = slice(c0, c0 + self.chol_chunk)
-                        cov = S2[sl] - s1[sl, :, None] * s1[sl, None, :] / nabs
-                        cov.mul_(scale / (nabs - 1))
-                        cov.diagonal(dim1=1, dim2=2).add_(scale * 1e-8)
-                        state['L'][sl] = torch.linalg.cholesky(cov).to(self.factor_dtype)
-                        del cov
+            if i > self.t0 and i % self.tadapt == 0:
+                # adaptation (admcmc.py:66-67) = snapshot of the history x_0..x_i: n = i + 1 samples
+                scale = self.gamma * 2.4 ** 2 / p
+                state['snap'] = {'k': (s['kcur'] + 1).clone(), 'w': s['mult'].to(torch.float32).sqrt_(),
+                                 'mean': s['sumx'] / (i + 1), 's_lr': float(np.sqrt(scale / i)),
+                                 's_iso': float(np.sqrt(scale * 1e-8))}
+                graph = None                                               # new snapshot tensors: recapture
             if self.use_graph and graph is None:
                 graph = make_graph()
-            nrun = min(nmcmc, (i // self.tadapt + 1) * self.tadapt) - i     # up to the next window boundary
+            nrun = min(nmcmc, (i // self.tadapt + 1) * self.tadapt) - i     # up to the next adaptation
             for _ in range(nrun):
                 if graph is not None:
                     graph.replay()

@@ -29,3 +29,25 @@ def test_initial_proposal_is_diag_plus_rank_one():
     z, z0 = rs.randn(400000, 4), rs.randn(400000, 1)
     draws = np.sqrt(0.09 * np.abs(x0)) * z + 0.1 * z0
     np.testing.assert_allclose(np.cov(draws.T), cov, atol=3e-3)
+
+
+def test_sample_space_draw_has_the_adapted_covariance():
+    """delta = sqrt(c/(n-1)) sum_k sqrt(w_k) u_k (x_k - m) + sqrt(c eps) v over the DISTINCT states of a
+    chain history has covariance c (cov + eps I) exactly (the identity behind qn_mcmc_propose_hist)."""
+    rs = np.random.RandomState(7)
+    p, K = 6, 23
+    xk = rs.randn(K, p).cumsum(axis=0) * 0.3                    # distinct states
+    w = rs.randint(1, 9, K)                                     # multiplicities (rejections repeat a state)
+    hist = np.repeat(xk, w, axis=0)                             # the chain as the reference sees it
+    n = hist.shape[0]
+    cov = np.cov(hist.T, ddof=1)
+    m = hist.mean(axis=0)
+    A = np.sqrt(w)[:, None] * (xk - m)                          # delta_lr = A^T u / sqrt(n-1)
+    np.testing.assert_allclose(A.T @ A / (n - 1), cov, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose((w[:, None] * xk).sum(axis=0) / n, m, rtol=1e-13)
+    # and by simulation, with the isotropic floor
+    c, eps = 0.37, 1e-2
+    u, v = rs.randn(200000, K), rs.randn(200000, p)
+    d = np.sqrt(c / (n - 1)) * (u @ A) + np.sqrt(c * eps) * v
+    target = c * (cov + eps * np.eye(p))
+    assert np.abs(np.cov(d.T) - target).max() < 0.02 * np.abs(target).max()

@@ -45,6 +45,81 @@ def test_device_engine_invariants_and_adaptation():
     assert np.all(lps[:, -200:].mean(axis=1) > lps[:, 0])                   # chains climbed from the random start
 
 
+def test_sample_space_proposal_kernel_covariance_and_history_tracking():
+    """qn_mcmc_propose_hist draws N(cur, c (cov + 1e-8 I)) for the history described by (hist, mult, mean):
+    empirical covariance over many independent streams vs numpy's covariance of the expanded history."""
+    import ctypes
+    from quinn_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(5)
+    p, K, kcap, C = 7, 40, 64, 20000
+    pstride = 8
+    x0 = rs.randn(p)
+    xk = x0 + np.concatenate([np.zeros((1, p)), (0.2 * rs.randn(K - 1, p)).cumsum(axis=0)])
+    w = rs.randint(1, 12, K)
+    full = np.repeat(xk, w, axis=0)
+    n = full.shape[0]
+    dev = torch.device("cuda")
+    hist1 = np.zeros((kcap, pstride), dtype=np.float32); hist1[:K, :p] = xk - x0
+    hist1[K:] = 1e6                                                          # rows beyond K must not be read
+    hist = torch.as_tensor(hist1, device=dev)[None].expand(C, kcap, pstride).contiguous()
+    wsn = np.zeros(kcap, dtype=np.float32); wsn[:K] = np.sqrt(w)
+    wsnap = torch.as_tensor(wsn, device=dev)[None].expand(C, kcap).contiguous()
+    ksnap = torch.full((C,), K, dtype=torch.int32, device=dev)
+    mean = torch.as_tensor((full - x0).mean(axis=0), device=dev)[None].expand(C, p).contiguous()
+    cur = torch.as_tensor(rs.randn(p), device=dev)[None].expand(C, p).contiguous()
+    step = torch.zeros(2, dtype=torch.int64, device=dev); step[0] = 17
+    out = torch.empty(C, p, dtype=torch.float64, device=dev)
+    c = 0.1 * 2.4 ** 2 / p
+    _lib.check(L.qn_mcmc_propose_hist(cur.data_ptr(), hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(),
+                                      mean.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, p,
+                                      pstride, kcap, 1234, step.data_ptr(), out.data_ptr(), None), "propose_hist")
+    torch.cuda.synchronize()
+    d = (out - cur).cpu().numpy()
+    target = c * (np.cov(full.T, ddof=1) + 1e-8 * np.eye(p))
+    assert np.abs(d.mean(axis=0)).max() < 4 * np.sqrt(np.diag(target).max() / C)
+    assert np.abs(np.cov(d.T) - target).max() < 0.05 * np.abs(target).max()
+    # a different step counter gives different draws; the same one reproduces them bit for bit
+    out2 = torch.empty_like(out)
+    _lib.check(L.qn_mcmc_propose_hist(cur.data_ptr(), hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(),
+                                      mean.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, p,
+                                      pstride, kcap, 1234, step.data_ptr(), out2.data_ptr(), None), "propose_hist")
+    assert torch.equal(out, out2)
+
+
+def test_history_of_distinct_states_matches_the_chain():
+    """After a run, (hist, mult, sumx) maintained by qn_mcmc_accept describe exactly the stored chain."""
+    from quinn_amd.mcmc.device_amcmc import DeviceAMCMC
+    from quinn_amd.ops import MLPArch, BatchedMLP
+    x, y = _problem(3)
+    arch = MLPArch((1, 8, 8, 1), "tanh")
+    op = BatchedMLP(arch, x, y)
+    C, nmcmc = 6, 450
+    ini = np.stack([np.random.RandomState(700 + c).rand(arch.nparams) for c in range(C)])
+    eng = DeviceAMCMC(op, 0.2, gamma=0.1, t0=50, tadapt=100, seed=3)
+    captured = {}
+    orig = eng._accept
+
+    def spy(s, prop, sse, n):
+        captured['s'] = s
+        return orig(s, prop, sse, n)
+    eng._accept = spy
+    r = eng.run(nmcmc, ini)
+    s = captured['s']
+    chain = r['chain'].cpu().numpy()
+    hist, mult, kcur, sumx = (s[k].cpu().numpy() for k in ('hist', 'mult', 'kcur', 'sumx'))
+    for c in range(C):
+        moved = (chain[c, 1:] != chain[c, :-1]).any(axis=1)
+        K = 1 + int(moved.sum())
+        assert kcur[c] == K - 1
+        idx = np.concatenate([[0], 1 + np.nonzero(moved)[0]])                # first occurrence of each distinct state
+        np.testing.assert_allclose(hist[c, :K, :arch.nparams], (chain[c, idx] - chain[c, 0]).astype(np.float32),
+                                   rtol=0, atol=0)
+        runs = np.diff(np.concatenate([idx, [nmcmc + 1]]))
+        assert np.array_equal(mult[c, :K], runs) and mult[c, :K].sum() == nmcmc + 1
+        np.testing.assert_allclose(sumx[c], (chain[c] - chain[c, 0]).sum(axis=0), rtol=1e-10, atol=1e-10)
+
+
 def test_device_engine_matches_host_sampler_in_distribution():
     x, y = _problem(1)
     torch.manual_seed(1)
