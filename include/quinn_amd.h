@@ -162,6 +162,21 @@ int qn_mcmc_propose_hist(const double* cur, const float* hist, const float* wsna
                          const double* msnap, double s_lr, double s_iso, int C, int64_t p, int64_t pstride,
                          int kcap, uint64_t seed, const int64_t* step_ptr, double* out, void* stream);
 
+/* The same draw for qn_mcmc_hist_block_steps() (= 32) consecutive steps in one pass over the stored states:
+ * the increment of step t depends only on the frozen snapshot and on that step's random numbers (keyed
+ * by the absolute step, exactly as in qn_mcmc_propose_hist), not on the chain's state, so
+ *   delta[c, t, :] = s_lr * sum_k wsnap[c,k] u_k^(step0+t) (hist[c,k,:] - msnap[c,:])
+ * for t = 0..31 reads the history once: HBM traffic per step / 32, a (32 x K).(K x p) product per chain
+ * (float32 accumulation).  coef: scratch of C * (ceil4(kcap) + 1) * 32 float32; delta: [C, 32, p] float64.
+ * qn_mcmc_apply_delta: out[c,:] = cur[c,:] + delta[c, t, :] + s_iso * v (the proposal of step step0 + t; v on the
+ * stream of the CURRENT step *step_ptr, as in qn_mcmc_propose_hist; s_iso is unused by the block call). */
+int qn_mcmc_hist_block_steps(void);
+int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap, const int32_t* ksnap, const double* msnap,
+                               double s_lr, double s_iso, int C, int64_t p, int64_t pstride, int kcap,
+                               uint64_t seed, int64_t step0, float* coef, double* delta, void* stream);
+int qn_mcmc_apply_delta(const double* cur, const double* delta, int t, double s_iso, int C, int64_t p, uint64_t seed,
+                        const int64_t* step_ptr, double* out, void* stream);
+
 /* Diagnostic: y[i] = device tanh(x[i]) in float64 (the activation used by every kernel). */
 int qn_debug_tanh(const double* x, double* y, int64_t n, void* stream);
 /* Diagnostic: the variant the fused kernels use when all weights and inputs are finite and bounded

@@ -149,6 +149,136 @@ __global__ __launch_bounds__(BLK) void k_propose_hist(HistArgs a, const double* 
     if (j + 1 < a.p) out[e0 + 1] = cur[e0 + 1] + a.s_lr * (acc1 - sA * msnap[e0 + 1]) + a.s_iso * zb;
 }
 
+// ---- the same draw for TB consecutive steps at once.  delta_t does not depend on the chain's state, only on
+// the frozen snapshot and on the step's random numbers, so the increments of the next TB steps can be formed
+// in ONE pass over the stored states: HBM traffic per step drops by TB and the kernel becomes a small
+// (TB x K) . (K x p) product per chain.  Random numbers are keyed by the absolute step exactly as in
+// k_propose_hist, so the increments do not depend on how steps are grouped.
+constexpr int TB = 32;           // steps per block
+constexpr int KB2 = 128;         // history rows per LDS chunk of coefficients
+struct HistBlockArgs {
+    int C, kcap, kstride;        // coef [C][kstride][TB] (step fastest)
+    int64_t p, pstride, step0;
+    double s_lr, s_iso;
+    uint64_t seed;
+};
+// coef[c][k][t] = sqrt(w_k) * u_k^(step0 + t)
+__global__ __launch_bounds__(BLK) void k_hist_coef(HistBlockArgs a, const float* __restrict__ wsnap,
+                                                   const int32_t* __restrict__ ksnap, float* __restrict__ coef) {
+    const int b = blockIdx.z, t = blockIdx.y;
+    const int K = ksnap[b] < a.kcap ? ksnap[b] : a.kcap;
+    const int kk = 2 * (blockIdx.x * BLK + threadIdx.x);
+    if (kk >= K) return;
+    const uint64_t kpairs = ((uint64_t)a.kcap + 1) / 2;
+    Philox ph;
+    ph.gen(a.seed, 2 * (uint64_t)(a.step0 + t) + 1, 2 * (uint64_t)a.C + (uint64_t)b * kpairs + (uint64_t)(kk >> 1));
+    double za, zb;
+    normal2(ph, za, zb);
+    float* cb = coef + (int64_t)b * a.kstride * TB;
+    cb[(int64_t)kk * TB + t] = wsnap[(int64_t)b * a.kcap + kk] * (float)za;
+    if (kk + 1 < K) cb[(int64_t)(kk + 1) * TB + t] = wsnap[(int64_t)b * a.kcap + kk + 1] * (float)zb;
+}
+// csum[c][t] = sum_k coef[c][k][t]   (one block per chain, fixed order)
+__global__ __launch_bounds__(BLK) void k_hist_coef_sum(HistBlockArgs a, const float* __restrict__ coef,
+                                                       const int32_t* __restrict__ ksnap, float* __restrict__ csum) {
+    __shared__ float part[BLK / TB][TB];
+    const int b = blockIdx.x, t = threadIdx.x % TB, g = threadIdx.x / TB;
+    const int K = ksnap[b] < a.kcap ? ksnap[b] : a.kcap;
+    const float* cb = coef + (int64_t)b * a.kstride * TB;
+    float sacc = 0.f;
+    for (int k = g; k < K; k += BLK / TB) sacc += cb[(int64_t)k * TB + t];
+    part[g][t] = sacc;
+    __syncthreads();
+    if (threadIdx.x < TB) {
+        float tot = 0.f;
+        for (int q = 0; q < BLK / TB; ++q) tot += part[q][threadIdx.x];
+        csum[(int64_t)b * TB + threadIdx.x] = tot;
+    }
+}
+// delta[c][t][:] = s_lr * (sum_k coef[c][k][t] hist[c][k][:] - csum[c][t] mean[c][:])   (the isotropic part is
+// added per step by k_apply_delta).  2 columns per thread held as one packed float pair per step: the inner
+// loop is TB v_pk_fma_f32 per history row, coefficients broadcast from LDS.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(BLK, 2) void k_hist_block(HistBlockArgs a, const float* __restrict__ hist,
+                                                       const float* __restrict__ coef, const float* __restrict__ csum,
+                                                       const int32_t* __restrict__ ksnap,
+                                                       const double* __restrict__ msnap, double* __restrict__ delta) {
+    __shared__ __attribute__((aligned(16))) float cs[KB2 * TB];
+    const int b = blockIdx.y;
+    const int K = ksnap[b] < a.kcap ? ksnap[b] : a.kcap;
+    const int64_t j = 2 * ((int64_t)blockIdx.x * BLK + threadIdx.x);
+    const bool live = j < a.p;
+    const float* hcol = hist + (int64_t)b * a.kcap * a.pstride + (live ? j : 0);
+    const float* cb = coef + (int64_t)b * a.kstride * TB;
+    v2f acc[TB];
+#pragma unroll
+    for (int t = 0; t < TB; ++t) acc[t] = (v2f){0.f, 0.f};
+    constexpr int RG = 8;
+    for (int k0 = 0; k0 < K; k0 += KB2) {
+        const int kn = K - k0 < KB2 ? K - k0 : KB2;
+        const int knp = (kn + RG - 1) / RG * RG;                           // rows padded to a group: zero coefficients
+        for (int e = threadIdx.x * 4; e < knp * TB; e += BLK * 4)          // contiguous [kn][TB] floats
+            *reinterpret_cast<float4*>(cs + e) = e < kn * TB ? *reinterpret_cast<const float4*>(cb + (int64_t)k0 * TB + e)
+                                                             : (float4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        const float* h = hcol + (int64_t)k0 * a.pstride;
+        // rows in groups of RG: the next group's RG loads (8 B per lane each) are in flight while the current
+        // group is multiplied -- one row ahead keeps far too few bytes in flight to stream from HBM
+        v2f hn[RG];
+#pragma unroll
+        for (int u = 0; u < RG; ++u) hn[u] = u < kn ? *reinterpret_cast<const v2f*>(h + (int64_t)u * a.pstride) : (v2f){0.f, 0.f};
+        for (int kk = 0; kk < kn; kk += RG) {
+            v2f hv[RG];
+#pragma unroll
+            for (int u = 0; u < RG; ++u) hv[u] = hn[u];
+#pragma unroll
+            for (int u = 0; u < RG; ++u)
+                hn[u] = kk + RG + u < kn ? *reinterpret_cast<const v2f*>(h + (int64_t)(kk + RG + u) * a.pstride)
+                                         : (v2f){0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < RG; ++u) {                                  // rows >= kn: zero row times zero coefficients
+                const float4* c4 = reinterpret_cast<const float4*>(cs + (kk + u) * TB);
+#pragma unroll
+                for (int t4 = 0; t4 < TB / 4; ++t4) {
+                    const float4 cv = c4[t4];
+                    acc[4 * t4 + 0] = __builtin_elementwise_fma((v2f){cv.x, cv.x}, hv[u], acc[4 * t4 + 0]);
+                    acc[4 * t4 + 1] = __builtin_elementwise_fma((v2f){cv.y, cv.y}, hv[u], acc[4 * t4 + 1]);
+                    acc[4 * t4 + 2] = __builtin_elementwise_fma((v2f){cv.z, cv.z}, hv[u], acc[4 * t4 + 2]);
+                    acc[4 * t4 + 3] = __builtin_elementwise_fma((v2f){cv.w, cv.w}, hv[u], acc[4 * t4 + 3]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!live) return;
+    const double m0 = msnap[(int64_t)b * a.p + j], m1 = j + 1 < a.p ? msnap[(int64_t)b * a.p + j + 1] : 0.0;
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+        const double sA = (double)csum[(int64_t)b * TB + t];
+        double* d = delta + ((int64_t)b * TB + t) * a.p + j;
+        d[0] = a.s_lr * ((double)acc[t].x - sA * m0);
+        if (j + 1 < a.p) d[1] = a.s_lr * ((double)acc[t].y - sA * m1);
+    }
+}
+// out[c][:] = cur[c][:] + delta[c][t][:] + s_iso * v,  v ~ N(0, I) on the stream of the current step
+__global__ __launch_bounds__(BLK) void k_apply_delta(const double* __restrict__ cur, const double* __restrict__ delta,
+                                                     int t, int64_t p, double s_iso, uint64_t seed,
+                                                     const int64_t* __restrict__ step_ptr, double* __restrict__ out) {
+    const int b = blockIdx.y;
+    const uint64_t step = (uint64_t)*step_ptr;
+    const int64_t jp = (int64_t)blockIdx.x * BLK + threadIdx.x;       // column pair
+    const int64_t j = 2 * jp;
+    if (j >= p) return;
+    Philox ph;
+    ph.gen(seed, 2 * step, (uint64_t)b * (uint64_t)((p + 1) / 2) + (uint64_t)jp);
+    double za, zb;
+    normal2(ph, za, zb);
+    const double* d = delta + ((int64_t)b * TB + t) * p + j;
+    const int64_t e0 = (int64_t)b * p + j;
+    out[e0] = cur[e0] + d[0] + s_iso * za;
+    if (j + 1 < p) out[e0 + 1] = cur[e0 + 1] + d[1] + s_iso * zb;
+}
+
 struct AcceptArgs {
     double half_inv_sig2, lp_const;       // log-posterior = -(half_inv_sig2 * sse + lp_const)
     int C, nmcmc, kcap;
@@ -257,6 +387,45 @@ extern "C" int qn_mcmc_propose_hist(const double* cur, const float* hist, const 
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_propose_hist, dim3(gx, C), dim3(BLK), 0, static_cast<hipStream_t>(stream), a, cur, hist, wsnap,
                        ksnap, msnap, step_ptr, out);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
+
+extern "C" int qn_mcmc_hist_block_steps(void) { return TB; }
+
+extern "C" int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap, const int32_t* ksnap,
+                                          const double* msnap, double s_lr, double s_iso, int C, int64_t p,
+                                          int64_t pstride, int kcap, uint64_t seed, int64_t step0, float* coef,
+                                          double* delta, void* stream) {
+    if (!hist || !wsnap || !ksnap || !msnap || !coef || !delta || C <= 0 || C > 65535 || p <= 0 || kcap <= 0 ||
+        pstride < p || (pstride & 1) || step0 < 0) {
+        qn_set_error("qn_mcmc_propose_hist_block: bad argument (pstride must be even and >= p)");
+        return QN_EINVAL;
+    }
+    HistBlockArgs a;
+    a.C = C; a.kcap = kcap; a.kstride = (kcap + 3) / 4 * 4; a.p = p; a.pstride = pstride; a.step0 = step0;
+    a.s_lr = s_lr; a.s_iso = s_iso; a.seed = seed;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_hist_coef, dim3(((kcap + 1) / 2 + BLK - 1) / BLK, TB, C), dim3(BLK), 0, st, a, wsnap, ksnap,
+                       coef);
+    float* csum = coef + (int64_t)C * a.kstride * TB;                  // [C][TB] behind the coefficients
+    hipLaunchKernelGGL(k_hist_coef_sum, dim3(C), dim3(BLK), 0, st, a, (const float*)coef, ksnap, csum);
+    hipLaunchKernelGGL(k_hist_block, dim3((int)(((p + 1) / 2 + BLK - 1) / BLK), C), dim3(BLK), 0, st, a, hist,
+                       (const float*)coef, (const float*)csum, ksnap, msnap, delta);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
+
+extern "C" int qn_mcmc_apply_delta(const double* cur, const double* delta, int t, double s_iso, int C, int64_t p,
+                                   uint64_t seed, const int64_t* step_ptr, double* out, void* stream) {
+    if (!cur || !delta || !out || !step_ptr || t < 0 || t >= TB || C <= 0 || C > 65535 || p <= 0) {
+        qn_set_error("qn_mcmc_apply_delta: bad argument");
+        return QN_EINVAL;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_apply_delta, dim3((int)(((p + 1) / 2 + BLK - 1) / BLK), C), dim3(BLK), 0,
+                       static_cast<hipStream_t>(stream), cur, delta, t, p, s_iso, seed, step_ptr, out);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }

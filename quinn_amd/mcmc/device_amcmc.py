@@ -21,7 +21,11 @@ proposal's ingredients and the chain history in HBM and never synchronises with 
     `qn_mcmc_accept` appends a row per accepted move and counts multiplicities) and a proposal is a
     K x p GEMV over them: at cfg2 K ~ 10^2..10^3 rows of 34 KB per chain and step, where a p x p factor
     is 290-580 MB per chain and step plus an O(p^3) factorisation per adaptation.  An adaptation is a
-    snapshot of (K, sqrt(w), mean): a few elementwise torch ops, no SYRK, no Cholesky.
+    snapshot of (K, sqrt(w), mean): a few elementwise torch ops, no SYRK, no Cholesky;
+  * delta does not depend on the chain's state, only on the frozen snapshot and the step's random
+    numbers, so the increments of the next 32 steps are formed in ONE pass over the history
+    (`qn_mcmc_propose_hist_block`: a (32 x K).(K x p) product per chain, HBM traffic per step / 32) and
+    a step's proposal is `cur + delta[t]`.
 
 Same target distribution and the same adaptation schedule as the reference; the random streams
 differ (Philox instead of numpy MT19937, sample-space draw instead of an SVD factor), so chains agree
@@ -67,6 +71,19 @@ class DeviceAMCMC:
             snap['mean'].data_ptr(), snap['s_lr'], snap['s_iso'], C, p, s['hist'].shape[2], s['hist'].shape[1],
             self.seed, s['step'].data_ptr(), out.data_ptr(), self._stream()), "qn_mcmc_propose_hist")
 
+    def _propose_hist_block(self, s, snap, step0, coef, delta):
+        C, _, p = delta.shape
+        _lib.check(self._L.qn_mcmc_propose_hist_block(
+            s['hist'].data_ptr(), snap['w'].data_ptr(), snap['k'].data_ptr(), snap['mean'].data_ptr(), snap['s_lr'],
+            snap['s_iso'], C, p, s['hist'].shape[2], s['hist'].shape[1], self.seed, int(step0), coef.data_ptr(),
+            delta.data_ptr(), self._stream()), "qn_mcmc_propose_hist_block")
+
+    def _apply_delta(self, s, snap, delta, t, out):
+        C, p = out.shape
+        _lib.check(self._L.qn_mcmc_apply_delta(s['cur'].data_ptr(), delta.data_ptr(), int(t), snap['s_iso'], C, p,
+                                               self.seed, s['step'].data_ptr(), out.data_ptr(), self._stream()),
+                   "qn_mcmc_apply_delta")
+
     def _accept(self, s, prop, sse, nmcmc):
         C, p = prop.shape
         _lib.check(self._L.qn_mcmc_accept(
@@ -111,8 +128,21 @@ class DeviceAMCMC:
             state['L'] = torch.linalg.cholesky(torch.as_tensor(np.asarray(self.cov_ini), dtype=f64, device=dev))
             z = torch.empty(C, p, dtype=f64, device=dev)
 
-        def one_step():
-            if state['snap'] is not None:
+        TB = int(self._L.qn_mcmc_hist_block_steps())
+        blk = {'coef': None, 'delta': None, 'start': -1}
+
+        def one_step(i=None):
+            if state['snap'] is not None and i is not None:
+                # increments of TB consecutive steps in one pass over the history (they do not depend on the
+                # chain's state); blocks restart at every adaptation
+                if blk['coef'] is None:
+                    blk['coef'] = torch.empty(C * ((kcap + 3) // 4 * 4 + 1) * TB, dtype=torch.float32, device=dev)
+                    blk['delta'] = torch.empty(C, TB, p, dtype=f64, device=dev)
+                if blk['start'] < 0 or i - blk['start'] >= TB:
+                    self._propose_hist_block(s, state['snap'], i, blk['coef'], blk['delta'])
+                    blk['start'] = i
+                self._apply_delta(s, state['snap'], blk['delta'], i - blk['start'], prop)
+            elif state['snap'] is not None:                                 # graph capture: one step at a time
                 self._propose_hist(s, state['snap'], prop)
             elif state['L'] is not None:                                    # user-supplied initial covariance
                 self._propose(None, None, 0.0, s['step'], z)
@@ -153,14 +183,15 @@ class DeviceAMCMC:
                                  'mean': s['sumx'] / (i + 1), 's_lr': float(np.sqrt(scale / i)),
                                  's_iso': float(np.sqrt(scale * 1e-8))}
                 graph = None                                               # new snapshot tensors: recapture
+                blk['start'] = -1
             if self.use_graph and graph is None:
                 graph = make_graph()
             nrun = min(nmcmc, (i // self.tadapt + 1) * self.tadapt) - i     # up to the next adaptation
-            for _ in range(nrun):
+            for k in range(nrun):
                 if graph is not None:
                     graph.replay()
                 else:
-                    one_step()
+                    one_step(i + k)
             i += nrun
             if verbose:
                 print('%d / %d completed, acceptance rate %lg' % (i, nmcmc, float(s['nacc'].double().mean()) / i))

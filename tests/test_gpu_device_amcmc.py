@@ -85,6 +85,26 @@ def test_sample_space_proposal_kernel_covariance_and_history_tracking():
                                       mean.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, p,
                                       pstride, kcap, 1234, step.data_ptr(), out2.data_ptr(), None), "propose_hist")
     assert torch.equal(out, out2)
+    # the 32-step block kernel: same random numbers per absolute step (float32 accumulation), so its
+    # increment for step 17 equals the single-step kernel's up to rounding; and each step's covariance is right
+    TB = L.qn_mcmc_hist_block_steps()
+    coef = torch.empty(C * ((kcap + 3) // 4 * 4 + 1) * TB, dtype=torch.float32, device=dev)
+    delta = torch.empty(C, TB, p, dtype=torch.float64, device=dev)
+    _lib.check(L.qn_mcmc_propose_hist_block(hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(), mean.data_ptr(),
+                                            float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, p, pstride, kcap,
+                                            1234, 10, coef.data_ptr(), delta.data_ptr(), None), "propose_hist_block")
+    out3 = torch.empty_like(out)
+    _lib.check(L.qn_mcmc_apply_delta(cur.data_ptr(), delta.data_ptr(), 7, float(np.sqrt(c * 1e-8)), C, p, 1234,
+                                     step.data_ptr(), out3.data_ptr(), None), "apply_delta")
+    torch.cuda.synchronize()
+    scale = float(np.sqrt(np.diag(target).max()))
+    assert (out3 - out).abs().max().item() < 1e-4 * scale              # step 10 + 7 = 17, the step drawn above
+    dl = delta.cpu().numpy()
+    for t in (0, 13, TB - 1):                                            # (the 1e-8 isotropic floor is added per step)
+        assert np.abs(np.cov(dl[:, t].T) - target).max() < 0.05 * np.abs(target).max()
+    # different steps of a block are independent draws
+    cc = np.corrcoef(dl[:, 3, 0], dl[:, 4, 0])[0, 1]
+    assert abs(cc) < 0.03
 
 
 def test_history_of_distinct_states_matches_the_chain():
