@@ -7,7 +7,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 for kind in logpost grad; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d $out/${kind}_$c -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --kind $kind > $out/${kind}_$c.log 2>&1 || echo "pass $kind $c failed"
+    rocprofv3 --pmc $c --output-format csv -d $out/${kind}_$c -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --kind $kind > $out/${kind}_$c.log 2>&1 || echo "pass $kind $c failed"
   done
 done
 python3 tools/prof_traffic.py $out
