@@ -32,11 +32,13 @@ class _ViLoss(torch.autograd.Function):
     """viloss(theta) with the forward (and, when grad is enabled, the backward) on the HIP kernels."""
 
     @staticmethod
-    def forward(ctx, theta, bnet, x, y, nsam, datanoise, num_batches):
+    def forward(ctx, theta, bnet, x, y, nsam, datanoise, num_batches, grad_mode):
         p = bnet.p
         mu, rho = theta.detach()[:p], theta.detach()[p:]
         eps = bnet._draw_eps(nsam)
-        need_grad = bool(ctx.needs_input_grad[0])     # grad mode is off inside forward()
+        # grad mode is off inside forward() and needs_input_grad ignores torch.no_grad(): the caller passes
+        # the mode it saw, so that the validation / full-train evaluations of nnfit (no_grad) stay forward-only
+        need_grad = bool(grad_mode and ctx.needs_input_grad[0])
         lp, lq, nll, W, gW = bnet._elbo(mu, rho, eps, x, y, nsam, datanoise, need_grad)
         loss = (lq - lp) / num_batches + nll
         ctx.bnet, ctx.nsam, ctx.datanoise, ctx.num_batches = bnet, nsam, datanoise, num_batches
@@ -58,7 +60,7 @@ class _ViLoss(torch.autograd.Function):
             _lib.check(L.qn_vi_grad(mu.data_ptr(), rho.data_ptr(), eps.data_ptr(), gW.data_ptr(), ctx.nsam, p,
                                     bnet.pi, bnet.sigma1, bnet.sigma2, gw_scale, kl_scale, bnet.op.qdt,
                                     dtheta.data_ptr(), dtheta[p:].data_ptr(), st), "qn_vi_grad")
-        return dtheta * gout, None, None, None, None, None, None
+        return dtheta * gout, None, None, None, None, None, None, None
 
 
 class BNet(torch.nn.Module):
@@ -170,4 +172,5 @@ class BNet(torch.nn.Module):
         datanoise, nsam, num_batches = self.loss_params
         xt = torch.as_tensor(data, dtype=torch.float64, device=self.device)
         yt = torch.as_tensor(target, dtype=torch.float64, device=self.device)
-        return _ViLoss.apply(self.theta, self, xt, yt, int(nsam), float(datanoise), num_batches)
+        return _ViLoss.apply(self.theta, self, xt, yt, int(nsam), float(datanoise), num_batches,
+                             torch.is_grad_enabled())
