@@ -130,8 +130,10 @@ int qn_adam_batched(double* W, const void* G, double* m, double* v, const double
  * qn_mcmc_propose: out[c,:] = cur[c,:] + sd[c,:] * z + c1 * z0_c with z ~ N(0,I), z0_c ~ N(0,1)
  *   (the initial proposal covariance c1^2 + diag(sd^2) = 0.01 + diag(0.09|x0|), admcmc.py:65);
  *   with cur == NULL it writes the standard normals z themselves (input of a dense factor product).
- *   Random numbers: Philox4x32-10 keyed by (seed, step). */
-int qn_mcmc_propose(const double* cur, const double* sd, double c1, int C, int64_t p, uint64_t seed,
+ *   Random numbers: Philox4x32-10 keyed by (seed, step, GLOBAL chain id = chain0 + c, purpose, index): a
+ *   chain's draws do not depend on how the chains are split over launches or ranks (every qn_mcmc_* call
+ *   takes chain0, the global id of its first chain). */
+int qn_mcmc_propose(const double* cur, const double* sd, double c1, int C, int chain0, int64_t p, uint64_t seed,
                     const int64_t* step_ptr, double* out, void* stream);
 
 /* qn_mcmc_accept: for every chain c: log-posterior of the proposal from its SSE,
@@ -143,7 +145,7 @@ int qn_mcmc_propose(const double* cur, const double* sd, double c1, int C, int64
  *   (row 0 = the start, a new row per accepted move), mult [C, kcap] their multiplicities in the
  *   chain so far, kcur [C] the index of the current state's row, sumx [C, p] the running sum of
  *   (x_i - x0) over all samples.  kcur[c] >= kcap means the history is full (rows are not stored). */
-int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int64_t p,
+int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int chain0, int64_t p,
                    int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
                    double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0, float* hist,
                    int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride, int64_t* step_ptr,
@@ -159,7 +161,7 @@ int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int
  *   rows of 34 KB per chain and step instead of 290-580 MB).  ksnap [C] = K per chain, msnap [C, p] =
  *   mean of (x - x0) at the adaptation, both frozen until the next adaptation.  pstride even, >= p. */
 int qn_mcmc_propose_hist(const double* cur, const float* hist, const float* wsnap, const int32_t* ksnap,
-                         const double* msnap, double s_lr, double s_iso, int C, int64_t p, int64_t pstride,
+                         const double* msnap, double s_lr, double s_iso, int C, int chain0, int64_t p, int64_t pstride,
                          int kcap, uint64_t seed, const int64_t* step_ptr, double* out, void* stream);
 
 /* The same draw for qn_mcmc_hist_block_steps() (= 32) consecutive steps in one pass over the stored states:
@@ -172,10 +174,10 @@ int qn_mcmc_propose_hist(const double* cur, const float* hist, const float* wsna
  * stream of the CURRENT step *step_ptr, as in qn_mcmc_propose_hist; s_iso is unused by the block call). */
 int qn_mcmc_hist_block_steps(void);
 int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap, const int32_t* ksnap, const double* msnap,
-                               double s_lr, double s_iso, int C, int64_t p, int64_t pstride, int kcap,
+                               double s_lr, double s_iso, int C, int chain0, int64_t p, int64_t pstride, int kcap,
                                uint64_t seed, int64_t step0, float* coef, double* delta, void* stream);
-int qn_mcmc_apply_delta(const double* cur, const double* delta, int t, double s_iso, int C, int64_t p, uint64_t seed,
-                        const int64_t* step_ptr, double* out, void* stream);
+int qn_mcmc_apply_delta(const double* cur, const double* delta, int t, double s_iso, int C, int chain0, int64_t p,
+                        uint64_t seed, const int64_t* step_ptr, double* out, void* stream);
 
 /* Diagnostic: y[i] = device tanh(x[i]) in float64 (the activation used by every kernel). */
 int qn_debug_tanh(const double* x, double* y, int64_t n, void* stream);

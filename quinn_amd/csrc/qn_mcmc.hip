@@ -31,6 +31,14 @@ struct Philox {
     }
 };
 
+// Philox counter of one draw: [global chain id : 24][purpose : 4][index : 36].  The chain id is GLOBAL
+// (chain0 + local index), so a chain's random numbers do not depend on how chains are split over launches /
+// ranks.  purposes: 0 elementwise normals (index = column pair), 1 per-chain scalar normal, 2 accept uniform,
+// 3 history coefficients (index = row pair)
+__device__ __forceinline__ uint64_t ctr_of(int chain, int purpose, uint64_t index) {
+    return ((uint64_t)chain << 40) | ((uint64_t)purpose << 36) | (index & 0xFFFFFFFFFull);
+}
+
 // uniform in (0, 1) with 53 random bits
 __device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {
     const uint64_t bits = ((uint64_t)hi << 21) ^ (uint64_t)(lo >> 11);        // 53 bits
@@ -49,21 +57,21 @@ __device__ __forceinline__ void normal2(const Philox& ph, double& a, double& b) 
 
 // stream ids: 2*step -> elementwise normals, 2*step+1 -> per-chain scalars (z0, uniform)
 __global__ __launch_bounds__(BLK) void k_propose(const double* __restrict__ cur, const double* __restrict__ sd,
-                                                 double c1, int C, int64_t p, uint64_t seed,
+                                                 double c1, int chain0, int64_t p, uint64_t seed,
                                                  const int64_t* __restrict__ step_ptr, double* __restrict__ out) {
     const int b = blockIdx.y;
     const uint64_t step = (uint64_t)*step_ptr;
     double z0 = 0.0;
     if (c1 != 0.0) {
         Philox ph;
-        ph.gen(seed, 2 * step + 1, (uint64_t)b);
+        ph.gen(seed, 2 * step + 1, ctr_of(chain0 + b, 1, 0));
         double dummy;
         normal2(ph, z0, dummy);
     }
     const int64_t npair = (p + 1) / 2;
     for (int64_t j = (int64_t)blockIdx.x * BLK + threadIdx.x; j < npair; j += (int64_t)gridDim.x * BLK) {
         Philox ph;
-        ph.gen(seed, 2 * step, (uint64_t)b * npair + j);
+        ph.gen(seed, 2 * step, ctr_of(chain0 + b, 0, (uint64_t)j));
         double za, zb;
         normal2(ph, za, zb);
         const int64_t e0 = (int64_t)b * p + 2 * j;
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(BLK) void k_propose(const double* __restrict__ cur,
 // the coefficients sqrt(w_k) u_k are generated per block into LDS, KC at a time.
 constexpr int KC = 2048;
 struct HistArgs {
-    int C, kcap;
+    int chain0, kcap;
     int64_t p, pstride;
     double s_lr, s_iso;
     uint64_t seed;
@@ -104,13 +112,12 @@ __global__ __launch_bounds__(BLK) void k_propose_hist(HistArgs a, const double* 
     const bool live = j < a.p;
     const float* hcol = hist + (int64_t)b * a.kcap * a.pstride + (live ? j : 0);
     const float* wrow = wsnap + (int64_t)b * a.kcap;
-    const uint64_t kpairs = ((uint64_t)a.kcap + 1) / 2;
     double acc0 = 0.0, acc1 = 0.0, sA = 0.0;
     for (int k0 = 0; k0 < K; k0 += KC) {
         const int kn = K - k0 < KC ? K - k0 : KC;
         for (int kk = 2 * threadIdx.x; kk < kn; kk += 2 * BLK) {
             Philox ph;
-            ph.gen(a.seed, 2 * step + 1, 2 * (uint64_t)a.C + (uint64_t)b * kpairs + (uint64_t)((k0 + kk) >> 1));
+            ph.gen(a.seed, 2 * step + 1, ctr_of(a.chain0 + b, 3, (uint64_t)((k0 + kk) >> 1)));
             double za, zb;
             normal2(ph, za, zb);
             coef[kk] = wrow[k0 + kk] * (float)za;
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(BLK) void k_propose_hist(HistArgs a, const double* 
     }
     if (!live) return;
     Philox ph;
-    ph.gen(a.seed, 2 * step, (uint64_t)b * (uint64_t)((a.p + 1) / 2) + (uint64_t)(j >> 1));
+    ph.gen(a.seed, 2 * step, ctr_of(a.chain0 + b, 0, (uint64_t)(j >> 1)));
     double za, zb;
     normal2(ph, za, zb);
     const int64_t e0 = (int64_t)b * a.p + j;
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(BLK) void k_propose_hist(HistArgs a, const double* 
 constexpr int TB = 32;           // steps per block
 constexpr int KB2 = 128;         // history rows per LDS chunk of coefficients
 struct HistBlockArgs {
-    int C, kcap, kstride;        // coef [C][kstride][TB] (step fastest)
+    int chain0, kcap, kstride;   // coef [C][kstride][TB] (step fastest)
     int64_t p, pstride, step0;
     double s_lr, s_iso;
     uint64_t seed;
@@ -169,9 +176,8 @@ __global__ __launch_bounds__(BLK) void k_hist_coef(HistBlockArgs a, const float*
     const int K = ksnap[b] < a.kcap ? ksnap[b] : a.kcap;
     const int kk = 2 * (blockIdx.x * BLK + threadIdx.x);
     if (kk >= K) return;
-    const uint64_t kpairs = ((uint64_t)a.kcap + 1) / 2;
     Philox ph;
-    ph.gen(a.seed, 2 * (uint64_t)(a.step0 + t) + 1, 2 * (uint64_t)a.C + (uint64_t)b * kpairs + (uint64_t)(kk >> 1));
+    ph.gen(a.seed, 2 * (uint64_t)(a.step0 + t) + 1, ctr_of(a.chain0 + b, 3, (uint64_t)(kk >> 1)));
     double za, zb;
     normal2(ph, za, zb);
     float* cb = coef + (int64_t)b * a.kstride * TB;
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(BLK, 2) void k_hist_block(HistBlockArgs a, const fl
 }
 // out[c][:] = cur[c][:] + delta[c][t][:] + s_iso * v,  v ~ N(0, I) on the stream of the current step
 __global__ __launch_bounds__(BLK) void k_apply_delta(const double* __restrict__ cur, const double* __restrict__ delta,
-                                                     int t, int64_t p, double s_iso, uint64_t seed,
+                                                     int t, int chain0, int64_t p, double s_iso, uint64_t seed,
                                                      const int64_t* __restrict__ step_ptr, double* __restrict__ out) {
     const int b = blockIdx.y;
     const uint64_t step = (uint64_t)*step_ptr;
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(BLK) void k_apply_delta(const double* __restrict__ 
     const int64_t j = 2 * jp;
     if (j >= p) return;
     Philox ph;
-    ph.gen(seed, 2 * step, (uint64_t)b * (uint64_t)((p + 1) / 2) + (uint64_t)jp);
+    ph.gen(seed, 2 * step, ctr_of(chain0 + b, 0, (uint64_t)jp));
     double za, zb;
     normal2(ph, za, zb);
     const double* d = delta + ((int64_t)b * TB + t) * p + j;
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(BLK) void k_apply_delta(const double* __restrict__ 
 
 struct AcceptArgs {
     double half_inv_sig2, lp_const;       // log-posterior = -(half_inv_sig2 * sse + lp_const)
-    int C, nmcmc, kcap;
+    int chain0, nmcmc, kcap;
     int64_t p, pstride;
     uint64_t seed;
 };
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(BLK) void k_accept(AcceptArgs a, const double* __re
     const double clp = cur_lp[b];
     const double mh = exp(plp - clp);                               // exp(current_U - proposed_U), mcmc.py:69-72
     Philox ph;
-    ph.gen(a.seed, 2 * (uint64_t)step + 1, (uint64_t)a.C + b);
+    ph.gen(a.seed, 2 * (uint64_t)step + 1, ctr_of(a.chain0 + b, 2, 0));
     const double u = u01(ph.c[0], ph.c[1]);
     const bool take = u < mh;                                       // NaN -> reject, inf -> accept, as `u < mh_prob`
     const double nlp = take ? plp : clp;
@@ -357,32 +363,32 @@ __global__ __launch_bounds__(BLK) void k_accept(AcceptArgs a, const double* __re
 
 }  // namespace
 
-extern "C" int qn_mcmc_propose(const double* cur, const double* sd, double c1, int C, int64_t p, uint64_t seed,
-                               const int64_t* step_ptr, double* out, void* stream) {
-    if (!out || !step_ptr || C <= 0 || p <= 0 || C > 65535 || (cur && !sd)) {
+extern "C" int qn_mcmc_propose(const double* cur, const double* sd, double c1, int C, int chain0, int64_t p,
+                               uint64_t seed, const int64_t* step_ptr, double* out, void* stream) {
+    if (!out || !step_ptr || C <= 0 || p <= 0 || C > 65535 || chain0 < 0 || (cur && !sd)) {
         qn_set_error("qn_mcmc_propose: bad argument");
         return QN_EINVAL;
     }
     int gx = (int)(((p + 1) / 2 + BLK - 1) / BLK);
     if (gx > 64) gx = 64;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_propose, dim3(gx, C), dim3(BLK), 0, static_cast<hipStream_t>(stream), cur, sd, c1, C, p, seed,
-                       step_ptr, out);
+    hipLaunchKernelGGL(k_propose, dim3(gx, C), dim3(BLK), 0, static_cast<hipStream_t>(stream), cur, sd, c1, chain0, p,
+                       seed, step_ptr, out);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }
 
 extern "C" int qn_mcmc_propose_hist(const double* cur, const float* hist, const float* wsnap, const int32_t* ksnap,
-                                    const double* msnap, double s_lr, double s_iso, int C, int64_t p,
+                                    const double* msnap, double s_lr, double s_iso, int C, int chain0, int64_t p,
                                     int64_t pstride, int kcap, uint64_t seed, const int64_t* step_ptr, double* out,
                                     void* stream) {
-    if (!cur || !hist || !wsnap || !ksnap || !msnap || !step_ptr || !out || C <= 0 || C > 65535 || p <= 0 ||
+    if (!cur || !hist || !wsnap || !ksnap || !msnap || !step_ptr || !out || C <= 0 || C > 65535 || chain0 < 0 || p <= 0 ||
         kcap <= 0 || pstride < p || (pstride & 1)) {
         qn_set_error("qn_mcmc_propose_hist: bad argument (pstride must be even and >= p)");
         return QN_EINVAL;
     }
     HistArgs a;
-    a.C = C; a.kcap = kcap; a.p = p; a.pstride = pstride; a.s_lr = s_lr; a.s_iso = s_iso; a.seed = seed;
+    a.chain0 = chain0; a.kcap = kcap; a.p = p; a.pstride = pstride; a.s_lr = s_lr; a.s_iso = s_iso; a.seed = seed;
     const int gx = (int)(((p + 1) / 2 + BLK - 1) / BLK);
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_propose_hist, dim3(gx, C), dim3(BLK), 0, static_cast<hipStream_t>(stream), a, cur, hist, wsnap,
@@ -394,16 +400,16 @@ extern "C" int qn_mcmc_propose_hist(const double* cur, const float* hist, const 
 extern "C" int qn_mcmc_hist_block_steps(void) { return TB; }
 
 extern "C" int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap, const int32_t* ksnap,
-                                          const double* msnap, double s_lr, double s_iso, int C, int64_t p,
-                                          int64_t pstride, int kcap, uint64_t seed, int64_t step0, float* coef,
-                                          double* delta, void* stream) {
-    if (!hist || !wsnap || !ksnap || !msnap || !coef || !delta || C <= 0 || C > 65535 || p <= 0 || kcap <= 0 ||
+                                          const double* msnap, double s_lr, double s_iso, int C, int chain0,
+                                          int64_t p, int64_t pstride, int kcap, uint64_t seed, int64_t step0,
+                                          float* coef, double* delta, void* stream) {
+    if (!hist || !wsnap || !ksnap || !msnap || !coef || !delta || C <= 0 || C > 65535 || chain0 < 0 || p <= 0 || kcap <= 0 ||
         pstride < p || (pstride & 1) || step0 < 0) {
         qn_set_error("qn_mcmc_propose_hist_block: bad argument (pstride must be even and >= p)");
         return QN_EINVAL;
     }
     HistBlockArgs a;
-    a.C = C; a.kcap = kcap; a.kstride = (kcap + 3) / 4 * 4; a.p = p; a.pstride = pstride; a.step0 = step0;
+    a.chain0 = chain0; a.kcap = kcap; a.kstride = (kcap + 3) / 4 * 4; a.p = p; a.pstride = pstride; a.step0 = step0;
     a.s_lr = s_lr; a.s_iso = s_iso; a.seed = seed;
     hipStream_t st = static_cast<hipStream_t>(stream);
     (void)hipGetLastError();
@@ -417,33 +423,33 @@ extern "C" int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap,
     return QN_OK;
 }
 
-extern "C" int qn_mcmc_apply_delta(const double* cur, const double* delta, int t, double s_iso, int C, int64_t p,
-                                   uint64_t seed, const int64_t* step_ptr, double* out, void* stream) {
-    if (!cur || !delta || !out || !step_ptr || t < 0 || t >= TB || C <= 0 || C > 65535 || p <= 0) {
+extern "C" int qn_mcmc_apply_delta(const double* cur, const double* delta, int t, double s_iso, int C, int chain0,
+                                   int64_t p, uint64_t seed, const int64_t* step_ptr, double* out, void* stream) {
+    if (!cur || !delta || !out || !step_ptr || t < 0 || t >= TB || C <= 0 || C > 65535 || chain0 < 0 || p <= 0) {
         qn_set_error("qn_mcmc_apply_delta: bad argument");
         return QN_EINVAL;
     }
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_apply_delta, dim3((int)(((p + 1) / 2 + BLK - 1) / BLK), C), dim3(BLK), 0,
-                       static_cast<hipStream_t>(stream), cur, delta, t, p, s_iso, seed, step_ptr, out);
+                       static_cast<hipStream_t>(stream), cur, delta, t, chain0, p, s_iso, seed, step_ptr, out);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }
 
-extern "C" int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int64_t p,
-                              int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
+extern "C" int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int chain0,
+                              int64_t p, int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
                               double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0,
                               float* hist, int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride,
                               int64_t* step_ptr, void* stream) {
     if (!prop || !sse_prop || !cur || !cur_lp || !best || !best_lp || !lps || !alphas || !nacc || !step_ptr ||
-        C <= 0 || p <= 0 || sigma <= 0.0 || (hist && (!x0 || !mult || !kcur || !sumx || kcap <= 0 || pstride < p))) {
+        C <= 0 || chain0 < 0 || p <= 0 || sigma <= 0.0 || (hist && (!x0 || !mult || !kcur || !sumx || kcap <= 0 || pstride < p))) {
         qn_set_error("qn_mcmc_accept: bad argument");
         return QN_EINVAL;
     }
     AcceptArgs a;
     a.half_inv_sig2 = 0.5 / (sigma * sigma);
     a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
-    a.C = C; a.nmcmc = nmcmc; a.kcap = kcap; a.p = p; a.pstride = pstride; a.seed = seed;
+    a.chain0 = chain0; a.nmcmc = nmcmc; a.kcap = kcap; a.p = p; a.pstride = pstride; a.seed = seed;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_accept, dim3(C), dim3(BLK), 0, static_cast<hipStream_t>(stream), a, prop, sse_prop, cur, cur_lp,
                        best, best_lp, chain, lps, alphas, nacc, x0, hist, mult, kcur, sumx, step_ptr);

@@ -42,7 +42,7 @@ from ..ops import BatchedMLP
 
 class DeviceAMCMC:
     def __init__(self, op: BatchedMLP, sigma, gamma=0.1, t0=100, tadapt=1000, cov_ini=None, seed=0,
-                 use_graph=False, max_history_bytes=64 << 30):
+                 use_graph=False, max_history_bytes=64 << 30, chain0=0):
         if op.dtype != "float64":
             raise NotImplementedError("the device AMCMC engine runs the float64 operator")
         self.op, self.sigma = op, float(sigma)
@@ -52,6 +52,7 @@ class DeviceAMCMC:
         self.seed = int(seed) & (2 ** 63 - 1)
         self.use_graph = use_graph
         self.max_history_bytes = int(max_history_bytes)
+        self.chain0 = int(chain0)      # global id of this engine's first chain (random streams are keyed by it)
         self._L = _lib.lib()
 
     # -- kernel wrappers (enqueue on the current stream) ---------------------------------------------
@@ -61,33 +62,33 @@ class DeviceAMCMC:
     def _propose(self, cur, sd, c1, step_ptr, out):
         C, p = out.shape
         _lib.check(self._L.qn_mcmc_propose(cur.data_ptr() if cur is not None else None,
-                                           sd.data_ptr() if sd is not None else None, c1, C, p, self.seed,
+                                           sd.data_ptr() if sd is not None else None, c1, C, self.chain0, p, self.seed,
                                            step_ptr.data_ptr(), out.data_ptr(), self._stream()), "qn_mcmc_propose")
 
     def _propose_hist(self, s, snap, out):
         C, p = out.shape
         _lib.check(self._L.qn_mcmc_propose_hist(
             s['cur'].data_ptr(), s['hist'].data_ptr(), snap['w'].data_ptr(), snap['k'].data_ptr(),
-            snap['mean'].data_ptr(), snap['s_lr'], snap['s_iso'], C, p, s['hist'].shape[2], s['hist'].shape[1],
-            self.seed, s['step'].data_ptr(), out.data_ptr(), self._stream()), "qn_mcmc_propose_hist")
+            snap['mean'].data_ptr(), snap['s_lr'], snap['s_iso'], C, self.chain0, p, s['hist'].shape[2],
+            s['hist'].shape[1], self.seed, s['step'].data_ptr(), out.data_ptr(), self._stream()), "qn_mcmc_propose_hist")
 
     def _propose_hist_block(self, s, snap, step0, coef, delta):
         C, _, p = delta.shape
         _lib.check(self._L.qn_mcmc_propose_hist_block(
             s['hist'].data_ptr(), snap['w'].data_ptr(), snap['k'].data_ptr(), snap['mean'].data_ptr(), snap['s_lr'],
-            snap['s_iso'], C, p, s['hist'].shape[2], s['hist'].shape[1], self.seed, int(step0), coef.data_ptr(),
+            snap['s_iso'], C, self.chain0, p, s['hist'].shape[2], s['hist'].shape[1], self.seed, int(step0), coef.data_ptr(),
             delta.data_ptr(), self._stream()), "qn_mcmc_propose_hist_block")
 
     def _apply_delta(self, s, snap, delta, t, out):
         C, p = out.shape
-        _lib.check(self._L.qn_mcmc_apply_delta(s['cur'].data_ptr(), delta.data_ptr(), int(t), snap['s_iso'], C, p,
-                                               self.seed, s['step'].data_ptr(), out.data_ptr(), self._stream()),
+        _lib.check(self._L.qn_mcmc_apply_delta(s['cur'].data_ptr(), delta.data_ptr(), int(t), snap['s_iso'], C,
+                                               self.chain0, p, self.seed, s['step'].data_ptr(), out.data_ptr(), self._stream()),
                    "qn_mcmc_apply_delta")
 
     def _accept(self, s, prop, sse, nmcmc):
         C, p = prop.shape
         _lib.check(self._L.qn_mcmc_accept(
-            prop.data_ptr(), sse.data_ptr(), self.sigma, self.op.N, C, p, nmcmc, self.seed, s['cur'].data_ptr(),
+            prop.data_ptr(), sse.data_ptr(), self.sigma, self.op.N, C, self.chain0, p, nmcmc, self.seed, s['cur'].data_ptr(),
             s['cur_lp'].data_ptr(), s['best'].data_ptr(), s['best_lp'].data_ptr(),
             s['chain'].data_ptr() if s['chain'] is not None else None, s['lps'].data_ptr(), s['alphas'].data_ptr(),
             s['nacc'].data_ptr(), s['x0'].data_ptr(), s['hist'].data_ptr(), s['mult'].data_ptr(),

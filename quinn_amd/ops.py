@@ -282,7 +282,7 @@ class BatchedMLP:
         return self._ws
 
     def _chunk(self, B, Nb, want_grad):
-        bc = B
+        bc = min(B, 65535)                       # one chain per blockIdx.y / .z: the grid limit of the C ABI
         while bc > 1 and self.workspace_bytes(bc, Nb, want_grad) > self.max_ws:
             bc = (bc + 1) // 2
         return bc

@@ -19,7 +19,7 @@ from ..mcmc.admcmc import AMCMC
 from ..mcmc.hmc import HMC
 from ..mcmc.mala import MALA
 from ..ops import BatchedMLP, neg_log_post_from_sse
-from ..parallel import dist_info, run_chains_sharded
+from ..parallel import all_gather_rows, dist_info, run_chains_sharded, shard_bounds
 from .quinn import QUiNNBase
 
 
@@ -124,18 +124,32 @@ class NN_MCMC(QUiNNBase):
         sampler_params = dict(sampler_params)      # None raises, as in the reference
         if engine == 'device':
             op = self._operator(self.lpinfo)
+            ini2 = np.atleast_2d(param_ini)
+            ctot = ini2.shape[0]
+            rank, world = dist_info()
+            lo, hi = shard_bounds(ctot) if world > 1 else (0, ctot)      # chains shard over ranks
+            seed0 = seeds[0] if seeds else 0
             if sampler == 'amcmc':
                 from ..mcmc.device_amcmc import DeviceAMCMC
-                eng = DeviceAMCMC(op, datanoise, seed=(seeds[0] if seeds else 0), **sampler_params)
+                # random streams are keyed by the GLOBAL chain id: results do not depend on the number of ranks
+                eng = DeviceAMCMC(op, datanoise, seed=seed0, chain0=lo, **sampler_params)
             elif sampler == 'hmc':
                 from ..mcmc.device_hmc import DeviceHMC
-                eng = DeviceHMC(op, datanoise, seed=(seeds[0] if seeds else 0), **sampler_params)
+                eng = DeviceHMC(op, datanoise, seed=seed0 + 7919 * rank, **sampler_params)
             else:
                 raise ValueError("engine='device' is implemented for sampler='amcmc' and 'hmc'")
-            res = eng.run(nmcmc, np.atleast_2d(param_ini), verbose=self.verbose)
-            self.mcmc_results = {k: (v.cpu().numpy() if v is not None else None) for k, v in res.items()}
+            if hi > lo:
+                res = eng.run(nmcmc, ini2[lo:hi], verbose=self.verbose and rank == 0)
+                res = {k: v.cpu().numpy() for k, v in res.items()}
+            else:
+                p_ = ini2.shape[1]
+                res = {'chain': np.zeros((0, nmcmc + 1, p_)), 'mapparams': np.zeros((0, p_)), 'maxpost': np.zeros(0),
+                       'accrate': np.zeros(0), 'logpost': np.zeros((0, nmcmc + 1)), 'alphas': np.zeros((0, nmcmc + 1))}
+            if world > 1:                                                  # the single collective, at the end
+                res = {k: all_gather_rows(v, ctot) for k, v in res.items()}
+            self.mcmc_results = res
             if np.ndim(param_ini) == 1:
-                self.mcmc_results = {k: (v[0] if v is not None else None) for k, v in self.mcmc_results.items()}
+                self.mcmc_results = {k: v[0] for k, v in self.mcmc_results.items()}
             self.samples, self.cmode = self.mcmc_results['chain'], self.mcmc_results['mapparams']
             return
         if sampler == 'amcmc':

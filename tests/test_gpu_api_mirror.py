@@ -58,3 +58,17 @@ def test_mlp_fit_and_predict():
     assert net.trained and len(net.history) == 300 and best is net.best_model
     assert net.history[-1][3] < net.history[0][3]                     # test_nnfit.py: loss decreases
     assert net.predict(x).shape == (50, 1)
+
+
+def test_more_weight_vectors_than_one_launch_takes():
+    """B > 65535 (grid limit of one launch) is split by the operator."""
+    from quinn_amd.ops import MLPArch, BatchedMLP
+    rs = np.random.RandomState(0)
+    x, y = rs.rand(5, 1), rs.rand(5, 1)
+    arch = MLPArch((1, 4, 1), "tanh")
+    op = BatchedMLP(arch, x, y)
+    W = rs.randn(70000, arch.nparams)
+    s = op.sse(W).cpu().numpy()
+    pick = [0, 65534, 65535, 65536, 69999]
+    ref = op.sse(W[pick]).cpu().numpy()
+    assert np.array_equal(s[pick], ref) and np.isfinite(s).all()

@@ -72,7 +72,7 @@ def test_sample_space_proposal_kernel_covariance_and_history_tracking():
     out = torch.empty(C, p, dtype=torch.float64, device=dev)
     c = 0.1 * 2.4 ** 2 / p
     _lib.check(L.qn_mcmc_propose_hist(cur.data_ptr(), hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(),
-                                      mean.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, p,
+                                      mean.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p,
                                       pstride, kcap, 1234, step.data_ptr(), out.data_ptr(), None), "propose_hist")
     torch.cuda.synchronize()
     d = (out - cur).cpu().numpy()
@@ -82,7 +82,7 @@ def test_sample_space_proposal_kernel_covariance_and_history_tracking():
     # a different step counter gives different draws; the same one reproduces them bit for bit
     out2 = torch.empty_like(out)
     _lib.check(L.qn_mcmc_propose_hist(cur.data_ptr(), hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(),
-                                      mean.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, p,
+                                      mean.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p,
                                       pstride, kcap, 1234, step.data_ptr(), out2.data_ptr(), None), "propose_hist")
     assert torch.equal(out, out2)
     # the 32-step block kernel: same random numbers per absolute step (float32 accumulation), so its
@@ -91,10 +91,10 @@ def test_sample_space_proposal_kernel_covariance_and_history_tracking():
     coef = torch.empty(C * ((kcap + 3) // 4 * 4 + 1) * TB, dtype=torch.float32, device=dev)
     delta = torch.empty(C, TB, p, dtype=torch.float64, device=dev)
     _lib.check(L.qn_mcmc_propose_hist_block(hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(), mean.data_ptr(),
-                                            float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, p, pstride, kcap,
+                                            float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p, pstride, kcap,
                                             1234, 10, coef.data_ptr(), delta.data_ptr(), None), "propose_hist_block")
     out3 = torch.empty_like(out)
-    _lib.check(L.qn_mcmc_apply_delta(cur.data_ptr(), delta.data_ptr(), 7, float(np.sqrt(c * 1e-8)), C, p, 1234,
+    _lib.check(L.qn_mcmc_apply_delta(cur.data_ptr(), delta.data_ptr(), 7, float(np.sqrt(c * 1e-8)), C, 0, p, 1234,
                                      step.data_ptr(), out3.data_ptr(), None), "apply_delta")
     torch.cuda.synchronize()
     scale = float(np.sqrt(np.diag(target).max()))
@@ -138,6 +138,25 @@ def test_history_of_distinct_states_matches_the_chain():
         runs = np.diff(np.concatenate([idx, [nmcmc + 1]]))
         assert np.array_equal(mult[c, :K], runs) and mult[c, :K].sum() == nmcmc + 1
         np.testing.assert_allclose(sumx[c], (chain[c] - chain[c, 0]).sum(axis=0), rtol=1e-10, atol=1e-10)
+
+
+def test_chains_do_not_depend_on_how_they_are_split():
+    """Random streams are keyed by the global chain id: running chains [0:6] in one engine or as [0:2] and [2:6] in
+    two engines (chain0 = 0 / 2, what two ranks would do) gives bit-identical chains -- through an adaptation."""
+    from quinn_amd.mcmc.device_amcmc import DeviceAMCMC
+    from quinn_amd.ops import MLPArch, BatchedMLP
+    x, y = _problem(4)
+    arch = MLPArch((1, 8, 8, 1), "tanh")
+    op = BatchedMLP(arch, x, y)
+    C, nmcmc = 6, 260
+    ini = np.stack([np.random.RandomState(800 + c).rand(arch.nparams) for c in range(C)])
+    kw = dict(gamma=0.1, t0=50, tadapt=100, seed=11)
+    whole = DeviceAMCMC(op, 0.2, **kw).run(nmcmc, ini)
+    a = DeviceAMCMC(op, 0.2, chain0=0, **kw).run(nmcmc, ini[:2])
+    b = DeviceAMCMC(op, 0.2, chain0=2, **kw).run(nmcmc, ini[2:])
+    for k in ('chain', 'logpost', 'alphas', 'accrate', 'mapparams'):
+        assert torch.equal(whole[k], torch.cat([a[k], b[k]])), k
+    assert (whole['accrate'] > 0).all()
 
 
 def test_device_engine_matches_host_sampler_in_distribution():

@@ -11,17 +11,19 @@ x = rs.rand(256, 1) * 2 * np.pi - np.pi
 y = np.sin(x) + 0.02 * rs.randn(256, 1)
 torch.manual_seed(0)
 out = {}
-for nch in (1, 64):
-    uq = NN_MCMC(MLP(1, 1, (16, 16), activ='tanh'), verbose=False)
-    kw = dict(zflag=False, datanoise=0.02, sampler='amcmc', sampler_params={'gamma': 0.01})
-    if nch > 1:
-        kw['seeds'] = list(range(nch))
-    np.random.seed(0)
-    uq.fit(x, y, nmcmc=50, **kw)
-    np.random.seed(0)
-    t0 = time.perf_counter()
-    uq.fit(x, y, nmcmc=1500, **kw)
-    el = time.perf_counter() - t0
-    out[f"{nch}_chains"] = {"steps_per_s": 1500 / el, "chain_steps_per_s": 1500 * nch / el,
-                            "accrate": float(np.mean(uq.mcmc_results['accrate']))}
+for engine, nsteps in (('host', 1500), ('device', 6000)):
+    for nch in (1, 64):
+        uq = NN_MCMC(MLP(1, 1, (16, 16), activ='tanh'), verbose=False)
+        kw = dict(zflag=False, datanoise=0.02, sampler='amcmc', sampler_params={'gamma': 0.01}, engine=engine)
+        if nch > 1 or engine == 'device':
+            kw['seeds'] = list(range(nch))
+        np.random.seed(0)
+        uq.fit(x, y, nmcmc=nsteps, **kw)              # warm-up of the same size (allocator)
+        np.random.seed(0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        uq.fit(x, y, nmcmc=nsteps, **kw)
+        torch.cuda.synchronize(); el = time.perf_counter() - t0
+        key = f"{nch}_chains" if engine == 'host' else f"{nch}_chains_device_engine"
+        out[key] = {"steps_per_s": nsteps / el, "chain_steps_per_s": nsteps * nch / el,
+                    "accrate": float(np.mean(np.asarray(uq.mcmc_results['accrate'])))}
 print(json.dumps(out))
