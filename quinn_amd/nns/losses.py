@@ -12,6 +12,22 @@ import torch
 from ..ops import MLPArch, BatchedMLP, flatten_module, neg_log_post_from_sse
 
 
+class NegLogPrior(torch.nn.Module):
+    """Gaussian negative log-prior of a module's weights around an anchor (quinn/nns/losses.py:212-256):
+    sum (w - anchor)^2 / (2 sigma^2) + (K/2) log(2 pi sigma^2).  O(p) host formula."""
+
+    def __init__(self, sigma, anchor):
+        super().__init__()
+        self.sigma = float(sigma)
+        self.anchor = anchor
+
+    def forward(self, model):
+        w = torch.cat([p.detach().flatten().double().cpu() for p in model.parameters()])
+        a = torch.as_tensor(np.asarray(self.anchor.detach().cpu() if isinstance(self.anchor, torch.Tensor)
+                                       else self.anchor), dtype=torch.float64).flatten()
+        return ((w - a) ** 2).sum() / 2 / self.sigma ** 2 + (w.numel() / 2) * np.log(2 * np.pi * self.sigma ** 2)
+
+
 class NegLogPost(torch.nn.Module):
     def __init__(self, nnmodel, fulldatasize, sigma, priorparams, device=None, dtype="float64"):
         super().__init__()

@@ -68,7 +68,7 @@ def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lra
     Args:
         arch (MLPArch); W0 [M,p] initial flat weights; xtrn (N,d), ytrn (N,o): the FULL dataset;
         rows [M, ntrn] int: the dataset rows member j trains on; xval, yval: validation set
-        shared by all members; perms: optional precomputed [M, nepochs, ntrn] permutations (a shard of
+        shared by all members (None: each member validates on its own rows); perms: optional precomputed [M, nepochs, ntrn] permutations (a shard of
         `draw_perms` when members are split over ranks); anchors [M,p] + prior_sigma: per-member Gaussian
         prior N(anchor, prior_sigma^2) added to the 'logpost' loss as the reference's NegLogPost does
         (losses.py:202-204, weight len(batch)/ntrn; used by NN_RMS); the rest as in `nnfit`.
@@ -89,9 +89,11 @@ def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lra
     rows = np.asarray(rows).reshape(M, -1)
     o = arch.dims[-1]
     op = BatchedMLP(arch, xtrn, ytrn, device=device, dtype=dtype)
-    opv = BatchedMLP(arch, xval, yval, device=device, dtype=dtype)
+    # xval None: every member validates on its OWN training rows (the reference's nnfit copies the member's
+    # subset as the validation set when val is None, nnfit.py:106-109)
+    opv = BatchedMLP(arch, xval, yval, device=device, dtype=dtype) if xval is not None else None
     dev = op.device
-    nval = opv.N
+    nval = opv.N if opv is not None else ntrn
     if loss_fn == 'mse':
         tail = lambda sse, n: sse / (n * o)                       # MSELoss(mean), nnfit.py:59-63
         gscale = lambda n: 1.0 / (n * o)
@@ -145,7 +147,7 @@ def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lra
             Wc = W if op.tdt == torch.float64 else W.to(op.tdt)
             sse, g = op.sse_grad(Wc, row_idx=idx)
             loss_trn = tail(sse, nb)
-            loss_val = tail(opv.sse(Wc), nval)
+            loss_val = tail(opv.sse(Wc) if opv is not None else op.sse(Wc, row_idx=rows32), nval)
             if i == 0:
                 loss_full = tail(op.sse(Wc, row_idx=rows32), ntrn)
             gextra = None

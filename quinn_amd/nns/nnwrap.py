@@ -55,11 +55,14 @@ class NNWrap():
         return self._predict(weights, x_in)
 
     def calc_loss(self, weights, loss_fn, inputs, targets):
-        """float: `loss_fn` (a `NegLogPost`) at the given flat weights (nnwrap.py:109-126)."""
-        if not isinstance(loss_fn, NegLogPost):
-            raise NotImplementedError("calc_loss on the accelerated path takes a quinn_amd NegLogPost")
+        """float: `loss_fn(inputs, targets)` with the module carrying the given flat weights (nnwrap.py:109-126).
+        A `NegLogPost` is evaluated on the device operator; any other callable is simply called on the tensors,
+        as the reference does (`loss_fn(inputs, targets).item()`, e.g. `torch.nn.MSELoss()` in its tests)."""
         self.p_unflatten(weights)
-        return loss_fn.value_and_grad(weights, inputs, np.asarray(targets))[0]
+        if isinstance(loss_fn, NegLogPost):
+            return loss_fn.value_and_grad(weights, inputs, np.asarray(targets))[0]
+        return float(loss_fn(torch.as_tensor(np.asarray(inputs), dtype=torch.float64),
+                             torch.as_tensor(np.asarray(targets), dtype=torch.float64)).item())
 
     def calc_lossgrad(self, weights, loss_fn, inputs, targets):
         """np.ndarray `(p,)`: gradient of `loss_fn` w.r.t. the flat weights (nnwrap.py:128-150)."""
@@ -67,6 +70,11 @@ class NNWrap():
             raise NotImplementedError("calc_lossgrad on the accelerated path takes a quinn_amd NegLogPost")
         self.p_unflatten(weights)
         return loss_fn.value_and_grad(weights, inputs, np.asarray(targets), want_grad=True)[1]
+
+
+def nnwrapper(x, nnmodel):
+    """numpy `(N,d)` -> numpy `(N,o)` through the module's current weights (nnwrap.py:306-327)."""
+    return NNWrap(nnmodel)(x)
 
 
 def nn_p(p, x, *otherpars):

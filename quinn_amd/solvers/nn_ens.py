@@ -39,11 +39,9 @@ class NN_Ens(QUiNNBase):
         ntrn = ytrn.shape[0]
         rows = np.stack([np.random.permutation(ntrn)[:int(ntrn * self.dfrac)] for _ in range(self.nens)])
         val = kwargs.pop('val', None)
-        xval, yval = (xtrn.copy(), ytrn.copy()) if val is None else val
-        # validation defaults to each member's OWN training subset in the reference (nnfit.py:106-109
-        # sees xtrn[ind_this]); a shared explicit validation set is the common case
-        if val is None and self.dfrac < 1.0:
-            raise NotImplementedError("dfrac < 1 without an explicit val=[xval, yval] set")
+        # no validation set: every member validates on its own training subset (nnfit.py:106-109 sees
+        # xtrn[ind_this] and copies it)
+        xval, yval = (None, None) if val is None else val
         for k in ('freq_plot', 'lhist_suffix', 'gradcheck', 'lossparams'):
             kwargs.pop(k, None)
         if kwargs.pop('priorparams', None) is not None:

@@ -28,9 +28,7 @@ class NN_RMS(NN_Ens):
         ntrn = ytrn.shape[0]
         rows = np.stack([np.random.permutation(ntrn)[:int(ntrn * self.dfrac)] for _ in range(self.nens)])
         val = kwargs.pop('val', None)
-        if val is None:
-            raise NotImplementedError("NN_RMS on the accelerated path needs an explicit val=[xval, yval] set")
-        xval, yval = val
+        xval, yval = (None, None) if val is None else val      # None: members validate on their own rows
         for k in ('freq_plot', 'lhist_suffix', 'gradcheck', 'lossparams', 'loss_fn', 'datanoise', 'priorparams'):
             kwargs.pop(k, None)
         nepochs = kwargs.pop('nepochs', 5000)

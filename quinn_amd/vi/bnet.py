@@ -79,7 +79,9 @@ class BNet(torch.nn.Module):
         for shp in _param_shapes(self.arch):                     # bnet.py:69-72: mu then rho, per tensor
             mus.append(torch.empty(shp, dtype=torch.float64).uniform_(mu_init_lower, mu_init_upper).flatten())
             rhos.append(torch.empty(shp, dtype=torch.float64).uniform_(rho_init_lower, rho_init_upper).flatten())
-        self.theta = torch.nn.Parameter(torch.cat(mus + rhos).to(self.device))
+        # ONE flat parameter [mu (p), rho (p)]; its name keeps `mu` / `rho` visible in named_parameters()
+        # (the reference registers one `*_mu` / `*_rho` pair per tensor, bnet.py:69-72)
+        self.mu_rho = torch.nn.Parameter(torch.cat(mus + rhos).to(self.device))
         self.log_prior = 0.0
         self.log_variational_posterior = 0.0
         self.loss_params = None
@@ -90,9 +92,14 @@ class BNet(torch.nn.Module):
         torch.nn.Module.__init__(new)
         for k in ('arch', 'p', 'pi', 'sigma1', 'sigma2', 'rng', 'op', 'device', 'nparams', 'loss_params'):
             setattr(new, k, getattr(self, k))
-        new.theta = torch.nn.Parameter(self.theta.detach().clone())
+        new.mu_rho = torch.nn.Parameter(self.mu_rho.detach().clone())
         new.log_prior, new.log_variational_posterior = self.log_prior, self.log_variational_posterior
         return new
+
+    @property
+    def theta(self):
+        """The flat variational parameter [mu, rho] (alias of `mu_rho`)."""
+        return self.mu_rho
 
     @property
     def mu(self):

@@ -1,0 +1,286 @@
+"""GPU: the scenarios of the reference's own tests for the hot-path components (tests/test_solvers.py,
+test_vi.py, test_ensemble.py, test_nnfit.py, test_losses.py, test_nnwrap.py, test_mlp.py), run through this
+package's mirrors of the same classes: same constructor arguments, calls and assertions, so that a user of
+the reference finds the same contract.  (Sampler-class scenarios of test_mcmc.py: tests/test_reference_scenarios_cpu.py.)
+Not mirrored because out of scope: Laplace / SWAG solvers, Hessian helpers of NNWrap."""
+import numpy as np
+import pytest
+import torch
+
+from quinn_amd.nns.losses import NegLogPost, NegLogPrior
+from quinn_amd.nns.mlp import MLP
+from quinn_amd.nns.nnfit import nnfit
+from quinn_amd.nns.nnwrap import NNWrap, nn_p, nnwrapper
+from quinn_amd.nns.rnet import RNet
+from quinn_amd.solvers.nn_ens import NN_Ens
+from quinn_amd.solvers.nn_mcmc import NN_MCMC
+from quinn_amd.solvers.nn_rms import NN_RMS
+from quinn_amd.solvers.nn_vi import NN_VI
+from quinn_amd.vi.bnet import BNet
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _reference_defaults():
+    """The reference switches torch's default dtype to double when it is imported (tchutils.py:9)."""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.double)
+    np.random.seed(42)
+    torch.manual_seed(42)
+    yield
+    torch.set_default_dtype(old)
+
+
+def sine(N):
+    x = np.linspace(-1, 1, N).reshape(-1, 1)
+    return x, np.sin(x)
+
+
+# ------------------------------------------------------------------ test_solvers.py: NN_MCMC
+def test_nn_mcmc_creation():                                 # :16-22
+    mcmc = NN_MCMC(MLP(1, 1, (5,), activ='tanh'), verbose=False)
+    assert mcmc.pdim > 0 and mcmc.samples is None
+
+
+def _fitted_mcmc(nmcmc=200):
+    mcmc = NN_MCMC(MLP(1, 1, (5,), activ='tanh'), verbose=False)
+    x, y = sine(20)
+    mcmc.fit(x, y, nmcmc=nmcmc, datanoise=0.1, sampler='amcmc', zflag=False, sampler_params={})
+    return mcmc, x
+
+
+def test_nn_mcmc_fit_amcmc():                                # :25-41
+    mcmc, _ = _fitted_mcmc()
+    assert mcmc.samples is not None and mcmc.cmode is not None
+
+
+def test_nn_mcmc_predict_sample():                           # :44-61
+    mcmc, x = _fitted_mcmc()
+    assert mcmc.predict_sample(x, mcmc.cmode).shape == (20, 1)
+
+
+def test_nn_mcmc_predict_ens():                              # :64-81
+    mcmc, x = _fitted_mcmc(300)
+    assert mcmc.predict_ens(x, nens=5, nburn=100).shape[0] == 5
+
+
+def test_nn_mcmc_predict_map():                              # :84-100
+    mcmc, x = _fitted_mcmc()
+    assert mcmc.predict_MAP(x).shape == (20, 1)
+
+
+# ------------------------------------------------------------------ test_solvers.py: NN_RMS
+def test_nn_rms_creation():                                  # :201-207
+    rms = NN_RMS(MLP(1, 1, (5,), activ='tanh'), nens=2, datanoise=0.1, priorsigma=1.0)
+    assert rms.datanoise == 0.1 and rms.priorsigma == 1.0
+
+
+def test_nn_rms_fit_predict_and_ens():                       # :210-245 (no validation set given)
+    rms = NN_RMS(MLP(1, 1, (5,), activ='tanh'), nens=2, datanoise=0.1, priorsigma=1.0)
+    x, y = sine(30)
+    rms.fit(x, y, nepochs=100, lrate=0.01, freq_out=1000)
+    assert rms.predict(x).shape == (30, 1)
+    assert rms.predict_ens(x).shape == (2, 30, 1)
+
+
+# ------------------------------------------------------------------ test_vi.py
+def test_bnet_has_variational_parameters():                  # :11-19
+    names = [n for n, _ in BNet(MLP(2, 1, (8,), activ='tanh')).named_parameters()]
+    assert any('mu' in n for n in names) and any('rho' in n for n in names)
+
+
+def test_bnet_forward():                                     # :22-46
+    bnet = BNet(MLP(2, 1, (8,), activ='tanh'))
+    x = torch.randn(10, 2)
+    assert bnet(x, sample=True).shape == (10, 1)
+    y = bnet(x, sample=False)
+    assert y.shape == (10, 1) and torch.all(torch.isfinite(torch.as_tensor(y)))
+
+
+def test_bnet_sample_elbo_returns_three_finite_terms():      # :49-61
+    bnet = BNet(MLP(2, 1, (8,), activ='tanh'))
+    bnet.loss_params = [0.05, 1, 1]
+    lp, lq, nll = bnet.sample_elbo(torch.randn(10, 2), torch.randn(10, 1), nsam=1, likparams=[0.05])
+    assert all(np.isfinite(float(v)) for v in (lp, lq, nll))
+
+
+def test_nn_vi_creation():                                   # :64-70
+    vi = NN_VI(MLP(1, 1, (8,), activ='tanh'))
+    assert vi.trained is False and vi.bmodel is not None
+
+
+def test_nn_vi_fit_predict():                                # :73-91
+    vi = NN_VI(MLP(1, 1, (8, 8), activ='tanh'))
+    x, y = sine(30)
+    vi.fit(x, y, nepochs=100, lrate=0.01, datanoise=0.1, freq_out=1000)
+    assert vi.trained and vi.predict_sample(x).shape == (30, 1)
+
+
+def test_nn_vi_predict_ens_and_uncertainty():                # :94-132
+    vi = NN_VI(MLP(1, 1, (8,), activ='tanh'))
+    x, y = sine(20)
+    vi.fit(x, y, nepochs=200, lrate=0.01, datanoise=0.1, freq_out=1000)
+    assert vi.predict_ens(x, nens=10).shape == (10, 20, 1)
+    assert np.mean(np.var(vi.predict_ens(x, nens=50), axis=0)) > 0
+
+
+# ------------------------------------------------------------------ test_ensemble.py
+def test_nn_ens_creation():                                  # :10-16
+    ens = NN_Ens(MLP(1, 1, (8, 8), activ='tanh'), nens=3)
+    assert ens.nens == 3 and len(ens.learners) == 3
+
+
+def test_nn_ens_fit_predict_without_validation_set():        # :19-34
+    ens = NN_Ens(MLP(1, 1, (8, 8), activ='tanh'), nens=2)
+    x, y = sine(30)
+    ens.fit(x, y, nepochs=100, lrate=0.01, freq_out=1000)
+    assert ens.predict(x).shape == (30, 1)
+
+
+def test_nn_ens_predict_sample_ens_and_moments():            # :37-93
+    ens = NN_Ens(MLP(1, 1, (8,), activ='tanh'), nens=3)
+    x, y = sine(20)
+    ens.fit(x, y, nepochs=100, lrate=0.01, freq_out=1000)
+    assert ens.predict_sample(x).shape == (20, 1)
+    assert ens.predict_ens(x).shape == (3, 20, 1)
+    ymean, yvar, ycov = ens.predict_mom_sample(x, msc=0, nsam=3)
+    assert ymean.shape == (20, 1) and yvar is None and ycov is None
+
+
+def test_nn_ens_data_fraction_without_validation_set():      # :96-111: members validate on their own subsets
+    ens = NN_Ens(MLP(1, 1, (8,), activ='tanh'), nens=2, dfrac=0.8)
+    x, y = sine(40)
+    ens.fit(x, y, nepochs=100, lrate=0.01, freq_out=1000)
+    assert ens.predict(x).shape == (40, 1)
+    h = np.array(ens.learners[0].history)
+    assert np.allclose(h[:, 2], h[:, 3])         # full-train loss == validation loss: same rows (nnfit.py:106-109)
+
+
+def test_nn_ens_multioutput():                               # :114-129
+    ens = NN_Ens(MLP(2, 2, (8,), activ='tanh'), nens=2)
+    x = np.random.rand(30, 2)
+    y = np.column_stack([x.sum(axis=1), x.prod(axis=1)])
+    ens.fit(x, y, nepochs=100, lrate=0.01, freq_out=1000)
+    assert ens.predict(x).shape == (30, 2)
+
+
+# ------------------------------------------------------------------ test_nnfit.py
+def test_nnfit_returns_result_dict():                        # :10-28
+    x, y = sine(50)
+    res = nnfit(MLP(1, 1, (16, 16), activ='tanh'), x, y, nepochs=200, lrate=0.01, freq_out=1000)
+    assert {'best_nnmodel', 'best_loss', 'best_epoch', 'history'} <= set(res)
+    assert res['best_loss'] < 1.0
+
+
+def test_nnfit_loss_decreases():                             # :31-47
+    x = np.linspace(-1, 1, 50).reshape(-1, 1)
+    res = nnfit(MLP(1, 1, (16,), activ='tanh'), x, x ** 2, nepochs=300, lrate=0.01, freq_out=1000)
+    assert res['history'][-1][2] < res['history'][0][2]
+
+
+def test_nnfit_with_validation_batches_and_weight_decay():   # :50-84, :124-137
+    x, y = sine(50)
+    xval = np.random.rand(10, 1) * 2 - 1
+    res = nnfit(MLP(1, 1, (16,), activ='tanh'), x, y, val=[xval, np.sin(xval)], nepochs=200, lrate=0.01, freq_out=1000)
+    assert res['best_loss'] < 1.0
+    x3 = np.linspace(-1, 1, 100).reshape(-1, 1)
+    res = nnfit(MLP(1, 1, (16,), activ='tanh'), x3, x3 ** 3, nepochs=200, lrate=0.01, batch_size=20, freq_out=1000)
+    assert res['best_loss'] < 1.0
+    res = nnfit(MLP(1, 1, (16,), activ='tanh'), x, y, nepochs=200, lrate=0.01, wd=0.001, freq_out=1000)
+    assert res['best_loss'] < 1.0
+
+
+def test_mlpbase_fit_then_predict_uses_best_model():         # :87-103
+    net = MLP(1, 1, (16,), activ='tanh')
+    x, y = sine(50)
+    net.fit(x, y, nepochs=200, lrate=0.01, freq_out=1000)
+    assert np.mean((net.predict(x) - y) ** 2) < 0.5
+
+
+def test_nnfit_multioutput():                                # :106-121
+    x = np.random.rand(50, 2)
+    y = np.column_stack([x.sum(axis=1), x.prod(axis=1), x[:, 0] - x[:, 1]])
+    res = nnfit(MLP(2, 3, (16,), activ='tanh'), x, y, nepochs=300, lrate=0.01, freq_out=1000)
+    assert res['best_nnmodel'] is not None
+
+
+# ------------------------------------------------------------------ test_losses.py
+def test_neglogprior_minimal_at_anchor_and_finite():         # :10-38
+    net = MLP(2, 1, (5,))
+    anchor = torch.cat([p.detach().flatten() for p in net.parameters()])
+    prior = NegLogPrior(1.0, anchor)
+    at_anchor = prior(net)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(1.0)
+    assert at_anchor < prior(net)
+    assert torch.isfinite(NegLogPrior(1.0, torch.zeros(net.numpar()))(net))
+
+
+def test_neglogpost_with_and_without_prior():                # :41-74
+    net = MLP(2, 1, (5,))
+    x, y = torch.randn(10, 2), torch.randn(10, 1)
+    v1 = NegLogPost(net, 50, 0.1, None)(x, y)
+    v2 = NegLogPost(net, 50, 0.1, {'sigma': 1.0, 'anchor': torch.randn(net.numpar())})(x, y)
+    assert torch.isfinite(v1) and torch.isfinite(v2)
+
+
+def test_neglogpost_perfect_target_beats_bad_target():       # :77-93
+    net = MLP(1, 1, (5,))
+    loss = NegLogPost(net, 10, 0.1, None)
+    x = torch.randn(10, 1)
+    y = net(x).detach()
+    assert loss(x, y) < loss(x, y + 10.0)
+
+
+# ------------------------------------------------------------------ test_nnwrap.py
+def test_nnwrap_call_flatten_unflatten_predict():            # :10-50
+    net = MLP(2, 1, (10,))
+    wrap = NNWrap(net)
+    x = np.random.rand(15, 2)
+    y1 = wrap(x)
+    assert isinstance(y1, np.ndarray) and y1.shape == (15, 1)
+    flat = wrap.p_flatten().detach().numpy().flatten()
+    assert len(flat) == net.numpar()
+    wrap.p_unflatten(flat)
+    assert np.allclose(y1, wrap(x))
+    assert wrap.predict(np.random.rand(10, 2), flat).shape == (10, 1)
+
+
+def test_nnwrap_calc_loss_and_grad():                        # :53-83
+    wrap = NNWrap(MLP(2, 2, (5,)))
+    w = wrap.p_flatten().detach().numpy().flatten()
+    val = wrap.calc_loss(w, torch.nn.MSELoss(), np.random.rand(10, 2), np.random.rand(10, 2))
+    assert isinstance(val, float) and val >= 0.0
+    net = MLP(2, 1, (5,))
+    wrap = NNWrap(net)
+    w = wrap.p_flatten().detach().numpy().flatten()
+    g = wrap.calc_lossgrad(w, NegLogPost(net, 10, 0.1, None), np.random.rand(10, 2), np.random.rand(10, 1))
+    assert g.shape == w.shape
+
+
+def test_nnwrapper_and_nn_p():                               # :102-136
+    net = MLP(2, 1, (10,))
+    x = np.random.rand(10, 2)
+    y = nnwrapper(x, net)
+    assert isinstance(y, np.ndarray) and y.shape == (10, 1)
+    net = MLP(2, 1, (5,))
+    p1 = NNWrap(net).p_flatten().detach().numpy().flatten()
+    y1 = nn_p(p1, x, net)
+    assert isinstance(y1, np.ndarray) and y1.shape == (10, 1)
+    assert not np.allclose(y1, nn_p(p1 + 0.1, x, net))
+
+
+# ------------------------------------------------------------------ test_mlp.py (the networks of the path)
+def test_mlp_and_rnet_shapes_numpar_predict():               # :10-54, :135-194
+    net = MLP(2, 1, (5,))
+    assert net.numpar() == 21
+    assert net(torch.randn(10, 2)).shape == (10, 1)
+    assert net.predict(np.random.rand(10, 2)).shape == (10, 1)
+    r = RNet(5, 3, indim=2, outdim=1, layer_pre=True, layer_post=True)
+    assert r(torch.randn(10, 2)).shape == (10, 1) and r.numpar() > 0
+    assert RNet(3, 4)(torch.randn(10, 3)).shape == (10, 3)
+    y = RNet(4, 3, indim=2, outdim=1, layer_pre=True, layer_post=True).predict(np.random.rand(10, 2))
+    assert isinstance(y, np.ndarray) and y.shape == (10, 1)
+    assert RNet(4, 3, indim=2, outdim=1, mlp=True, layer_pre=True, layer_post=True)(torch.randn(5, 2)).shape == (5, 1)
