@@ -86,12 +86,14 @@ def fit_ensemble(spec, w0, xtrn, ytrn, xval, yval, nens, dfrac, nepochs, batch_s
                  np_rng, gen, wd=0.0):
     """NN_Ens.fit: members are deep copies of ONE module (identical w0, learner.py:28);
     member j trains on rows np_rng.permutation(ntrn)[:int(ntrn*dfrac)] (nn_ens.py:63-64),
-    members strictly one after another (so both RNG streams are consumed member-major)."""
+    members strictly one after another (so both RNG streams are consumed member-major).
+    xval None: each member validates on a copy of its own training subset (nnfit.py:106-109)."""
     members = []
     ntrn = ytrn.shape[0]
     for _ in range(nens):
         rows = np_rng.permutation(ntrn)[:int(ntrn * dfrac)]
-        info = fit_member_mse(spec, w0, xtrn[rows], ytrn[rows], xval, yval, nepochs, batch_size,
+        xv, yv = (xtrn[rows], ytrn[rows]) if xval is None else (xval, yval)
+        info = fit_member_mse(spec, w0, xtrn[rows], ytrn[rows], xv, yv, nepochs, batch_size,
                               lrate, gen, wd=wd)
         info["rows"] = rows
         members.append(info)

@@ -499,3 +499,29 @@ def g10():
 
 if __name__ == "__main__" and "rnet" in sys.argv[1:]:
     g10()
+
+
+# ---------------------------------------------------------------- G11: ensemble without a validation set
+def g11():
+    """NN_Ens.fit with dfrac < 1 and val=None: every member validates on its own training subset
+    (nnfit.py:106-109) -- the call pattern of tests/test_ensemble.py:96-111."""
+    d, o, hls, act, N = 1, 1, (8,), "tanh", 40
+    torch.manual_seed(110)
+    net = MLP(d, o, hls, activ=act)
+    w0 = NNWrap(net).p_flatten().detach().numpy().flatten()
+    x, y = data(N, d, o, 0.05, 140)
+    ens = NN_Ens(net, nens=2, dfrac=0.8, verbose=False)
+    np.random.seed(111)
+    torch.manual_seed(112)
+    ens.fit(x, y, lrate=0.01, batch_size=10, nepochs=15, freq_out=1000)
+    hist = np.array([np.array(l.nnmodel.history) for l in ens.learners])
+    best = np.array([NNWrap(l.best_model).p_flatten().detach().numpy().flatten() for l in ens.learners])
+    final = np.array([np.concatenate([p.detach().flatten().numpy() for p in l.nnmodel.nnmodel.parameters()])
+                      for l in ens.learners])
+    save("g11_ens_noval.npz", dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y, w0=w0, nens=2,
+         dfrac=0.8, lrate=0.01, batch_size=10, nepochs=15, np_seed=111, torch_seed=112, history=hist, best=best,
+         final=final)
+
+
+if __name__ == "__main__" and "ens_noval" in sys.argv[1:]:
+    g11()

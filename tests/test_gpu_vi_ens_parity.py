@@ -176,3 +176,19 @@ def test_reduce_lr_on_plateau_matches_torch_scheduler():
     np.testing.assert_allclose(h[:, 3], ref["history"][:, 1], rtol=1e-8, atol=1e-11)
     fin = np.concatenate([q.detach().flatten().numpy() for q in net.parameters()])
     np.testing.assert_allclose(fin, ref["final"], rtol=1e-8, atol=1e-10)
+
+
+def test_g11_ensemble_without_validation_set():
+    """dfrac < 1 and no val=: members validate on their own subsets (tests/test_ensemble.py:96-111 of the reference)."""
+    g = load_golden("g11_ens_noval.npz")
+    net = _net(g)
+    load_flat_into(net, g["w0"])
+    ens = NN_Ens(net, nens=int(g["nens"]), dfrac=float(g["dfrac"]), verbose=False)
+    np.random.seed(int(g["np_seed"]))
+    torch.manual_seed(int(g["torch_seed"]))
+    ens.fit(g["x"], g["y"], lrate=float(g["lrate"]), batch_size=int(g["batch_size"]), nepochs=int(g["nepochs"]),
+            freq_out=1000)
+    hist = np.array([l.history for l in ens.learners])
+    np.testing.assert_allclose(hist, g["history"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(ens.fit_results["best_w"], g["best"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(ens.fit_results["final_w"], g["final"], rtol=1e-9, atol=1e-11)

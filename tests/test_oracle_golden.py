@@ -183,3 +183,16 @@ def test_g7_prediction_from_chain():
     cov = np.cov(yens[:, :, 0], rowvar=False, ddof=1)          # quinn.py:93-94
     assert np.array_equal(cov, g["ycov"][:, :, 0])
     assert np.array_equal(np.diag(cov), g["yvar"][:, 0])
+
+
+def test_g11_ensemble_without_validation_set_bitwise():
+    g = load_golden("g11_ens_noval.npz")
+    spec = spec_of(g)
+    rng = np.random.RandomState(int(g["np_seed"]))
+    gen = torch.Generator(); gen.manual_seed(int(g["torch_seed"]))
+    members = fit_ref.fit_ensemble(spec, g["w0"], g["x"], g["y"], None, None, int(g["nens"]), float(g["dfrac"]),
+                                   int(g["nepochs"]), int(g["batch_size"]), float(g["lrate"]), rng, gen)
+    for j, m in enumerate(members):
+        assert np.array_equal(m["history"], g["history"][j])
+        assert np.array_equal(m["best"], g["best"][j])
+        assert np.array_equal(m["final"], g["final"][j])
