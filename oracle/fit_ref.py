@@ -82,6 +82,61 @@ def fit_member_mse(spec, w0, xtrn, ytrn, xval, yval, nepochs, batch_size, lrate,
     return info
 
 
+def neg_log_post_with_prior(mod, x, y, sigma, fulldatasize, anchor, prior_sigma):
+    """NegLogPost.forward with a Gaussian prior (losses.py:197-204 + NegLogPrior.forward :238-256): the prior is
+    summed parameter tensor by parameter tensor and weighted len(batch) / fulldatasize."""
+    sig = torch.tensor(float(sigma), dtype=F64)
+    pi = torch.tensor(np.pi, dtype=F64)
+    pred = mod(x)
+    val = 0.5 * torch.sum(torch.pow(y - pred, 2)) / sig ** 2
+    val = val + (len(pred) / 2) * torch.log(2 * pi)
+    val = val + len(pred) * torch.log(sig)
+    if anchor is not None:
+        ps = torch.tensor(float(prior_sigma), dtype=F64)
+        nlp, i = 0, 0
+        for p in mod.parameters():
+            n = p.flatten().size()[0]
+            nlp = nlp + torch.sum(torch.pow(p.flatten() - anchor[i:i + n], 2)) / 2 / ps ** 2
+            i += n
+        nlp = nlp + (i / 2) * torch.log(2 * pi * ps ** 2)
+        val = val + len(pred) * nlp / fulldatasize
+    return val
+
+
+def fit_member_logpost(spec, w0, xtrn, ytrn, xval, yval, nepochs, batch_size, lrate, gen, datanoise,
+                       anchor=None, prior_sigma=None, wd=0.0):
+    """nnfit(loss_fn='logpost', datanoise, priorparams) for one module (nnfit.py:64-66): NegLogPost over the
+    member's ntrn rows, optionally with the anchored Gaussian prior."""
+    mod = build_module(spec)
+    load_flat(mod, w0)
+    xt, yt = torch.as_tensor(xtrn, dtype=F64), torch.as_tensor(ytrn, dtype=F64)
+    xv, yv = torch.as_tensor(xval, dtype=F64), torch.as_tensor(yval, dtype=F64)
+    a = None if anchor is None else torch.as_tensor(anchor, dtype=F64)
+    ntrn = xt.shape[0]
+    info = train_loop(list(mod.parameters()),
+                      lambda xb, yb: neg_log_post_with_prior(mod, xb, yb, datanoise, ntrn, a, prior_sigma),
+                      xt, yt, xv, yv, nepochs, batch_size, lrate, wd, "adam", gen, lambda: flat_params(mod))
+    info["final"] = flat_params(mod)
+    return info
+
+
+def fit_rms(spec, w0, xtrn, ytrn, xval, yval, nens, dfrac, nepochs, batch_size, lrate, np_rng, gen, datanoise,
+            priorsigma):
+    """NN_RMS.fit (nn_rms.py:41-57): per member, in this order: np permutation -> data subset; anchor =
+    randn(p) * priorsigma from the global torch generator; then nnfit with the 'logpost' loss and that prior."""
+    members = []
+    ntrn = ytrn.shape[0]
+    for _ in range(nens):
+        rows = np_rng.permutation(ntrn)[:int(ntrn * dfrac)]
+        anchor = torch.randn(size=(spec.nparams,), dtype=F64, generator=gen) * priorsigma
+        xv, yv = (xtrn[rows], ytrn[rows]) if xval is None else (xval, yval)
+        info = fit_member_logpost(spec, w0, xtrn[rows], ytrn[rows], xv, yv, nepochs, batch_size, lrate, gen,
+                                  datanoise, anchor=anchor, prior_sigma=priorsigma)
+        info["rows"], info["anchor"] = rows, anchor.numpy().copy()
+        members.append(info)
+    return members
+
+
 def fit_ensemble(spec, w0, xtrn, ytrn, xval, yval, nens, dfrac, nepochs, batch_size, lrate,
                  np_rng, gen, wd=0.0):
     """NN_Ens.fit: members are deep copies of ONE module (identical w0, learner.py:28);

@@ -254,8 +254,13 @@ def nnfit(nnmodel, xtrn, ytrn, val=None, loss_fn='mse', loss_xy=None, datanoise=
     if scheduler_lr == "ReduceLROnPlateau" and lmbd is not None:
         print("Trying to use two schedulers. Exiting.")
         sys.exit()
-    if priorparams is not None:
-        raise NotImplementedError("prior terms (NegLogPrior / NN_RMS) are not part of the accelerated path yet")
+    anchors, prior_sigma = None, None
+    if priorparams is not None:                      # Gaussian prior of NegLogPost (nnfit.py:64-66, losses.py:202-204)
+        if loss_fn != 'logpost' or loss_xy is not None:
+            raise ValueError("priorparams go with loss_fn='logpost'")
+        a = priorparams['anchor']
+        anchors = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, dtype=np.float64).reshape(1, -1)
+        prior_sigma = float(priorparams['sigma'])
     ntrn = xtrn.shape[0]
     if val is None:
         xval, yval = xtrn.copy(), ytrn.copy()
@@ -267,7 +272,8 @@ def nnfit(nnmodel, xtrn, ytrn, val=None, loss_fn='mse', loss_xy=None, datanoise=
         res = fit_members(arch, flatten_module(nnmodel)[None, :], xtrn, ytrn, np.arange(ntrn)[None, :], xval, yval,
                           nepochs, batch_size, lrate=lrate, wd=wd, optimizer=optimizer, loss_fn=loss_fn,
                           datanoise=datanoise, lmbd=lmbd, perm_mode=perm_mode, device=device, dtype=dtype,
-                          freq_out=freq_out, scheduler_lr=scheduler_lr, cooldown=cooldown, factor=factor)
+                          freq_out=freq_out, scheduler_lr=scheduler_lr, cooldown=cooldown, factor=factor,
+                          anchors=anchors, prior_sigma=prior_sigma)
         load_flat_into(nnmodel, res['final_w'][0])
         best = copy.deepcopy(nnmodel)
         load_flat_into(best, res['best_w'][0])

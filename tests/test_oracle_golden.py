@@ -196,3 +196,17 @@ def test_g11_ensemble_without_validation_set_bitwise():
         assert np.array_equal(m["history"], g["history"][j])
         assert np.array_equal(m["best"], g["best"][j])
         assert np.array_equal(m["final"], g["final"][j])
+
+
+def test_g9_rms_anchored_ensemble_bitwise():
+    g = load_golden("g9_rms.npz")
+    spec = spec_of(g)
+    rng = np.random.RandomState(int(g["np_seed"]))
+    gen = torch.Generator(); gen.manual_seed(int(g["torch_seed"]))
+    members = fit_ref.fit_rms(spec, g["w0"], g["x"], g["y"], g["xval"], g["yval"], int(g["nens"]), float(g["dfrac"]),
+                              int(g["nepochs"]), int(g["batch_size"]), float(g["lrate"]), rng, gen,
+                              float(g["datanoise"]), float(g["priorsigma"]))
+    for j, m in enumerate(members):
+        assert np.array_equal(m["history"], g["history"][j])
+        assert np.array_equal(m["best"], g["best"][j])
+        assert np.array_equal(m["final"], g["final"][j])
