@@ -77,3 +77,78 @@ class QUiNNBase():
             print(f"msc={msc}, but needs to be 0,1, or 2. Exiting.")
             sys.exit()
         return ymean, yvar, ycov
+
+    # -- figures (presentation only; same signatures and file names as quinn.py:106-260) ---------------
+    @staticmethod
+    def _center_and_spread(yens, quantiles):
+        """(centre, lower, upper) of an ensemble: mean and +-std, or median and the distances to the quartiles."""
+        if quantiles:
+            q25, q50, q75 = np.quantile(yens, [0.25, 0.5, 0.75], axis=0)
+            return q50, q50 - q25, q75 - q50
+        sd = np.std(yens, axis=0)
+        return np.mean(yens, axis=0), sd, sd
+
+    def predict_plot(self, xx_list, yy_list, nmc=100, plot_qt=False, labels=None, colors=None, iouts=None, msize=14,
+                     figname=None):
+        """Predicted-vs-data ('diagonal') figure per output, error bars from an `nmc`-member ensemble;
+        saved as `fitdiag_o<iout>.png` unless `figname` is given."""
+        import matplotlib
+        matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+        assert len(xx_list) == len(yy_list)
+        stats = [self._center_and_spread(self.predict_ens(xx, nens=nmc), plot_qt) for xx in xx_list]
+        nset, nout = len(xx_list), stats[0][0].shape[1]
+        labels = labels or [f'Set {i + 1}' for i in range(nset)]
+        colors = colors or (['b', 'g', 'r', 'c', 'm', 'y'] * nset)[:nset]
+        for iout in (range(nout) if iouts is None else iouts):
+            plt.figure(figsize=(10, 10))
+            lo = min(float(yy[:, iout].min()) for yy in yy_list)
+            hi = max(float(yy[:, iout].max()) for yy in yy_list)
+            plt.plot([lo, hi], [lo, hi], 'k--', linewidth=1)
+            for (mid, dl, du), yy, lab, col in zip(stats, yy_list, labels, colors):
+                plt.errorbar(yy[:, iout], mid[:, iout], yerr=[dl[:, iout], du[:, iout]], fmt=col + 'o', markersize=msize / 2,
+                             markeredgecolor='w', label=lab)
+            plt.xlabel(f'Model output # {iout + 1}')
+            plt.ylabel(f'Fit output # {iout + 1}')
+            plt.legend()
+            plt.savefig(figname or f'fitdiag_o{iout}.png')
+            plt.close()
+
+    def plot_1d_fits(self, xx_list, yy_list, domain=None, ngr=111, plot_qt=False, nmc=100, true_model=None,
+                     labels=None, colors=None, name_postfix=''):
+        """One-dimensional slices of the fit through the middle of the domain, one figure per (input, output),
+        saved as `fit_d<idim>_o<iout>_<name_postfix>.png`: data, ensemble members, centre and spread band."""
+        import matplotlib
+        matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+        assert len(xx_list) == len(yy_list)
+        nset = len(xx_list)
+        labels = labels or [f'Set {i + 1}' for i in range(nset)]
+        colors = colors or (['b', 'g', 'r', 'c', 'm', 'y'] * nset)[:nset]
+        if domain is None:
+            xall = np.vstack(xx_list)
+            domain = np.stack([xall.min(axis=0), xall.max(axis=0)], axis=1)
+        ndim, nout = xx_list[0].shape[1], yy_list[0].shape[1]
+        mid_label, band_label = ('Median Pred.', 'Qtile') if plot_qt else ('Mean Pred.', 'St.Dev.')
+        for idim in range(ndim):
+            unit = np.full((ngr, ndim), 0.5)
+            unit[:, idim] = np.linspace(0.0, 1.0, ngr)
+            xgrid = unit * (domain[:, 1] - domain[:, 0]) + domain[:, 0]
+            yens = self.predict_ens(xgrid, nens=nmc)
+            mid, dl, du = self._center_and_spread(yens, plot_qt)
+            for iout in range(nout):
+                plt.figure(figsize=(12, 8))
+                for xx, yy, lab, col in zip(xx_list, yy_list, labels, colors):
+                    plt.plot(xx[:, idim], yy[:, iout], col + 'o', markersize=13, markeredgecolor='w', label=lab, zorder=1000)
+                if true_model is not None:
+                    plt.plot(xgrid[:, idim], true_model(xgrid, 0.0)[:, iout], 'k-', alpha=0.5, label='Truth')
+                for member in yens:
+                    plt.plot(xgrid[:, idim], member[:, iout], 'm--', linewidth=1, zorder=-10000)
+                plt.plot(xgrid[:, idim], mid[:, iout], 'm-', linewidth=5, label=mid_label)
+                plt.fill_between(xgrid[:, idim], mid[:, iout] - dl[:, iout], mid[:, iout] + du[:, iout], color='plum',
+                                 alpha=0.9, zorder=-1000, label=band_label)
+                plt.legend()
+                plt.xlabel(f'Input # {idim + 1}')
+                plt.ylabel(f'Output # {iout + 1}')
+                plt.savefig(f'fit_d{idim}_o{iout}_{name_postfix}.png')
+                plt.close()
