@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (N=1 only)")
     ap.add_argument("--path", default="auto", choices=["auto", "generic", "fused"])
+    ap.add_argument("--graph", type=int, default=-1, help="capture this many consecutive steps in one HIP graph and "
+                    "replay it (0 = direct launches, -1 = the largest divisor of --steps up to 50)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,16 +173,42 @@ def main():
 
     for i in range(args.warmup):
         out = run(batches[i % NBATCH])
+    if args.graph < 0:
+        args.graph = max(g for g in range(1, 51) if args.steps % g == 0)
+        if args.graph == 1:
+            args.graph = 0
+    if args.graph:
+        # G consecutive steps (rotating over the resident weight batches) captured once and replayed
+        assert args.steps % args.graph == 0
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for i in range(NBATCH):
+                out = run(batches[i])
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(args.graph):
+                out = run(batches[i % NBATCH])
+        graph.replay()
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    nlaunch = args.steps // args.graph if args.graph else args.steps
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlaunch)]
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        out = run(batches[i % NBATCH])
-        ev[i][1].record()
+    if args.graph:
+        for i in range(nlaunch):
+            ev[i][0].record()
+            graph.replay()
+            ev[i][1].record()
+    else:
+        for i in range(args.steps):
+            ev[i][0].record()
+            out = run(batches[i % NBATCH])
+            ev[i][1].record()
     barrier()
     el = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # device time per launch group
+    # device time per step (one launch group = forward kernel + partial-sum kernel)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / (args.graph if args.graph else 1)
     lp_last = -neg_log_post_from_sse(out[0].cpu().numpy(), N, SIGMA)
     assert np.all(np.isfinite(lp_last))
 
@@ -217,6 +245,8 @@ def main():
                                    "regression; step = batched " + ("log-posterior+gradient" if want_grad else "log-posterior")
                                    + " of all 64 chains", "chains_per_gpu": CHAINS, "N": N, "dims": list(DIMS),
                        "kind": args.kind, "kernel_path": {1: "generic", 2: "fused"}.get(path, str(path)),
+                       "launch": (f"HIP graph of {args.graph} steps, replayed {args.steps // args.graph}x" if args.graph
+                                  else "direct launches"),
                        "parallelism": f"chains sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "flops_per_eval": flops, "evals_per_launch": CHAINS,
