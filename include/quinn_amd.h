@@ -169,13 +169,15 @@ int qn_mcmc_propose_hist(const double* cur, const float* hist, const float* wsna
  * by the absolute step, exactly as in qn_mcmc_propose_hist), not on the chain's state, so
  *   delta[c, t, :] = s_lr * sum_k wsnap[c,k] u_k^(step0+t) (hist[c,k,:] - msnap[c,:])
  * for t = 0..31 reads the history once: HBM traffic per step / 32, a (32 x K).(K x p) product per chain
- * (float32 accumulation).  coef: scratch of C * (ceil4(kcap) + 1) * 32 float32; delta: [C, 32, p] float64.
+ * (float32 accumulation).  step_ptr != NULL: step0 is read from the device step counter when the kernels
+ * run (a static launch, capturable in a HIP graph).  coef: scratch of C * (ceil4(kcap) + 1) * 32 float32; delta: [C, 32, p] float64.
  * qn_mcmc_apply_delta: out[c,:] = cur[c,:] + delta[c, t, :] + s_iso * v (the proposal of step step0 + t; v on the
  * stream of the CURRENT step *step_ptr, as in qn_mcmc_propose_hist; s_iso is unused by the block call). */
 int qn_mcmc_hist_block_steps(void);
 int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap, const int32_t* ksnap, const double* msnap,
                                double s_lr, double s_iso, int C, int chain0, int64_t p, int64_t pstride, int kcap,
-                               uint64_t seed, int64_t step0, float* coef, double* delta, void* stream);
+                               uint64_t seed, int64_t step0, const int64_t* step_ptr, float* coef, double* delta,
+                               void* stream);
 int qn_mcmc_apply_delta(const double* cur, const double* delta, int t, double s_iso, int C, int chain0, int64_t p,
                         uint64_t seed, const int64_t* step_ptr, double* out, void* stream);
 

@@ -166,6 +166,7 @@ constexpr int KB2 = 128;         // history rows per LDS chunk of coefficients
 struct HistBlockArgs {
     int chain0, kcap, kstride;   // coef [C][kstride][TB] (step fastest)
     int64_t p, pstride, step0;
+    const int64_t* step_ptr;     // non-NULL: the block starts at the CURRENT device step counter (static launch)
     double s_lr, s_iso;
     uint64_t seed;
 };
@@ -177,7 +178,8 @@ __global__ __launch_bounds__(BLK) void k_hist_coef(HistBlockArgs a, const float*
     const int kk = 2 * (blockIdx.x * BLK + threadIdx.x);
     if (kk >= K) return;
     Philox ph;
-    ph.gen(a.seed, 2 * (uint64_t)(a.step0 + t) + 1, ctr_of(a.chain0 + b, 3, (uint64_t)(kk >> 1)));
+    const int64_t step0 = a.step_ptr ? *a.step_ptr : a.step0;
+    ph.gen(a.seed, 2 * (uint64_t)(step0 + t) + 1, ctr_of(a.chain0 + b, 3, (uint64_t)(kk >> 1)));
     double za, zb;
     normal2(ph, za, zb);
     float* cb = coef + (int64_t)b * a.kstride * TB;
@@ -402,7 +404,7 @@ extern "C" int qn_mcmc_hist_block_steps(void) { return TB; }
 extern "C" int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap, const int32_t* ksnap,
                                           const double* msnap, double s_lr, double s_iso, int C, int chain0,
                                           int64_t p, int64_t pstride, int kcap, uint64_t seed, int64_t step0,
-                                          float* coef, double* delta, void* stream) {
+                                          const int64_t* step_ptr, float* coef, double* delta, void* stream) {
     if (!hist || !wsnap || !ksnap || !msnap || !coef || !delta || C <= 0 || C > 65535 || chain0 < 0 || p <= 0 || kcap <= 0 ||
         pstride < p || (pstride & 1) || step0 < 0) {
         qn_set_error("qn_mcmc_propose_hist_block: bad argument (pstride must be even and >= p)");
@@ -410,6 +412,7 @@ extern "C" int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap,
     }
     HistBlockArgs a;
     a.chain0 = chain0; a.kcap = kcap; a.kstride = (kcap + 3) / 4 * 4; a.p = p; a.pstride = pstride; a.step0 = step0;
+    a.step_ptr = step_ptr;
     a.s_lr = s_lr; a.s_iso = s_iso; a.seed = seed;
     hipStream_t st = static_cast<hipStream_t>(stream);
     (void)hipGetLastError();

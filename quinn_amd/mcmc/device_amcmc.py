@@ -7,8 +7,9 @@ proposal's ingredients and the chain history in HBM and never synchronises with 
 
   * one MH step = proposal kernel (in-kernel Philox normals) -> batched log-posterior kernel ->
     `qn_mcmc_accept` (accept test, state / MAP / history update); the step counter lives in device
-    memory, so the step is a static launch sequence that can also be captured in ONE HIP graph
-    (`use_graph=True`; direct launches are faster at cfg2 and the default);
+    memory, so a run of steps is a static launch sequence: 32 steps at a time are captured in ONE HIP
+    graph and replayed (`use_graph=True`, the default; a graph of a single step is slower than four direct
+    launches, a graph of 32 steps hides most of the launch gaps between dependent kernels);
   * initial proposal covariance 0.01 + diag(0.09|x0|) (admcmc.py:65) = diagonal + rank one:
     drawn exactly as sqrt(0.09|x0|) * z + 0.1 * z0 without forming a p x p matrix (`qn_mcmc_propose`);
   * adapted proposals are drawn in SAMPLE SPACE (`qn_mcmc_propose_hist`).  The reference's covariance
@@ -42,7 +43,7 @@ from ..ops import BatchedMLP
 
 class DeviceAMCMC:
     def __init__(self, op: BatchedMLP, sigma, gamma=0.1, t0=100, tadapt=1000, cov_ini=None, seed=0,
-                 use_graph=False, max_history_bytes=64 << 30, chain0=0):
+                 use_graph=True, max_history_bytes=64 << 30, chain0=0):
         if op.dtype != "float64":
             raise NotImplementedError("the device AMCMC engine runs the float64 operator")
         self.op, self.sigma = op, float(sigma)
@@ -72,11 +73,12 @@ class DeviceAMCMC:
             snap['mean'].data_ptr(), snap['s_lr'], snap['s_iso'], C, self.chain0, p, s['hist'].shape[2],
             s['hist'].shape[1], self.seed, s['step'].data_ptr(), out.data_ptr(), self._stream()), "qn_mcmc_propose_hist")
 
-    def _propose_hist_block(self, s, snap, step0, coef, delta):
+    def _propose_hist_block(self, s, snap, coef, delta):
         C, _, p = delta.shape
         _lib.check(self._L.qn_mcmc_propose_hist_block(
             s['hist'].data_ptr(), snap['w'].data_ptr(), snap['k'].data_ptr(), snap['mean'].data_ptr(), snap['s_lr'],
-            snap['s_iso'], C, self.chain0, p, s['hist'].shape[2], s['hist'].shape[1], self.seed, int(step0), coef.data_ptr(),
+            snap['s_iso'], C, self.chain0, p, s['hist'].shape[2], s['hist'].shape[1], self.seed, 0, s['step'].data_ptr(),
+            coef.data_ptr(),
             delta.data_ptr(), self._stream()), "qn_mcmc_propose_hist_block")
 
     def _apply_delta(self, s, snap, delta, t, out):
@@ -130,51 +132,32 @@ class DeviceAMCMC:
             z = torch.empty(C, p, dtype=f64, device=dev)
 
         TB = int(self._L.qn_mcmc_hist_block_steps())
-        blk = {'coef': None, 'delta': None, 'start': -1}
+        G = TB                                                              # steps per captured graph
+        coef = delta = None
 
-        def one_step(i=None):
-            if state['snap'] is not None and i is not None:
-                # increments of TB consecutive steps in one pass over the history (they do not depend on the
-                # chain's state); blocks restart at every adaptation
-                if blk['coef'] is None:
-                    blk['coef'] = torch.empty(C * ((kcap + 3) // 4 * 4 + 1) * TB, dtype=torch.float32, device=dev)
-                    blk['delta'] = torch.empty(C, TB, p, dtype=f64, device=dev)
-                if blk['start'] < 0 or i - blk['start'] >= TB:
-                    self._propose_hist_block(s, state['snap'], i, blk['coef'], blk['delta'])
-                    blk['start'] = i
-                self._apply_delta(s, state['snap'], blk['delta'], i - blk['start'], prop)
-            elif state['snap'] is not None:                                 # graph capture: one step at a time
-                self._propose_hist(s, state['snap'], prop)
-            elif state['L'] is not None:                                    # user-supplied initial covariance
+        def step_initial():
+            if state['L'] is not None:                                      # user-supplied initial covariance
                 self._propose(None, None, 0.0, s['step'], z)
                 prop.copy_(s['cur'] + z @ state['L'].T)
             else:
                 self._propose(s['cur'], std0, 0.1, s['step'], prop)
-            sse = self.op.sse(prop)
-            self._accept(s, prop, sse, nmcmc)
+            self._accept(s, prop, self.op.sse(prop), nmcmc)
 
-        graph = None
+        def block_adapted(nsteps):
+            # increments of TB consecutive steps in ONE pass over the history (they do not depend on the chain's
+            # state), then nsteps <= TB steps; the block starts at the device step counter
+            self._propose_hist_block(s, state['snap'], coef, delta)
+            for t in range(nsteps):
+                self._apply_delta(s, state['snap'], delta, t, prop)
+                self._accept(s, prop, self.op.sse(prop), nmcmc)
 
-        def make_graph():
-            if not self.use_graph:
-                return None
-            # warm-up on a side stream (allocator / library handles), then capture one step.  The warm-up
-            # step is a real step: rewind the counter and every piece of state afterwards (the chain /
-            # history rows it wrote are rewritten by the real step).
-            snap = {k: v.clone() for k, v in s.items() if k not in ('chain', 'hist') and isinstance(v, torch.Tensor)}
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                one_step()
-            torch.cuda.current_stream(dev).wait_stream(side)
+        def capture(fn):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                one_step()
-            torch.cuda.synchronize(dev)
-            for k, v in snap.items():                                      # capture itself does not execute
-                s[k].copy_(v)
+                fn()
             return g
 
+        graphs = {'initial': None, 'adapted': None}
         i = 0
         while i < nmcmc:
             if i > self.t0 and i % self.tadapt == 0:
@@ -183,16 +166,31 @@ class DeviceAMCMC:
                 state['snap'] = {'k': (s['kcur'] + 1).clone(), 'w': s['mult'].to(torch.float32).sqrt_(),
                                  'mean': s['sumx'] / (i + 1), 's_lr': float(np.sqrt(scale / i)),
                                  's_iso': float(np.sqrt(scale * 1e-8))}
-                graph = None                                               # new snapshot tensors: recapture
-                blk['start'] = -1
-            if self.use_graph and graph is None:
-                graph = make_graph()
+                graphs['adapted'] = None                                    # new snapshot tensors: recapture
+                if coef is None:
+                    coef = torch.empty(C * ((kcap + 3) // 4 * 4 + 1) * TB, dtype=torch.float32, device=dev)
+                    delta = torch.empty(C, TB, p, dtype=f64, device=dev)
             nrun = min(nmcmc, (i // self.tadapt + 1) * self.tadapt) - i     # up to the next adaptation
-            for k in range(nrun):
-                if graph is not None:
-                    graph.replay()
-                else:
-                    one_step(i + k)
+            adapted = state['snap'] is not None
+            nfull, rest = divmod(nrun, G)
+            if self.use_graph and nfull > 0 and (adapted or state['L'] is None):   # (torch matmul path: not captured)
+                # G steps = 4 G launches (+3 for the block kernels) captured once and replayed: the launch gaps of
+                # dependent kernels, ~6 us each when issued one by one, mostly disappear
+                key = 'adapted' if adapted else 'initial'
+                if graphs[key] is None:
+                    graphs[key] = capture((lambda: block_adapted(G)) if adapted
+                                          else (lambda: [step_initial() for _ in range(G)]))
+                for _ in range(nfull):
+                    graphs[key].replay()
+            else:
+                rest = nrun
+            if adapted:
+                while rest > 0:
+                    block_adapted(min(rest, TB))
+                    rest -= min(rest, TB)
+            else:
+                for _ in range(rest):
+                    step_initial()
             i += nrun
             if verbose:
                 print('%d / %d completed, acceptance rate %lg' % (i, nmcmc, float(s['nacc'].double().mean()) / i))
