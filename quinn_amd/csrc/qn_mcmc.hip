@@ -294,8 +294,10 @@ struct AcceptArgs {
     uint64_t seed;
 };
 
-// one workgroup per chain
-__global__ __launch_bounds__(BLK) void k_accept(AcceptArgs a, const double* __restrict__ prop,
+// one workgroup per chain, 1024 threads: the row updates are latency-bound (a handful of dependent 8-byte
+// accesses per element), so what counts is loads in flight per chain -- 256 threads took 41 us at p = 8513
+constexpr int ABLK = 1024;
+__global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __restrict__ prop,
                                                 const double* __restrict__ sse_prop, double* __restrict__ cur,
                                                 double* __restrict__ cur_lp, double* __restrict__ best,
                                                 double* __restrict__ best_lp, double* __restrict__ chain,
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(BLK) void k_accept(AcceptArgs a, const double* __re
     const int kc = hist ? kcur[b] : 0;
     const int knew = take ? kc + 1 : kc;
     float* hrow = (hist && take && knew < a.kcap) ? hist + ((int64_t)b * a.kcap + knew) * a.pstride : nullptr;
-    for (int64_t e = threadIdx.x; e < a.p; e += BLK) {
+    for (int64_t e = threadIdx.x; e < a.p; e += ABLK) {
         const double v = take ? prop[base + e] : cur[base + e];
         if (take) cur[base + e] = v;
         if (better) best[base + e] = v;
@@ -454,7 +456,7 @@ extern "C" int qn_mcmc_accept(const double* prop, const double* sse_prop, double
     a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
     a.chain0 = chain0; a.nmcmc = nmcmc; a.kcap = kcap; a.p = p; a.pstride = pstride; a.seed = seed;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_accept, dim3(C), dim3(BLK), 0, static_cast<hipStream_t>(stream), a, prop, sse_prop, cur, cur_lp,
+    hipLaunchKernelGGL(k_accept, dim3(C), dim3(ABLK), 0, static_cast<hipStream_t>(stream), a, prop, sse_prop, cur, cur_lp,
                        best, best_lp, chain, lps, alphas, nacc, x0, hist, mult, kcur, sumx, step_ptr);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;

@@ -7,9 +7,9 @@ proposal's ingredients and the chain history in HBM and never synchronises with 
 
   * one MH step = proposal kernel (in-kernel Philox normals) -> batched log-posterior kernel ->
     `qn_mcmc_accept` (accept test, state / MAP / history update); the step counter lives in device
-    memory, so a run of steps is a static launch sequence: 32 steps at a time are captured in ONE HIP
-    graph and replayed (`use_graph=True`, the default; a graph of a single step is slower than four direct
-    launches, a graph of 32 steps hides most of the launch gaps between dependent kernels);
+    memory, so a run of steps is a static launch sequence; `use_graph=True` captures 32 steps at a time in
+    ONE HIP graph and replays it (measured at cfg2: no faster than direct launches -- the host keeps the
+    queue full either way -- so direct launching is the default);
   * initial proposal covariance 0.01 + diag(0.09|x0|) (admcmc.py:65) = diagonal + rank one:
     drawn exactly as sqrt(0.09|x0|) * z + 0.1 * z0 without forming a p x p matrix (`qn_mcmc_propose`);
   * adapted proposals are drawn in SAMPLE SPACE (`qn_mcmc_propose_hist`).  The reference's covariance
@@ -43,7 +43,7 @@ from ..ops import BatchedMLP
 
 class DeviceAMCMC:
     def __init__(self, op: BatchedMLP, sigma, gamma=0.1, t0=100, tadapt=1000, cov_ini=None, seed=0,
-                 use_graph=True, max_history_bytes=64 << 30, chain0=0):
+                 use_graph=False, max_history_bytes=64 << 30, chain0=0):
         if op.dtype != "float64":
             raise NotImplementedError("the device AMCMC engine runs the float64 operator")
         self.op, self.sigma = op, float(sigma)
