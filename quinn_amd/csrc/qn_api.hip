@@ -57,6 +57,32 @@ extern "C" int qn_mlp_desc_create(const int* dims, int ndims, int act, int has_b
     }
     d->p = off;
     d->kind = QN_KIND_MLP;
+    d->padded = nullptr;
+    // hidden widths <= 64 that are not one common 16 / 32 / 64: zero-padded twin for the fused kernels
+    if (d->nlayers >= 2) {
+        int hmax = 0;
+        bool uniform = true;
+        for (int l = 1; l < d->nlayers; ++l) {
+            hmax = d->dims[l] > hmax ? d->dims[l] : hmax;
+            uniform = uniform && d->dims[l] == d->dims[1];
+        }
+        const int H = hmax <= 16 ? 16 : hmax <= 32 ? 32 : 64;
+        if (hmax <= 64 && !(uniform && hmax == H)) {
+            qn_desc* q = new qn_desc(*d);
+            int64_t o2 = 0;
+            for (int l = 1; l < q->nlayers; ++l) q->dims[l] = H;
+            for (int l = 0; l < q->nlayers; ++l) {
+                q->offW[l] = o2;
+                o2 += (int64_t)q->dims[l] * q->dims[l + 1];
+                q->offB[l] = o2;
+                if (q->has_bias) o2 += q->dims[l + 1];
+            }
+            q->p = o2;
+            q->hmax = H > q->dims[q->nlayers] ? H : q->dims[q->nlayers];
+            q->padded = nullptr;
+            d->padded = q;
+        }
+    }
     *out = d;
     return QN_OK;
 }
@@ -96,21 +122,108 @@ extern "C" int qn_rnet_desc_create(int indim, int rdim, int outdim, int nsteps, 
     d->rn_offWW = off; off += (int64_t)npar * rdim * rdim;
     d->rn_offBB = off; if (has_bias) off += (int64_t)npar * rdim;
     d->p = off;
+    d->padded = nullptr;
     *out = d;
     return QN_OK;
 }
 
 extern "C" int qn_mlp_desc_destroy(qn_desc* d) {
+    if (d) delete d->padded;
     delete d;
     return QN_OK;
 }
 
 extern "C" int64_t qn_mlp_num_params(const qn_desc* d) { return d ? d->p : -1; }
 
-static bool use_fused(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
-    if (d->kind != QN_KIND_MLP || g_forced_path.load() == QN_PATH_GENERIC) return false;
-    return qn_fused_supported(d, B, Nb, want_grad, dtype);
+// the descriptor the fused kernels would run: the network itself, or its zero-padded twin
+static const qn_desc* fused_desc(const qn_desc* d) { return d->padded ? d->padded : d; }
+static bool fused_ok(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
+    return d->kind == QN_KIND_MLP && qn_fused_supported(fused_desc(d), B, Nb, want_grad, dtype);
 }
+static bool use_fused(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
+    if (g_forced_path.load() == QN_PATH_GENERIC) return false;
+    return fused_ok(d, B, Nb, want_grad, dtype);
+}
+static size_t fused_ws(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
+    size_t tot = qn_fused_workspace(fused_desc(d), B, Nb, want_grad, dtype);
+    if (d->padded) tot += (want_grad ? 2 : 1) * qn_align((size_t)B * d->padded->p * sizeof(double));
+    return tot;
+}
+
+// ---- zero-padding of hidden layers (weights in, gradients out); one thread per element, layer found by offset
+namespace {
+struct PadMap {
+    int L, has_bias;
+    int hin[QN_MAX_LAYERS], hout[QN_MAX_LAYERS], Hin[QN_MAX_LAYERS], Hout[QN_MAX_LAYERS];
+    int64_t off[QN_MAX_LAYERS + 1], offp[QN_MAX_LAYERS + 1], p, pp;
+};
+__global__ void k_pad_weights(PadMap m, const double* __restrict__ W, double* __restrict__ Wp) {
+    const int b = blockIdx.y;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m.pp; e += (int64_t)gridDim.x * blockDim.x) {
+        int l = 0;
+        while (l + 1 < m.L && e >= m.offp[l + 1]) ++l;
+        const int64_t loc = e - m.offp[l], nW = (int64_t)m.Hout[l] * m.Hin[l];
+        double v = 0.0;
+        if (loc < nW) {
+            const int j = (int)(loc / m.Hin[l]), i = (int)(loc % m.Hin[l]);
+            if (j < m.hout[l] && i < m.hin[l]) v = W[(int64_t)b * m.p + m.off[l] + (int64_t)j * m.hin[l] + i];
+        } else {
+            const int j = (int)(loc - nW);
+            if (j < m.hout[l]) v = W[(int64_t)b * m.p + m.off[l] + (int64_t)m.hout[l] * m.hin[l] + j];
+        }
+        Wp[(int64_t)b * m.pp + e] = v;
+    }
+}
+__global__ void k_unpad_grad(PadMap m, const double* __restrict__ Gp, double* __restrict__ G) {
+    const int b = blockIdx.y;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m.p; e += (int64_t)gridDim.x * blockDim.x) {
+        int l = 0;
+        while (l + 1 < m.L && e >= m.off[l + 1]) ++l;
+        const int64_t loc = e - m.off[l], nW = (int64_t)m.hout[l] * m.hin[l];
+        int64_t src;
+        if (loc < nW) src = m.offp[l] + (loc / m.hin[l]) * m.Hin[l] + loc % m.hin[l];
+        else src = m.offp[l] + (int64_t)m.Hout[l] * m.Hin[l] + (loc - nW);
+        G[(int64_t)b * m.p + e] = Gp[(int64_t)b * m.pp + src];
+    }
+}
+PadMap pad_map(const qn_desc* d) {
+    const qn_desc* q = d->padded;
+    PadMap m;
+    m.L = d->nlayers; m.has_bias = d->has_bias; m.p = d->p; m.pp = q->p;
+    for (int l = 0; l < d->nlayers; ++l) {
+        m.hin[l] = d->dims[l]; m.hout[l] = d->dims[l + 1]; m.Hin[l] = q->dims[l]; m.Hout[l] = q->dims[l + 1];
+        m.off[l] = d->offW[l]; m.offp[l] = q->offW[l];
+    }
+    m.off[d->nlayers] = d->p; m.offp[d->nlayers] = q->p;
+    return m;
+}
+// pad -> fused kernels on the padded twin -> unpad the gradient
+int run_padded(const qn_desc* d, const double* W, const void* X, const void* Y, const int32_t* row_idx, int B, int N,
+               int Nb, double* sse, void* pred, double* gradW, void* ws, size_t ws_bytes, hipStream_t st) {
+    const qn_desc* q = d->padded;
+    const size_t wbytes = qn_align((size_t)B * q->p * sizeof(double));
+    const size_t head = (gradW ? 2 : 1) * wbytes;
+    if (head > ws_bytes) {
+        qn_set_error("workspace too small: need more than %zu bytes, got %zu", head, ws_bytes);
+        return QN_EWORKSPACE;
+    }
+    double* Wp = static_cast<double*>(ws);
+    double* Gp = gradW ? reinterpret_cast<double*>(static_cast<char*>(ws) + wbytes) : nullptr;
+    const PadMap m = pad_map(d);
+    (void)hipGetLastError();
+    int gx = (int)((q->p + 255) / 256);
+    hipLaunchKernelGGL(k_pad_weights, dim3(gx > 64 ? 64 : gx, B), dim3(256), 0, st, m, W, Wp);
+    const int rc = qn_fused_run(q, QN_F64, Wp, X, Y, row_idx, B, N, Nb, sse, pred, Gp, static_cast<char*>(ws) + head,
+                                ws_bytes - head, st);
+    if (rc) return rc;
+    if (gradW) {
+        gx = (int)((d->p + 255) / 256);
+        hipLaunchKernelGGL(k_unpad_grad, dim3(gx > 64 ? 64 : gx, B), dim3(256), 0, st, m, (const double*)Gp, gradW);
+    }
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
+}  // namespace
 
 extern "C" int qn_mlp_path(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
     if (!d) return QN_EINVAL;
@@ -122,7 +235,7 @@ extern "C" size_t qn_workspace_bytes(const qn_desc* d, int B, int Nb, int want_g
     if (d->kind == QN_KIND_RNET) return qn_rnet_workspace(d, B, Nb, want_grad, dtype);
     // sized for either family so that qn_set_path never invalidates a caller's buffer
     size_t g = qn_generic_workspace(d, B, Nb, want_grad, dtype);
-    size_t f = qn_fused_supported(d, B, Nb, want_grad, dtype) ? qn_fused_workspace(d, B, Nb, want_grad, dtype) : 0;
+    size_t f = fused_ok(d, B, Nb, want_grad, dtype) ? fused_ws(d, B, Nb, want_grad, dtype) : 0;
     if (g_forced_path.load() == QN_PATH_AUTO && f) return f;
     return g > f ? g : f;
 }
@@ -157,12 +270,15 @@ static int run(const char* fn, const qn_desc* d, int dtype, const void* W, const
     const int want_grad = gradW != nullptr;
     if (d->kind == QN_KIND_RNET)
         return qn_rnet_run(d, dtype, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
-    if (g_forced_path.load() == QN_PATH_FUSED && !qn_fused_supported(d, B, Nb, want_grad, dtype)) {
+    if (g_forced_path.load() == QN_PATH_FUSED && !fused_ok(d, B, Nb, want_grad, dtype)) {
         qn_set_error("%s: fused path forced but not supported for this shape", fn);
         return QN_EUNSUPPORTED;
     }
-    if (use_fused(d, B, Nb, want_grad, dtype))
+    if (use_fused(d, B, Nb, want_grad, dtype)) {
+        if (d->padded)
+            return run_padded(d, (const double*)W, X, Y, row_idx, B, N, Nb, sse, pred, (double*)gradW, ws, ws_bytes, st);
         return qn_fused_run(d, dtype, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
+    }
     return qn_generic_run(d, dtype, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
 }
 

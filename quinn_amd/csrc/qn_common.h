@@ -23,6 +23,9 @@ struct qn_desc {
     int rn_r, rn_steps, rn_npar, rn_pre, rn_post, rn_mlp;
     int64_t rn_offWpre, rn_offBpre, rn_offWpost, rn_offBpost, rn_offWW, rn_offBB;
     double rn_coef[QN_MAX_LAYERS * QN_MAX_LAYERS];   // [steps][npar]: W_i = sum_k coef[i][k] * ww_k
+    // ---- MLP whose hidden widths are <= 64 but not all equal to 16 / 32 / 64: the same network with every hidden
+    // layer zero-padded to one of those widths, which the fused kernels take (qn_api.hip: pad -> fused -> unpad)
+    qn_desc* padded;
 };
 enum { QN_KIND_MLP = 0, QN_KIND_RNET = 1 };
 

@@ -1,6 +1,7 @@
 """GPU: randomized cross-check of the two kernel families (fused MFMA vs layer-wise) over shapes the
 fused family supports: hidden width 16/32/64, 1-4 hidden layers, d, o in 1..4, every activation, with
-and without bias, ragged row counts, per-member row subsets.  float64; SSE 1e-12, gradient 1e-10."""
+and without bias, ragged row counts, per-member row subsets; plus hidden widths that the library zero-pads to
+those (any width <= 64, non-uniform).  float64; SSE 1e-12, gradient 1e-10."""
 import numpy as np
 import pytest
 import torch
@@ -26,7 +27,20 @@ def _cases(n=36, seed=123):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(), ids=lambda c: f"{c[0]}-{c[1]}-b{int(c[2])}-N{c[3]}-B{c[4]}-idx{int(c[5])}")
+def _ragged_cases():
+    """Hidden widths that are not one common 16 / 32 / 64: the library zero-pads them for the fused kernels."""
+    shapes = [(1, 11, 11, 11, 1), (2, 50, 3), (1, 20, 40, 10, 1), (3, 64, 32, 2), (1, 3, 1), (4, 33, 17, 64, 5, 4),
+              (1, 64, 64, 63, 1), (2, 1, 1, 2)]
+    rs = np.random.RandomState(7)
+    out = []
+    for k, dims in enumerate(shapes):
+        act = ["tanh", "relu", "identity"][k % 3]
+        out.append((dims, act, k % 4 != 3, int(rs.choice([1, 37, 130, 400])), int(rs.randint(1, 6)), k % 2 == 1))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases() + _ragged_cases(),
+                         ids=lambda c: f"{c[0]}-{c[1]}-b{int(c[2])}-N{c[3]}-B{c[4]}-idx{int(c[5])}")
 def test_fused_equals_generic(case):
     dims, act, bias, N, B, use_idx = case
     rs = np.random.RandomState(sum(dims) * 1000 + N * 7 + B)           # deterministic per case
