@@ -29,7 +29,7 @@ def _cases(n=36, seed=123):
 
 def _ragged_cases():
     """Hidden widths that are not one common 16 / 32 / 64: the library zero-pads them for the fused kernels."""
-    shapes = [(1, 11, 11, 11, 1), (2, 50, 3), (1, 20, 40, 10, 1), (3, 64, 32, 2), (1, 3, 1), (4, 33, 17, 64, 5, 4),
+    shapes = [(1, 11, 11, 11, 1), (2, 50, 3), (1, 20, 40, 10, 1), (3, 64, 32, 2), (1, 3, 1), (4, 33, 17, 64, 4),
               (1, 64, 64, 63, 1), (2, 1, 1, 2)]
     rs = np.random.RandomState(7)
     out = []
