@@ -45,6 +45,29 @@ def test_device_engine_invariants_and_adaptation():
     assert np.all(lps[:, -200:].mean(axis=1) > lps[:, 0])                   # chains climbed from the random start
 
 
+def test_device_normals_are_standard_normal():
+    """The in-kernel Philox + float32 Box-Muller normals (qn_mcmc_propose with cur = NULL writes them out)."""
+    from quinn_amd import _lib
+    L = _lib.lib()
+    C, p = 512, 8191                                                        # odd p: the last pair is half used
+    z = torch.empty(C, p, dtype=torch.float64, device="cuda")
+    step = torch.zeros(2, dtype=torch.int64, device="cuda"); step[0] = 3
+    _lib.check(L.qn_mcmc_propose(None, None, 0.0, C, 0, p, 99, step.data_ptr(), z.data_ptr(), None), "propose")
+    torch.cuda.synchronize()
+    v = z.cpu().numpy().ravel()
+    n = v.size
+    assert np.isfinite(v).all() and abs(v).max() < 8.5
+    assert abs(v.mean()) < 5 / np.sqrt(n) and abs(v.var() - 1) < 5 * np.sqrt(2 / n)
+    assert abs((v ** 3).mean()) < 5 * np.sqrt(15 / n) and abs((v ** 4).mean() - 3) < 5 * np.sqrt(96 / n)
+    assert abs(np.mean(np.abs(v) > 3) - 0.0026998) < 5 * np.sqrt(0.0027 / n)     # tail mass
+    zc = z.cpu().numpy()
+    assert abs(np.corrcoef(zc[:, 0], zc[:, 1])[0, 1]) < 0.2 and abs(np.corrcoef(zc[0], zc[1])[0, 1]) < 0.06
+    z2 = torch.empty_like(z)
+    step[0] = 4
+    _lib.check(L.qn_mcmc_propose(None, None, 0.0, C, 0, p, 99, step.data_ptr(), z2.data_ptr(), None), "propose")
+    assert not torch.equal(z, z2)
+
+
 def test_sample_space_proposal_kernel_covariance_and_history_tracking():
     """qn_mcmc_propose_hist draws N(cur, c (cov + 1e-8 I)) for the history described by (hist, mult, mean):
     empirical covariance over many independent streams vs numpy's covariance of the expanded history."""
