@@ -17,7 +17,7 @@ x = rs.rand(N, 1) * 2 * np.pi - np.pi
 y = 0.02 * rs.randn(N, 1) + np.sin(x)
 op = BatchedMLP(arch, x, y)
 ini = np.stack([np.random.RandomState(1000 + c).rand(arch.nparams) for c in range(C)])
-UG = os.environ.get("USE_GRAPH", "1") == "1"
+UG = os.environ.get("USE_GRAPH", "0") == "1"
 res = {"use_graph": UG, "nmcmc": NMCMC}
 eng = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=1000, seed=1, use_graph=UG)
 eng.run(20, ini, store_chain=True)                      # warm-up (first launches)
