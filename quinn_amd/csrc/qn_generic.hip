@@ -291,6 +291,10 @@ __global__ __launch_bounds__(BLK) void k_gemm64(GemmArgs g, const T* __restrict_
     // from a clamped, valid address instead of masking: those output columns are never stored.
     constexpr int NE = GKB / 4;                 // doubles per thread and operand per K-step
     T pr[NE], qr[NE];
+    // DW, i-tile 0 only: the bias gradient db[j] = sum_n dz[j][n] is the row sum of the P operand, which passes
+    // through this thread's registers anyway (thread = row tid>>2, a quarter of each K-step)
+    const bool want_rowsum = MODE == GEMM_DW && g.has_bias && n0 == 0;
+    T rsum = T(0);
     const int ncl = Nb - 1;
     auto gload = [&](int k0) {
         if (MODE == GEMM_FWD) {          // P[m][k] = W[j0+m][k0+k];  Q[k][n] = in[k0+k][n0+n]
@@ -325,6 +329,10 @@ __global__ __launch_bounds__(BLK) void k_gemm64(GemmArgs g, const T* __restrict_
                 for (int u = 0; u < NE; ++u) pr[u] = k0 + kq + u < kend ? ps[u] : T(0);
 #pragma unroll
                 for (int u = 0; u < NE; ++u) qr[u] = k0 + kq2 + u < kend ? qs[u] : T(0);
+            }
+            if (want_rowsum) {
+#pragma unroll
+                for (int u = 0; u < NE; ++u) rsum += pr[u];
             }
         }
     };
@@ -414,6 +422,13 @@ __global__ __launch_bounds__(BLK) void k_gemm64(GemmArgs g, const T* __restrict_
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) orow[16 * ni] = acc[mi][ni][r];
             }
+        if (want_rowsum) {          // 4 adjacent lanes hold the quarters of one row; bias block follows the weights
+            rsum += __shfl_xor(rsum, 1, 64);
+            rsum += __shfl_xor(rsum, 2, 64);
+            if ((tid & 3) == 0)
+                out[(int64_t)b * g.out_stride_b + (int64_t)slab * g.out_stride_k + (int64_t)g.h_out * g.h_in + m0 +
+                    (tid >> 2)] = rsum;
+        }
         return;
     }
     const int hrows = MODE == GEMM_FWD ? g.h_out : g.h_in;
@@ -488,25 +503,6 @@ __global__ __launch_bounds__(BLK) void k_gemm64(GemmArgs g, const T* __restrict_
     }
 }
 
-// db[b][j] = sum_n dz[b][j][n]   (one block per (j, b); fixed-order reduction)
-template <typename T>
-__global__ __launch_bounds__(BLK) void k_rowsum(const T* __restrict__ dz, int h, int Nb, int64_t p, int64_t offB,
-                                                T* __restrict__ gradW) {
-    __shared__ double red[BLK / 64];
-    const int j = blockIdx.x, b = blockIdx.y;
-    const T* row = dz + ((int64_t)b * h + j) * Nb;
-    double s = 0.0;
-    for (int n = threadIdx.x; n < Nb; n += BLK) s += (double)row[n];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < BLK / 64; ++w) t += red[w];
-        gradW[(int64_t)b * p + offB + j] = (T)t;
-    }
-}
-
 // gradW[b][off + e] = sum_k slab[b][k][e]
 template <typename T>
 __global__ __launch_bounds__(BLK) void k_slab_reduce(const T* __restrict__ slab, int ksplit, int64_t n, int64_t p,
@@ -565,7 +561,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
             if (gemm_layer(d, l)) {
                 const int tiles = (d->dims[l] / 64) * (d->dims[l + 1] / 64);
                 const int ks = dw_ksplit(B, tiles, Nb);
-                if (ks > 1) need = std::max(need, (size_t)B * ks * d->dims[l] * d->dims[l + 1]);
+                if (ks > 1) need = std::max(need, (size_t)B * ks * ((size_t)d->dims[l] * d->dims[l + 1] + d->dims[l + 1]));
             }
         if (need) dwslab = c.take<T>(need);
     }
@@ -617,7 +613,8 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                 GemmArgs g = gargs(l);
                 const int tiles = (g.h_in / 64) * (g.h_out / 64);
                 const int ks = dw_ksplit(B, tiles, Nb);
-                const int64_t nW = (int64_t)g.h_in * g.h_out;
+                // weights and (if any) the bias block behind them: contiguous in the flat layout and in a slab
+                const int64_t nW = (int64_t)g.h_in * g.h_out + (d->has_bias ? g.h_out : 0);
                 g.ksplit = ks;
                 g.kchunk = ((Nb + ks - 1) / ks + GKB - 1) / GKB * GKB;
                 T* dst = gradW + d->offW[l];
@@ -631,9 +628,6 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                     hipLaunchKernelGGL(k_slab_reduce<T>, dim3(gx, B), dim3(BLK), 0, st, (const T*)dwslab, ks, nW, d->p,
                                        d->offW[l], gradW);
                 }
-                if (d->has_bias)
-                    hipLaunchKernelGGL(k_rowsum<T>, dim3(g.h_out, B), dim3(BLK), 0, st, dz, g.h_out, Nb, d->p,
-                                       d->offB[l], gradW);
                 T* dzp = dzbuf[l & 1];
                 g.ksplit = 1; g.kchunk = Nb;
                 hipLaunchKernelGGL((k_gemm64<T, GEMM_DA>), dim3(gemm_grid(g, g.h_in / 64, (Nb + 63) / 64, B)), dim3(BLK), 0,
@@ -862,7 +856,7 @@ size_t qn_generic_workspace(const qn_desc* d, int B, int Nb, int want_grad, int 
             if (gemm_layer(d, l)) {
                 const int tiles = (d->dims[l] / 64) * (d->dims[l + 1] / 64);
                 const int ks = dw_ksplit(B, tiles, Nb);
-                if (ks > 1) need = std::max(need, (size_t)B * ks * d->dims[l] * d->dims[l + 1]);
+                if (ks > 1) need = std::max(need, (size_t)B * ks * ((size_t)d->dims[l] * d->dims[l + 1] + d->dims[l + 1]));
             }
         tot += qn_align(need * e);
     }
