@@ -114,7 +114,10 @@ class NN_MCMC(QUiNNBase):
             draw = (lambda r: r.rand(self.pdim)) if rngs else (lambda r: np.random.rand(self.pdim))
             inis = [draw(r) for r in (rngs or [None])]
             if zflag:
+                # BFGS pre-fit of the random start (nn_mcmc.py:125-127).  The reference lets scipy difference the
+                # log-posterior (p + 1 evaluations per gradient); here the gradient kernel is the jacobian
                 inis = [minimize((lambda x, fcn, lpinfo: -fcn(x, lpinfo)), ini, args=(self.logpost, self.lpinfo),
+                                 jac=(lambda x, fcn, lpinfo: -self.logpostgrad(x, lpinfo)),
                                  method='BFGS', options={'gtol': 1e-13}).x for ini in inis]
             param_ini = np.stack(inis) if rngs else inis[0]
         param_ini = np.asarray(param_ini, dtype=np.float64)

@@ -113,5 +113,9 @@ def test_zflag_bfgs_and_single_vector_api():
     np.random.seed(42)
     small.fit(x, np.sin(3 * x), zflag=True, datanoise=0.1, nmcmc=200, sampler='amcmc', sampler_params={})
     assert small.samples.shape == (201, small.pdim) and small.cmode.shape == (small.pdim,)
+    # the BFGS pre-fit (device gradient as jacobian) starts the chain near a mode: far above a random start
+    lp0 = small.mcmc_results['logpost'][0]
+    rnd = np.mean([small.logpost(np.random.RandomState(s).rand(small.pdim), small.lpinfo) for s in range(5)])
+    assert lp0 > rnd + 10.0, (lp0, rnd)
     assert small.predict_ens(x, nens=5, nburn=100).shape == (5, 20, 1)
     assert small.predict_MAP(x).shape == (20, 1)
