@@ -363,14 +363,14 @@ __global__ __launch_bounds__(BLK) void k_accept(AcceptArgs a, const double* __re
             lps[(int64_t)b * (a.nmcmc + 1) + step + 1] = nlp;
             alphas[(int64_t)b * (a.nmcmc + 1) + step + 1] = mh;
             if (take) nacc[b] += 1;
-            // the step counter is advanced by the last CHAIN to finish (one contended atomic per chain, not per block;
-            // every block has read the counter at entry, before its chain could be counted)
-            __threadfence();
-            const unsigned int arrived = atomicAdd(reinterpret_cast<unsigned int*>(step_ptr + 1), 1u);
-            if (arrived == gridDim.y - 1) {
-                reinterpret_cast<unsigned int*>(step_ptr + 1)[0] = 0u;
-                *step_ptr = step + 1;
-            }
+        }
+        // the step counter is advanced by the last block of the GRID to get here (all blocks have read it already:
+        // it is read at kernel entry and the increment happens after a device-scope arrival count)
+        __threadfence();
+        const unsigned int arrived = atomicAdd(reinterpret_cast<unsigned int*>(step_ptr + 1), 1u);
+        if (arrived == gridDim.x * gridDim.y - 1) {
+            reinterpret_cast<unsigned int*>(step_ptr + 1)[0] = 0u;
+            *step_ptr = step + 1;
         }
     }
 }
