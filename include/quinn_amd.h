@@ -144,13 +144,12 @@ int qn_mcmc_propose(const double* cur, const double* sd, double c1, int C, int c
  *   (qn_mcmc_propose_hist): hist [C, kcap, pstride] float32 = the DISTINCT states visited, minus x0
  *   (row 0 = the start, a new row per accepted move), mult [C, kcap] their multiplicities in the
  *   chain so far, kcur [C] the index of the current state's row, sumx [C, p] the running sum of
- *   (x_i - x0) over all samples.  kcur[c] >= kcap means the history is full (rows are not stored).
- *   arrive [C] int32: scratch of the kernel, zero before the first call (it resets itself). */
+ *   (x_i - x0) over all samples.  kcur[c] >= kcap means the history is full (rows are not stored). */
 int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int chain0, int64_t p,
                    int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
                    double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0, float* hist,
-                   int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride, int32_t* arrive,
-                   int64_t* step_ptr, void* stream);
+                   int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride, int64_t* step_ptr,
+                   void* stream);
 
 /* qn_mcmc_propose_hist: the ADAPTED proposal of adaptive Metropolis (admcmc.py:52-70), drawn in sample
  *   space.  After an adaptation at step i the reference proposes from N(x, c (cov_i + 1e-8 I)) with

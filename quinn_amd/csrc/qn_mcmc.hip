@@ -299,13 +299,10 @@ struct AcceptArgs {
     uint64_t seed;
 };
 
-// grid (chunks, chains): the row updates are latency-bound (a handful of dependent 8-byte accesses per element), so
-// what counts is loads in flight -- one 256-thread workgroup per chain took 41 us at p = 8513, a 1024-thread one
-// 18 us.  Every block of a chain takes the same accept decision from the same scalars (read at entry); the LAST
-// block of the chain to finish (arrival counter arrive[c], self-resetting) writes the chain's scalars back, so no
-// block can see them half updated.
-constexpr int ACH = 4 * BLK;            // elements per block
-__global__ __launch_bounds__(BLK) void k_accept(AcceptArgs a, const double* __restrict__ prop,
+// one workgroup per chain, 1024 threads: the row updates are latency-bound (a handful of dependent 8-byte
+// accesses per element), so what counts is loads in flight per chain -- 256 threads took 41 us at p = 8513
+constexpr int ABLK = 1024;
+__global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __restrict__ prop,
                                                 const double* __restrict__ sse_prop, double* __restrict__ cur,
                                                 double* __restrict__ cur_lp, double* __restrict__ best,
                                                 double* __restrict__ best_lp, double* __restrict__ chain,
@@ -313,8 +310,8 @@ __global__ __launch_bounds__(BLK) void k_accept(AcceptArgs a, const double* __re
                                                 int64_t* __restrict__ nacc, const double* __restrict__ x0,
                                                 float* __restrict__ hist, int32_t* __restrict__ mult,
                                                 int32_t* __restrict__ kcur, double* __restrict__ sumx,
-                                                int32_t* __restrict__ arrive, int64_t* __restrict__ step_ptr) {
-    const int b = blockIdx.y;
+                                                int64_t* __restrict__ step_ptr) {
+    const int b = blockIdx.x;
     const int64_t step = *step_ptr;
     const double plp = -(a.half_inv_sig2 * sse_prop[b] + a.lp_const);
     const double clp = cur_lp[b];
@@ -332,8 +329,7 @@ __global__ __launch_bounds__(BLK) void k_accept(AcceptArgs a, const double* __re
     const int kc = hist ? kcur[b] : 0;
     const int knew = take ? kc + 1 : kc;
     float* hrow = (hist && take && knew < a.kcap) ? hist + ((int64_t)b * a.kcap + knew) * a.pstride : nullptr;
-    const int64_t e1 = ((int64_t)blockIdx.x + 1) * ACH < a.p ? ((int64_t)blockIdx.x + 1) * ACH : a.p;
-    for (int64_t e = (int64_t)blockIdx.x * ACH + threadIdx.x; e < e1; e += BLK) {
+    for (int64_t e = threadIdx.x; e < a.p; e += ABLK) {
         const double v = take ? prop[base + e] : cur[base + e];
         if (take) cur[base + e] = v;
         if (better) best[base + e] = v;
@@ -346,29 +342,28 @@ __global__ __launch_bounds__(BLK) void k_accept(AcceptArgs a, const double* __re
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
-        const bool chain_last = atomicAdd(reinterpret_cast<unsigned int*>(arrive + b), 1u) == gridDim.x - 1;
-        if (chain_last) {
-            arrive[b] = 0;
-            if (hist) {
-                if (take) {
-                    kcur[b] = knew;                                 // knew >= kcap: history full, the host checks
-                    if (knew < a.kcap) mult[(int64_t)b * a.kcap + knew] = 1;
-                } else if (kc < a.kcap) {
-                    mult[(int64_t)b * a.kcap + kc] += 1;
-                }
+        if (hist) {
+            if (take) {
+                kcur[b] = knew;                                     // knew >= kcap: history full, the host checks
+                if (knew < a.kcap) mult[(int64_t)b * a.kcap + knew] = 1;
+            } else if (kc < a.kcap) {
+                mult[(int64_t)b * a.kcap + kc] += 1;
             }
-            cur_lp[b] = nlp;
-            if (better) best_lp[b] = nlp;
-            lps[(int64_t)b * (a.nmcmc + 1) + step + 1] = nlp;
-            alphas[(int64_t)b * (a.nmcmc + 1) + step + 1] = mh;
-            if (take) nacc[b] += 1;
         }
-        // the step counter is advanced by the last block of the GRID to get here (all blocks have read it already:
-        // it is read at kernel entry and the increment happens after a device-scope arrival count)
+        cur_lp[b] = nlp;
+        if (better) best_lp[b] = nlp;
+        lps[(int64_t)b * (a.nmcmc + 1) + step + 1] = nlp;
+        alphas[(int64_t)b * (a.nmcmc + 1) + step + 1] = mh;
+        if (take) nacc[b] += 1;
+    }
+    // the step counter is advanced by the last block to get here (all blocks have read it already:
+    // it is read at kernel entry and the increment happens after a device-scope arrival count)
+    __shared__ int last;
+    if (threadIdx.x == 0) {
         __threadfence();
         const unsigned int arrived = atomicAdd(reinterpret_cast<unsigned int*>(step_ptr + 1), 1u);
-        if (arrived == gridDim.x * gridDim.y - 1) {
+        last = arrived == (unsigned int)(gridDim.x - 1);
+        if (last) {
             reinterpret_cast<unsigned int*>(step_ptr + 1)[0] = 0u;
             *step_ptr = step + 1;
         }
@@ -455,9 +450,9 @@ extern "C" int qn_mcmc_accept(const double* prop, const double* sse_prop, double
                               int64_t p, int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
                               double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0,
                               float* hist, int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride,
-                              int32_t* arrive, int64_t* step_ptr, void* stream) {
-    if (!prop || !sse_prop || !cur || !cur_lp || !best || !best_lp || !lps || !alphas || !nacc || !step_ptr || !arrive ||
-        C <= 0 || C > 65535 || chain0 < 0 || p <= 0 || sigma <= 0.0 || (hist && (!x0 || !mult || !kcur || !sumx || kcap <= 0 || pstride < p))) {
+                              int64_t* step_ptr, void* stream) {
+    if (!prop || !sse_prop || !cur || !cur_lp || !best || !best_lp || !lps || !alphas || !nacc || !step_ptr ||
+        C <= 0 || chain0 < 0 || p <= 0 || sigma <= 0.0 || (hist && (!x0 || !mult || !kcur || !sumx || kcap <= 0 || pstride < p))) {
         qn_set_error("qn_mcmc_accept: bad argument");
         return QN_EINVAL;
     }
@@ -466,9 +461,8 @@ extern "C" int qn_mcmc_accept(const double* prop, const double* sse_prop, double
     a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
     a.chain0 = chain0; a.nmcmc = nmcmc; a.kcap = kcap; a.p = p; a.pstride = pstride; a.seed = seed;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_accept, dim3((unsigned)((p + ACH - 1) / ACH), C), dim3(BLK), 0, static_cast<hipStream_t>(stream), a,
-                       prop, sse_prop, cur, cur_lp, best, best_lp, chain, lps, alphas, nacc, x0, hist, mult, kcur, sumx,
-                       arrive, step_ptr);
+    hipLaunchKernelGGL(k_accept, dim3(C), dim3(ABLK), 0, static_cast<hipStream_t>(stream), a, prop, sse_prop, cur, cur_lp,
+                       best, best_lp, chain, lps, alphas, nacc, x0, hist, mult, kcur, sumx, step_ptr);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }

@@ -95,7 +95,7 @@ class DeviceAMCMC:
             s['chain'].data_ptr() if s['chain'] is not None else None, s['lps'].data_ptr(), s['alphas'].data_ptr(),
             s['nacc'].data_ptr(), s['x0'].data_ptr(), s['hist'].data_ptr(), s['mult'].data_ptr(),
             s['kcur'].data_ptr(), s['sumx'].data_ptr(), s['hist'].shape[1], s['hist'].shape[2],
-            s['arrive'].data_ptr(), s['step'].data_ptr(), self._stream()), "qn_mcmc_accept")
+            s['step'].data_ptr(), self._stream()), "qn_mcmc_accept")
 
     def run(self, nmcmc, param_ini, store_chain=True, verbose=False):
         dev, f64 = self.dev, torch.float64
@@ -118,7 +118,6 @@ class DeviceAMCMC:
              'mult': torch.zeros(C, kcap, dtype=torch.int32, device=dev),
              'kcur': torch.zeros(C, dtype=torch.int32, device=dev),
              'sumx': torch.zeros(C, p, dtype=f64, device=dev),
-             'arrive': torch.zeros(C, dtype=torch.int32, device=dev),
              'step': torch.zeros(2, dtype=torch.int64, device=dev)}
         s['hist'][:, 0] = 0.0                                               # row 0 = x_0 - x_0
         s['mult'][:, 0] = 1
