@@ -329,15 +329,31 @@ __global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __r
     const int kc = hist ? kcur[b] : 0;
     const int knew = take ? kc + 1 : kc;
     float* hrow = (hist && take && knew < a.kcap) ? hist + ((int64_t)b * a.kcap + knew) * a.pstride : nullptr;
-    for (int64_t e = threadIdx.x; e < a.p; e += ABLK) {
-        const double v = take ? prop[base + e] : cur[base + e];
-        if (take) cur[base + e] = v;
-        if (better) best[base + e] = v;
-        if (crow) crow[e] = v;
-        if (hist) {
-            const double dv = v - x0[base + e];
-            if (hrow) hrow[e] = (float)dv;
-            sumx[base + e] += dv;
+    // batches of UB elements per thread: all loads of a batch are issued before its first store, so the
+    // (independent) elements overlap their memory latency instead of paying it one after the other
+    constexpr int UB = 4;
+    for (int64_t e0 = threadIdx.x; e0 < a.p; e0 += (int64_t)UB * ABLK) {
+        double v[UB], xv[UB], sv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int64_t e = e0 + (int64_t)u * ABLK;
+            const bool in = e < a.p;
+            v[u] = in ? (take ? prop[base + e] : cur[base + e]) : 0.0;
+            xv[u] = (in && hist) ? x0[base + e] : 0.0;
+            sv[u] = (in && hist) ? sumx[base + e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int64_t e = e0 + (int64_t)u * ABLK;
+            if (e >= a.p) break;
+            if (take) cur[base + e] = v[u];
+            if (better) best[base + e] = v[u];
+            if (crow) crow[e] = v[u];
+            if (hist) {
+                const double dv = v[u] - xv[u];
+                if (hrow) hrow[e] = (float)dv;
+                sumx[base + e] = sv[u] + dv;
+            }
         }
     }
     __syncthreads();
