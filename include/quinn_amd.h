@@ -159,7 +159,7 @@ int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int
  *   u_k, v_j iid N(0,1), wsnap = sqrt(w), s_lr = sqrt(c/(n-1)), s_iso = sqrt(c 1e-8), has exactly that
  *   covariance: a K x p GEMV over the stored states instead of a p x p factor (cfg2: K ~ 10^2..10^3
  *   rows of 34 KB per chain and step instead of 290-580 MB).  ksnap [C] = K per chain, msnap [C, p] =
- *   mean of (x - x0) at the adaptation, both frozen until the next adaptation.  pstride a multiple of 4, >= p. */
+ *   mean of (x - x0) at the adaptation, both frozen until the next adaptation.  pstride even, >= p. */
 int qn_mcmc_propose_hist(const double* cur, const float* hist, const float* wsnap, const int32_t* ksnap,
                          const double* msnap, double s_lr, double s_iso, int C, int chain0, int64_t p, int64_t pstride,
                          int kcap, uint64_t seed, const int64_t* step_ptr, double* out, void* stream);

@@ -212,9 +212,6 @@ __global__ __launch_bounds__(BLK) void k_hist_coef_sum(HistBlockArgs a, const fl
 // added per step by k_apply_delta).  2 columns per thread held as one packed float pair per step: the inner
 // loop is TB v_pk_fma_f32 per history row, coefficients broadcast from LDS.
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-// 4 columns per thread (two packed pairs per step): every coefficient read from LDS feeds 4 FMAs, and a history
-// row is a 16-byte load per lane (pstride is a multiple of 4)
 __global__ __launch_bounds__(BLK, 2) void k_hist_block(HistBlockArgs a, const float* __restrict__ hist,
                                                        const float* __restrict__ coef, const float* __restrict__ csum,
                                                        const int32_t* __restrict__ ksnap,
@@ -222,15 +219,14 @@ __global__ __launch_bounds__(BLK, 2) void k_hist_block(HistBlockArgs a, const fl
     __shared__ __attribute__((aligned(16))) float cs[KB2 * TB];
     const int b = blockIdx.y;
     const int K = ksnap[b] < a.kcap ? ksnap[b] : a.kcap;
-    const int64_t j = 4 * ((int64_t)blockIdx.x * BLK + threadIdx.x);
+    const int64_t j = 2 * ((int64_t)blockIdx.x * BLK + threadIdx.x);
     const bool live = j < a.p;
     const float* hcol = hist + (int64_t)b * a.kcap * a.pstride + (live ? j : 0);
     const float* cb = coef + (int64_t)b * a.kstride * TB;
-    v2f acc0[TB], acc1[TB];
+    v2f acc[TB];
 #pragma unroll
-    for (int t = 0; t < TB; ++t) acc0[t] = acc1[t] = (v2f){0.f, 0.f};
-    constexpr int RG = 4;
-    const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TB; ++t) acc[t] = (v2f){0.f, 0.f};
+    constexpr int RG = 8;
     for (int k0 = 0; k0 < K; k0 += KB2) {
         const int kn = K - k0 < KB2 ? K - k0 : KB2;
         const int knp = (kn + RG - 1) / RG * RG;                           // rows padded to a group: zero coefficients
@@ -239,50 +235,42 @@ __global__ __launch_bounds__(BLK, 2) void k_hist_block(HistBlockArgs a, const fl
                                                              : (float4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();
         const float* h = hcol + (int64_t)k0 * a.pstride;
-        // rows in groups of RG: the next group's loads (16 B per lane each) are in flight while the current group
-        // is multiplied -- one row ahead keeps far too few bytes in flight to stream from HBM
-        v4f hn[RG];
+        // rows in groups of RG: the next group's RG loads (8 B per lane each) are in flight while the current
+        // group is multiplied -- one row ahead keeps far too few bytes in flight to stream from HBM
+        v2f hn[RG];
 #pragma unroll
-        for (int u = 0; u < RG; ++u) hn[u] = u < kn ? *reinterpret_cast<const v4f*>(h + (int64_t)u * a.pstride) : zero4;
+        for (int u = 0; u < RG; ++u) hn[u] = u < kn ? *reinterpret_cast<const v2f*>(h + (int64_t)u * a.pstride) : (v2f){0.f, 0.f};
         for (int kk = 0; kk < kn; kk += RG) {
-            v4f hv[RG];
+            v2f hv[RG];
 #pragma unroll
             for (int u = 0; u < RG; ++u) hv[u] = hn[u];
 #pragma unroll
             for (int u = 0; u < RG; ++u)
-                hn[u] = kk + RG + u < kn ? *reinterpret_cast<const v4f*>(h + (int64_t)(kk + RG + u) * a.pstride) : zero4;
+                hn[u] = kk + RG + u < kn ? *reinterpret_cast<const v2f*>(h + (int64_t)(kk + RG + u) * a.pstride)
+                                         : (v2f){0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < RG; ++u) {                                  // rows >= kn: zero row times zero coefficients
                 const float4* c4 = reinterpret_cast<const float4*>(cs + (kk + u) * TB);
-                const v2f h01 = {hv[u].x, hv[u].y}, h23 = {hv[u].z, hv[u].w};
 #pragma unroll
                 for (int t4 = 0; t4 < TB / 4; ++t4) {
                     const float4 cv = c4[t4];
-                    acc0[4 * t4 + 0] = __builtin_elementwise_fma((v2f){cv.x, cv.x}, h01, acc0[4 * t4 + 0]);
-                    acc1[4 * t4 + 0] = __builtin_elementwise_fma((v2f){cv.x, cv.x}, h23, acc1[4 * t4 + 0]);
-                    acc0[4 * t4 + 1] = __builtin_elementwise_fma((v2f){cv.y, cv.y}, h01, acc0[4 * t4 + 1]);
-                    acc1[4 * t4 + 1] = __builtin_elementwise_fma((v2f){cv.y, cv.y}, h23, acc1[4 * t4 + 1]);
-                    acc0[4 * t4 + 2] = __builtin_elementwise_fma((v2f){cv.z, cv.z}, h01, acc0[4 * t4 + 2]);
-                    acc1[4 * t4 + 2] = __builtin_elementwise_fma((v2f){cv.z, cv.z}, h23, acc1[4 * t4 + 2]);
-                    acc0[4 * t4 + 3] = __builtin_elementwise_fma((v2f){cv.w, cv.w}, h01, acc0[4 * t4 + 3]);
-                    acc1[4 * t4 + 3] = __builtin_elementwise_fma((v2f){cv.w, cv.w}, h23, acc1[4 * t4 + 3]);
+                    acc[4 * t4 + 0] = __builtin_elementwise_fma((v2f){cv.x, cv.x}, hv[u], acc[4 * t4 + 0]);
+                    acc[4 * t4 + 1] = __builtin_elementwise_fma((v2f){cv.y, cv.y}, hv[u], acc[4 * t4 + 1]);
+                    acc[4 * t4 + 2] = __builtin_elementwise_fma((v2f){cv.z, cv.z}, hv[u], acc[4 * t4 + 2]);
+                    acc[4 * t4 + 3] = __builtin_elementwise_fma((v2f){cv.w, cv.w}, hv[u], acc[4 * t4 + 3]);
                 }
             }
         }
         __syncthreads();
     }
     if (!live) return;
-    double m[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) m[q] = j + q < a.p ? msnap[(int64_t)b * a.p + j + q] : 0.0;
+    const double m0 = msnap[(int64_t)b * a.p + j], m1 = j + 1 < a.p ? msnap[(int64_t)b * a.p + j + 1] : 0.0;
 #pragma unroll
     for (int t = 0; t < TB; ++t) {
         const double sA = (double)csum[(int64_t)b * TB + t];
         double* d = delta + ((int64_t)b * TB + t) * a.p + j;
-        const double v[4] = {(double)acc0[t].x, (double)acc0[t].y, (double)acc1[t].x, (double)acc1[t].y};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (j + q < a.p) d[q] = a.s_lr * (v[q] - sA * m[q]);
+        d[0] = a.s_lr * ((double)acc[t].x - sA * m0);
+        if (j + 1 < a.p) d[1] = a.s_lr * ((double)acc[t].y - sA * m1);
     }
 }
 // out[c][:] = cur[c][:] + delta[c][t][:] + s_iso * v,  v ~ N(0, I) on the stream of the current step
@@ -441,8 +429,8 @@ extern "C" int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap,
                                           int64_t p, int64_t pstride, int kcap, uint64_t seed, int64_t step0,
                                           const int64_t* step_ptr, float* coef, double* delta, void* stream) {
     if (!hist || !wsnap || !ksnap || !msnap || !coef || !delta || C <= 0 || C > 65535 || chain0 < 0 || p <= 0 || kcap <= 0 ||
-        pstride < p || (pstride & 3) || step0 < 0) {
-        qn_set_error("qn_mcmc_propose_hist_block: bad argument (pstride must be a multiple of 4 and >= p)");
+        pstride < p || (pstride & 1) || step0 < 0) {
+        qn_set_error("qn_mcmc_propose_hist_block: bad argument (pstride must be even and >= p)");
         return QN_EINVAL;
     }
     HistBlockArgs a;
@@ -455,7 +443,7 @@ extern "C" int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap,
                        coef);
     float* csum = coef + (int64_t)C * a.kstride * TB;                  // [C][TB] behind the coefficients
     hipLaunchKernelGGL(k_hist_coef_sum, dim3(C), dim3(BLK), 0, st, a, (const float*)coef, ksnap, csum);
-    hipLaunchKernelGGL(k_hist_block, dim3((int)(((p + 3) / 4 + BLK - 1) / BLK), C), dim3(BLK), 0, st, a, hist,
+    hipLaunchKernelGGL(k_hist_block, dim3((int)(((p + 1) / 2 + BLK - 1) / BLK), C), dim3(BLK), 0, st, a, hist,
                        (const float*)coef, (const float*)csum, ksnap, msnap, delta);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
