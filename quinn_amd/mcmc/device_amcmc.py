@@ -12,7 +12,8 @@ proposal's ingredients and the chain history in HBM and never synchronises with 
     queue full either way -- so direct launching is the default);
   * initial proposal covariance 0.01 + diag(0.09|x0|) (admcmc.py:65) = diagonal + rank one:
     drawn exactly as sqrt(0.09|x0|) * z + 0.1 * z0 without forming a p x p matrix (`qn_mcmc_propose`);
-  * adapted proposals are drawn in SAMPLE SPACE (`qn_mcmc_propose_hist`).  The reference's covariance
+  * adapted proposals are drawn in SAMPLE SPACE (`qn_mcmc_propose_hist_block`; one step at a time:
+    `qn_mcmc_propose_hist`).  The reference's covariance
     recursion (admcmc.py:52-59) is, in closed form, the unbiased sample covariance of x_0..x_i
     (tests/test_amcmc_math.py), and an adaptation at step i sets the proposal covariance to
     c (cov_i + 1e-8 I), c = gamma 2.4^2 / p (admcmc.py:66-67).  A chain of n = i + 1 samples has only
@@ -65,13 +66,6 @@ class DeviceAMCMC:
         _lib.check(self._L.qn_mcmc_propose(cur.data_ptr() if cur is not None else None,
                                            sd.data_ptr() if sd is not None else None, c1, C, self.chain0, p, self.seed,
                                            step_ptr.data_ptr(), out.data_ptr(), self._stream()), "qn_mcmc_propose")
-
-    def _propose_hist(self, s, snap, out):
-        C, p = out.shape
-        _lib.check(self._L.qn_mcmc_propose_hist(
-            s['cur'].data_ptr(), s['hist'].data_ptr(), snap['w'].data_ptr(), snap['k'].data_ptr(),
-            snap['mean'].data_ptr(), snap['s_lr'], snap['s_iso'], C, self.chain0, p, s['hist'].shape[2],
-            s['hist'].shape[1], self.seed, s['step'].data_ptr(), out.data_ptr(), self._stream()), "qn_mcmc_propose_hist")
 
     def _propose_hist_block(self, s, snap, coef, delta):
         C, _, p = delta.shape
