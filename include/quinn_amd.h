@@ -186,6 +186,9 @@ int qn_debug_tanh(const double* x, double* y, int64_t n, void* stream);
 /* Diagnostic: the variant the fused kernels use when all weights and inputs are finite and bounded
  * (no NaN handling; same values for every non-NaN input). */
 int qn_debug_tanh_finite(const double* x, double* y, int64_t n, void* stream);
+/* Diagnostic: the table-assisted tanh of the fused kernels (tanh(n/16) from LDS + a short polynomial;
+ * nansafe != 0: NaN-propagating variant). */
+int qn_debug_tanh_table(const double* x, double* y, int64_t n, int nansafe, void* stream);
 
 const char* qn_last_error(void);
 /* "quinn_amd <version> gfx950" */

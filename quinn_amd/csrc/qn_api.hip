@@ -477,7 +477,15 @@ __global__ void k_tanh_f64(const double* __restrict__ x, double* __restrict__ y,
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = qn_tanh_f64_impl<NANSAFE>(x[i]);
 }
-int debug_tanh(const char* fn, bool nansafe, const double* x, double* y, int64_t n, void* stream) {
+template <bool NANSAFE>
+__global__ void k_tanh_f64_tab(const double* __restrict__ x, double* __restrict__ y, int64_t n) {
+    __shared__ double tab[QN_TANH_TAB_N + 1];
+    qn_tanh_table_stage(tab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = qn_tanh_f64_tab<NANSAFE>(x[i], tab);
+}
+int debug_tanh(const char* fn, int variant, const double* x, double* y, int64_t n, void* stream) {
     if (!x || !y || n <= 0) {
         qn_set_error("%s: bad argument", fn);
         return QN_EINVAL;
@@ -485,16 +493,21 @@ int debug_tanh(const char* fn, bool nansafe, const double* x, double* y, int64_t
     (void)hipGetLastError();
     const dim3 grid((unsigned)((n + 255) / 256));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (nansafe) hipLaunchKernelGGL(k_tanh_f64<true>, grid, dim3(256), 0, st, x, y, n);
-    else hipLaunchKernelGGL(k_tanh_f64<false>, grid, dim3(256), 0, st, x, y, n);
+    if (variant == 0) hipLaunchKernelGGL(k_tanh_f64<true>, grid, dim3(256), 0, st, x, y, n);
+    else if (variant == 1) hipLaunchKernelGGL(k_tanh_f64<false>, grid, dim3(256), 0, st, x, y, n);
+    else if (variant == 2) hipLaunchKernelGGL(k_tanh_f64_tab<true>, grid, dim3(256), 0, st, x, y, n);
+    else hipLaunchKernelGGL(k_tanh_f64_tab<false>, grid, dim3(256), 0, st, x, y, n);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }
 }  // namespace
 
 extern "C" int qn_debug_tanh(const double* x, double* y, int64_t n, void* stream) {
-    return debug_tanh("qn_debug_tanh", true, x, y, n, stream);
+    return debug_tanh("qn_debug_tanh", 0, x, y, n, stream);
 }
 extern "C" int qn_debug_tanh_finite(const double* x, double* y, int64_t n, void* stream) {
-    return debug_tanh("qn_debug_tanh_finite", false, x, y, n, stream);
+    return debug_tanh("qn_debug_tanh_finite", 1, x, y, n, stream);
+}
+extern "C" int qn_debug_tanh_table(const double* x, double* y, int64_t n, int nansafe, void* stream) {
+    return debug_tanh("qn_debug_tanh_table", nansafe ? 2 : 3, x, y, n, stream);
 }

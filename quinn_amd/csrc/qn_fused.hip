@@ -50,10 +50,11 @@ __host__ __device__ constexpr int stride_of(int H) { return (H + 31) / 32 * 32; 
 __host__ __device__ inline int lds_doubles(int H, int dp, int o, int nhid) {
     return H * dp + H + (nhid - 1) * (H * stride_of(H) + H) + o * H + o + 8;   // + reduction scratch
 }
+constexpr int TANH_TAB = (QN_TANH_TAB_N + 1) & ~1;      // doubles reserved for the tanh table behind an image
 inline int padded_d(int d) { return d <= 2 ? 2 : 4; }
 
-template <int ACT, bool NANSAFE = true> __device__ __forceinline__ double act_apply(double z) {
-    if constexpr (ACT == QN_ACT_TANH) return qn_tanh_f64_impl<NANSAFE>(z);
+template <int ACT, bool NANSAFE = true> __device__ __forceinline__ double act_apply(double z, const double* tab) {
+    if constexpr (ACT == QN_ACT_TANH) return qn_tanh_f64_tab<NANSAFE>(z, tab);
     else if constexpr (ACT == QN_ACT_RELU) return z > 0.0 ? z : 0.0;
     else return z;
 }
@@ -148,6 +149,8 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
     const int offW0 = 0, offb0 = H * DP, offHH = offb0 + H;
     const int offWl = offHH + (NH - 1) * (H * S + H), offbl = offWl + o * H;
     double* red = lds + ((offbl + o + 1) & ~1);      // 4 doubles behind the weight image
+    const double* tanh_tab = lds + ((lds_doubles(H, DP, o, NH) + 1) & ~1);
+    qn_tanh_table_stage(lds + ((lds_doubles(H, DP, o, NH) + 1) & ~1), threadIdx.x, NT);   // barrier: block_or below
 
     // NaN-free tanh only if nothing can produce a NaN: all weights of this chain bounded (checked while
     // staging) and, per wave iteration, all inputs of its rows bounded (checked in fetch)
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
                         double z = lds[offb0 + j];
 #pragma unroll
                         for (int k = 0; k < DP; ++k) z = fma(lds[offW0 + j * DP + k], xk[g][k], z);
-                        act[g][t][i] = act_apply<ACT, NS>(z);
+                        act[g][t][i] = act_apply<ACT, NS>(z, tanh_tab);
                     }
             }
         };
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
 #pragma unroll
                     for (int t = 0; t < T; ++t)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) act[g][t][i] = act_apply<ACT, NS>(acc[g][t][i]);
+                        for (int i = 0; i < 4; ++i) act[g][t][i] = act_apply<ACT, NS>(acc[g][t][i], tanh_tab);
             };
             if (ACT == QN_ACT_TANH && !nan_possible) epilogue(std::false_type{});
             else epilogue(std::true_type{});
@@ -332,14 +335,15 @@ __host__ __device__ inline int bwd_lds_doubles(int H, int dp, int o, int nhid) {
 // activation of one 16x16 tile (4 values per lane); the switch is wave-uniform and sits OUTSIDE the
 // element loop, the sched_barrier keeps the scheduler from interleaving more than one tile's tanh
 // chains (register pressure)
-__device__ __forceinline__ void act_tile(const v4d& z, double (&out)[4], int act, bool nan_possible) {
+__device__ __forceinline__ void act_tile(const v4d& z, double (&out)[4], int act, bool nan_possible,
+                                         const double* tanh_tab) {
     if (act == QN_ACT_TANH) {
         if (nan_possible) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) out[i] = qn_tanh_f64(z[i]);
+            for (int i = 0; i < 4; ++i) out[i] = qn_tanh_f64_tab<true>(z[i], tanh_tab);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) out[i] = qn_tanh_f64_finite(z[i]);
+            for (int i = 0; i < 4; ++i) out[i] = qn_tanh_f64_tab<false>(z[i], tanh_tab);
         }
     } else if (act == QN_ACT_RELU) {
 #pragma unroll
@@ -379,6 +383,8 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
     double* Sx = SD + H * NSP;
     double* Sdl = Sx + ROWS_IT * DP;
     double* red = Sdl + ROWS_IT * OMAX;
+    const double* tanh_tab = lds + ((bwd_lds_doubles(H, DP, o, NH) + 1) & ~1);
+    qn_tanh_table_stage(lds + ((bwd_lds_doubles(H, DP, o, NH) + 1) & ~1), threadIdx.x, WG);   // barrier: block_or below
 
     const bool w_unbounded = block_or(stage_weights<H, DP>(lds, W + (int64_t)b * a.p, a), red + 6);
 
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
                 for (int k = 0; k < DP; ++k) z[i] = fma(lds[offW0 + j * DP + k], xk[k], z[i]);
             }
-            act_tile(z, act[0][t], act_kind, nan_possible);
+            act_tile(z, act[0][t], act_kind, nan_possible, tanh_tab);
         }
 #pragma unroll
         for (int layer = 1; layer < NH; ++layer) {
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int t = 0; t < T; ++t) act_tile(acc[t], act[layer][t], act_kind, nan_possible);
+                for (int t = 0; t < T; ++t) act_tile(acc[t], act[layer][t], act_kind, nan_possible, tanh_tab);
             }
         }
         double (&alast)[T][4] = act[NH - 1];
@@ -861,7 +867,8 @@ void plan(const qn_desc* d, int B, int Nb, int want_grad, FusedArgs* a) {
 }
 
 size_t lds_need(int H, int d, int o, int nhid, int want_grad) {
-    return sizeof(double) * (size_t)(want_grad ? bwd_lds_doubles(H, 4, o, nhid) : lds_doubles(H, padded_d(d), o, nhid));
+    return sizeof(double) * (size_t)((want_grad ? bwd_lds_doubles(H, 4, o, nhid) : lds_doubles(H, padded_d(d), o, nhid)) +
+                                     2 + TANH_TAB);
 }
 
 using fwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*);

@@ -70,6 +70,49 @@ __device__ __forceinline__ bool qn_bounded(double v) {
     return (unsigned)(__double2hiint(v) & 0x7fffffff) < 0x5f300000u;   // exponent field < 1023 + 500
 }
 
+// ---------------------------------------------------------------------------------------------
+// Table-assisted tanh for float64 (kernels that have LDS to spare): 17 DP instructions + v_rcp instead of 25.
+//   |x| = a + b,  a = n/16 (n = round(16|x|) by the 1.5*2^52 trick; its low mantissa word IS n),  |b| <= 1/32 exact;
+//   tanh(a) from a table of 321 correctly rounded values in LDS (qn_tanh_table.h; one ds_read_b64 -- the LDS
+//   pipe is idle next to the DP pipe in these kernels);
+//   tanh(b) = b + b^3 (-1/3 + 2/15 b^2 - 17/315 b^4 + 62/2835 b^6)   (next term 8e-18 relative at |b| = 1/32);
+//   tanh(a + b) = (tanh a + tanh b) / (1 + tanh a tanh b): no cancellation (tanh a >= 0.0624 > |tanh b| for n >= 1,
+//   and for n = 0 the result is tanh b itself), quotient by v_rcp_f64 + one cubic Newton step as above.
+// Same contract as qn_tanh_f64_impl: NANSAFE = false for arguments that cannot be NaN (+-inf included).
+#include "qn_tanh_table.h"
+static __device__ const double qn_tanh_table_g[QN_TANH_TAB_N] = {QN_TANH_TAB_VALUES};
+// copy the table into LDS (call with all threads of the block, then synchronise)
+__device__ __forceinline__ void qn_tanh_table_stage(double* lds_tab, int tid, int nthreads) {
+    for (int e = tid; e < QN_TANH_TAB_N; e += nthreads) lds_tab[e] = qn_tanh_table_g[e];
+}
+template <bool NANSAFE>
+__device__ __forceinline__ double qn_tanh_f64_tab(double x, const double* __restrict__ lds_tab) {
+    const double kClamp = 20.0;
+    double ax;
+    asm("v_min_f64 %0, |%1|, %2" : "=v"(ax) : "v"(x), "s"(kClamp));
+    const double kMagic = 6755399441055744.0;                          // 1.5 * 2^52
+    const double zm = fma(ax, 16.0, kMagic);                           // 16|x| rounded to an integer n in 0..320
+    const double T = lds_tab[__double2loint(zm)];                      // tanh(n / 16)
+    const double b = fma(zm - kMagic, -0.0625, ax);                    // exact
+    const double b2 = b * b;
+    double q = 2.18694885361552028e-02;                                // 62/2835
+    q = fma(q, b2, -5.39682539682539683e-02);                          // -17/315
+    q = fma(q, b2, 1.33333333333333333e-01);                           // 2/15
+    q = fma(q, b2, -3.33333333333333333e-01);                          // -1/3
+    const double tb = fma(b * b2, q, b);
+    const double num = T + tb;
+    const double den = fma(T, tb, 1.0);                                // in [0.97, 1.03]
+    double y = __builtin_amdgcn_rcp(den);
+    const double e0 = fma(-den, y, 1.0);
+    y = fma(y, fma(e0, e0, e0), y);
+    const double r = num * y;                                          // >= 0
+    if constexpr (!NANSAFE) return __builtin_copysign(r, x);
+    const int xh = __double2hiint(x);
+    const int nanmask = (0x7ff00000 - (xh & 0x7fffffff)) >> 31;        // all ones iff x is NaN
+    const int rh = (__double2hiint(r) | (xh & 0x80000000)) | nanmask;
+    return __hiloint2double(rh, __double2loint(r));
+}
+
 // tanh for float32: 1 - 2 / (exp(2|x|) + 1) on the hardware exp2 / rcp (7 instructions, absolute error
 // ~2e-7, i.e. float32-level; NaN propagates through v_exp_f32).
 __device__ __forceinline__ float qn_tanh_f32(float x) {

@@ -50,3 +50,39 @@ def test_tanh_f64_ulp_error(fn):
     tref = torch.tanh(torch.tensor(xs)).numpy()
     fin = np.isfinite(xs)
     assert np.max(np.abs(got[fin] - tref[fin]) / ulp[fin]) < 4.0
+
+
+@pytest.mark.parametrize("nansafe", [1, 0])
+def test_table_assisted_tanh_ulp_error(nansafe):
+    """The tanh of the fused kernels (qn_tanh_f64_tab): table of tanh(n/16) in LDS + odd polynomial for the rest."""
+    rs = np.random.RandomState(1)
+    grid = np.arange(0, 321) / 16.0                                      # the table nodes and the bin edges around them
+    xs = np.concatenate([rs.uniform(-20, 20, 200000), rs.uniform(-1, 1, 200000), rs.uniform(-1e-3, 1e-3, 50000),
+                         10.0 ** rs.uniform(-300, -3, 20000), grid, -grid, grid + 1 / 32, grid[1:] - 1 / 32,
+                         np.nextafter(grid + 1 / 32, 0), np.nextafter(grid + 1 / 32, 40),
+                         np.array([0.0, -0.0, 19.0, 19.07, 25.0, -40.0, 1e300, -1e300, np.inf, -np.inf, 5e-324])])
+    x = torch.tensor(xs, device="cuda")
+    y = torch.empty_like(x)
+    L = _lib.lib()
+    _lib.check(L.qn_debug_tanh_table(x.data_ptr(), y.data_ptr(), x.numel(), nansafe, None), "qn_debug_tanh_table")
+    torch.cuda.synchronize()
+    got = y.cpu().numpy()
+    ref = _ref_tanh(xs)
+    ulp = np.spacing(np.abs(ref.astype(np.float64)))
+    err = np.abs(got.astype(np.longdouble) - ref) / np.maximum(ulp, 5e-324)
+    assert err.max() < 3.0, (err.max(), xs[np.argmax(err)])
+    assert np.mean(err) < 0.7
+    assert got[np.where(xs == np.inf)[0][0]] == 1.0 and got[np.where(xs == -np.inf)[0][0]] == -1.0
+    assert np.signbit(got[np.where(xs == 0.0)[0][-1]])                  # tanh(-0.0) = -0.0
+    assert (np.abs(got) <= 1.0).all() and (np.sign(got) == np.sign(xs)).all()
+    if nansafe:
+        z = torch.tensor([np.nan, 1.0], device="cuda", dtype=torch.float64)
+        w = torch.empty_like(z)
+        _lib.check(L.qn_debug_tanh_table(z.data_ptr(), w.data_ptr(), 2, 1, None), "qn_debug_tanh_table")
+        assert torch.isnan(w[0]) and abs(w[1].item() - np.tanh(1.0)) < 1e-15
+    # monotone on a fine grid across many table bins
+    t = torch.linspace(0.0, 4.0, 200001, dtype=torch.float64, device="cuda")
+    u = torch.empty_like(t)
+    _lib.check(L.qn_debug_tanh_table(t.data_ptr(), u.data_ptr(), t.numel(), nansafe, None), "qn_debug_tanh_table")
+    d = (u[1:] - u[:-1]).cpu().numpy()
+    assert (d >= -2.3e-16).all()                                         # never decreases by more than ~1 ulp
