@@ -71,13 +71,13 @@ __device__ __forceinline__ bool qn_bounded(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Table-assisted tanh for float64 (kernels that have LDS to spare): 17 DP instructions + v_rcp instead of 25.
+// Table-assisted tanh for float64 (kernels that have LDS to spare): 18 DP instructions + v_rcp instead of 25.
 //   |x| = a + b,  a = n/16 (n = round(16|x|) by the 1.5*2^52 trick; its low mantissa word IS n),  |b| <= 1/32 exact;
 //   tanh(a) from a table of 321 correctly rounded values in LDS (qn_tanh_table.h; one ds_read_b64 -- the LDS
 //   pipe is idle next to the DP pipe in these kernels);
 //   tanh(b) = b + b^3 (-1/3 + 2/15 b^2 - 17/315 b^4 + 62/2835 b^6)   (next term 8e-18 relative at |b| = 1/32);
 //   tanh(a + b) = (tanh a + tanh b) / (1 + tanh a tanh b): no cancellation (tanh a >= 0.0624 > |tanh b| for n >= 1,
-//   and for n = 0 the result is tanh b itself), quotient by v_rcp_f64 + one cubic Newton step as above.
+//   and for n = 0 the result is tanh b itself), quotient by v_rcp_f64 + a residual-corrected division.
 // Same contract as qn_tanh_f64_impl: NANSAFE = false for arguments that cannot be NaN (+-inf included).
 #include "qn_tanh_table.h"
 static __device__ const double qn_tanh_table_g[QN_TANH_TAB_N] = {QN_TANH_TAB_VALUES};
@@ -102,10 +102,13 @@ __device__ __forceinline__ double qn_tanh_f64_tab(double x, const double* __rest
     const double tb = fma(b * b2, q, b);
     const double num = T + tb;
     const double den = fma(T, tb, 1.0);                                // in [0.97, 1.03]
-    double y = __builtin_amdgcn_rcp(den);
-    const double e0 = fma(-den, y, 1.0);
-    y = fma(y, fma(e0, e0, e0), y);
-    const double r = num * y;                                          // >= 0
+    // quotient with ONE final rounding: y1 = 1/den to 2^-48, r0 = num y1, exact residual num - den r0 folded back
+    // (a plain num * (1/den) rounds the reciprocal and the product: a full ulp more, which matters here because num
+    // and den can sit in the binade above the result)
+    const double y0 = __builtin_amdgcn_rcp(den);                       // 2^-24
+    const double y1 = fma(y0, fma(-den, y0, 1.0), y0);
+    const double r0 = num * y1;
+    const double r = fma(fma(-den, r0, num), y1, r0);                  // >= 0
     if constexpr (!NANSAFE) return __builtin_copysign(r, x);
     const int xh = __double2hiint(x);
     const int nanmask = (0x7ff00000 - (xh & 0x7fffffff)) >> 31;        // all ones iff x is NaN
