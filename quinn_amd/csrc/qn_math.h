@@ -71,21 +71,19 @@ __device__ __forceinline__ bool qn_bounded(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Table-assisted tanh for float64 (kernels that have LDS to spare): 16 DP instructions + v_rcp instead of 25.
+// Table-assisted tanh for float64 (kernels that have LDS to spare): 18 DP instructions + v_rcp instead of 25.
 //   |x| = a + b,  a = n/16 (n = round(16|x|) by the 1.5*2^52 trick; its low mantissa word IS n),  |b| <= 1/32 exact;
-//   (T, S) = (tanh a, 1 - tanh^2 a) from a table of 321 correctly rounded pairs in LDS (qn_tanh_table.h; one
-//   ds_read_b128 -- the LDS pipe is idle next to the DP pipe in these kernels);
-//   tb = tanh(b) = b + b^3 (-1/3 + 2/15 b^2 - 17/315 b^4 + 62/2835 b^6)   (next term 8e-18 relative at |b| = 1/32);
-//   tanh(a + b) = T + S tb / (1 + T tb): the correction is at most 0.031, so its quotient only needs 2^-48
-//   (v_rcp_f64 + one Newton step), and the result carries the rounding of T and of the final fma: max error < 2 ulp
-//   (tests/test_gpu_math.py).  For n = 0: T = 0, S = 1, the result is tb itself.
+//   tanh(a) from a table of 321 correctly rounded values in LDS (qn_tanh_table.h; one ds_read_b64 -- the LDS
+//   pipe is idle next to the DP pipe in these kernels);
+//   tanh(b) = b + b^3 (-1/3 + 2/15 b^2 - 17/315 b^4 + 62/2835 b^6)   (next term 8e-18 relative at |b| = 1/32);
+//   tanh(a + b) = (tanh a + tanh b) / (1 + tanh a tanh b): no cancellation (tanh a >= 0.0624 > |tanh b| for n >= 1,
+//   and for n = 0 the result is tanh b itself), quotient by v_rcp_f64 + a residual-corrected division.
 // Same contract as qn_tanh_f64_impl: NANSAFE = false for arguments that cannot be NaN (+-inf included).
 #include "qn_tanh_table.h"
-static __device__ const double qn_tanh_table_g[2 * QN_TANH_TAB_N] = {QN_TANH_TAB_VALUES};
-typedef double qn_v2d __attribute__((ext_vector_type(2)));
-// copy the table into LDS (16-byte aligned; call with all threads of the block, then synchronise)
+static __device__ const double qn_tanh_table_g[QN_TANH_TAB_N] = {QN_TANH_TAB_VALUES};
+// copy the table into LDS (call with all threads of the block, then synchronise)
 __device__ __forceinline__ void qn_tanh_table_stage(double* lds_tab, int tid, int nthreads) {
-    for (int e = tid; e < 2 * QN_TANH_TAB_N; e += nthreads) lds_tab[e] = qn_tanh_table_g[e];
+    for (int e = tid; e < QN_TANH_TAB_N; e += nthreads) lds_tab[e] = qn_tanh_table_g[e];
 }
 template <bool NANSAFE>
 __device__ __forceinline__ double qn_tanh_f64_tab(double x, const double* __restrict__ lds_tab) {
@@ -94,7 +92,7 @@ __device__ __forceinline__ double qn_tanh_f64_tab(double x, const double* __rest
     asm("v_min_f64 %0, |%1|, %2" : "=v"(ax) : "v"(x), "s"(kClamp));
     const double kMagic = 6755399441055744.0;                          // 1.5 * 2^52
     const double zm = fma(ax, 16.0, kMagic);                           // 16|x| rounded to an integer n in 0..320
-    const qn_v2d ts = reinterpret_cast<const qn_v2d*>(lds_tab)[__double2loint(zm)];   // (tanh, sech^2) at n / 16
+    const double T = lds_tab[__double2loint(zm)];                      // tanh(n / 16)
     const double b = fma(zm - kMagic, -0.0625, ax);                    // exact
     const double b2 = b * b;
     double q = 2.18694885361552028e-02;                                // 62/2835
@@ -102,10 +100,15 @@ __device__ __forceinline__ double qn_tanh_f64_tab(double x, const double* __rest
     q = fma(q, b2, 1.33333333333333333e-01);                           // 2/15
     q = fma(q, b2, -3.33333333333333333e-01);                          // -1/3
     const double tb = fma(b * b2, q, b);
-    const double den = fma(ts.x, tb, 1.0);                             // in [0.97, 1.03]
+    const double num = T + tb;
+    const double den = fma(T, tb, 1.0);                                // in [0.97, 1.03]
+    // quotient with ONE final rounding: y1 = 1/den to 2^-48, r0 = num y1, exact residual num - den r0 folded back
+    // (a plain num * (1/den) rounds the reciprocal and the product: a full ulp more, which matters here because num
+    // and den can sit in the binade above the result)
     const double y0 = __builtin_amdgcn_rcp(den);                       // 2^-24
-    const double y1 = fma(y0, fma(-den, y0, 1.0), y0);                 // 2^-48
-    const double r = fma(ts.y, tb * y1, ts.x);                         // >= 0
+    const double y1 = fma(y0, fma(-den, y0, 1.0), y0);
+    const double r0 = num * y1;
+    const double r = fma(fma(-den, r0, num), y1, r0);                  // >= 0
     if constexpr (!NANSAFE) return __builtin_copysign(r, x);
     const int xh = __double2hiint(x);
     const int nanmask = (0x7ff00000 - (xh & 0x7fffffff)) >> 31;        // all ones iff x is NaN
