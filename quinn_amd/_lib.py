@@ -57,14 +57,15 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIBPATH):
-        raise QuinnAmdError(f"{LIBPATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("QUINN_AMD_LIB", LIBPATH)      # A/B builds of the kernels (tools/ab_build.sh)
+    if not os.path.exists(path):
+        raise QuinnAmdError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     # torch ships its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).
     # It must be the one already mapped when this library is loaded, otherwise the process ends
     # up with two runtimes and ours sees no device / cannot share torch's streams and memory.
     import torch  # noqa: F401
-    L = ctypes.CDLL(LIBPATH)
+    L = ctypes.CDLL(path)
     vp, i32, i64, f64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_size_t
     L.qn_mlp_desc_create.argtypes = [ctypes.POINTER(i32), i32, i32, i32, ctypes.POINTER(vp)]
     L.qn_mlp_desc_create.restype = i32

@@ -479,7 +479,7 @@ __global__ void k_tanh_f64(const double* __restrict__ x, double* __restrict__ y,
 }
 template <bool NANSAFE>
 __global__ void k_tanh_f64_tab(const double* __restrict__ x, double* __restrict__ y, int64_t n) {
-    __shared__ double tab[QN_TANH_TAB_N + 1];
+    __shared__ double tab[QN_TANH_LDS_DOUBLES];
     qn_tanh_table_stage(tab, threadIdx.x, blockDim.x);
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -50,7 +50,7 @@ __host__ __device__ constexpr int stride_of(int H) { return (H + 31) / 32 * 32; 
 __host__ __device__ inline int lds_doubles(int H, int dp, int o, int nhid) {
     return H * dp + H + (nhid - 1) * (H * stride_of(H) + H) + o * H + o + 8;   // + reduction scratch
 }
-constexpr int TANH_TAB = (QN_TANH_TAB_N + 1) & ~1;      // doubles reserved for the tanh table behind an image
+constexpr int TANH_TAB = QN_TANH_LDS_DOUBLES;           // doubles reserved for the tanh table behind an image
 inline int padded_d(int d) { return d <= 2 ? 2 : 4; }
 
 template <int ACT, bool NANSAFE = true> __device__ __forceinline__ double act_apply(double z, const double* tab) {

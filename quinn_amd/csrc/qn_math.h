@@ -81,9 +81,18 @@ __device__ __forceinline__ bool qn_bounded(double v) {
 // Same contract as qn_tanh_f64_impl: NANSAFE = false for arguments that cannot be NaN (+-inf included).
 #include "qn_tanh_table.h"
 static __device__ const double qn_tanh_table_g[QN_TANH_TAB_N] = {QN_TANH_TAB_VALUES};
-// copy the table into LDS (call with all threads of the block, then synchronise)
+#ifdef QN_TANH_SFORM
+static __device__ const double qn_sech2_table_g[QN_TANH_TAB_N] = {QN_SECH2_TAB_VALUES};
+#define QN_TANH_LDS_DOUBLES (2 * (QN_TANH_TAB_N + 1))
+#else
+#define QN_TANH_LDS_DOUBLES (QN_TANH_TAB_N + 1)
+#endif
+// copy the table(s) into LDS (call with all threads of the block, then synchronise)
 __device__ __forceinline__ void qn_tanh_table_stage(double* lds_tab, int tid, int nthreads) {
     for (int e = tid; e < QN_TANH_TAB_N; e += nthreads) lds_tab[e] = qn_tanh_table_g[e];
+#ifdef QN_TANH_SFORM
+    for (int e = tid; e < QN_TANH_TAB_N; e += nthreads) lds_tab[QN_TANH_TAB_N + 1 + e] = qn_sech2_table_g[e];
+#endif
 }
 template <bool NANSAFE>
 __device__ __forceinline__ double qn_tanh_f64_tab(double x, const double* __restrict__ lds_tab) {
@@ -100,6 +109,16 @@ __device__ __forceinline__ double qn_tanh_f64_tab(double x, const double* __rest
     q = fma(q, b2, 1.33333333333333333e-01);                           // 2/15
     q = fma(q, b2, -3.33333333333333333e-01);                          // -1/3
     const double tb = fma(b * b2, q, b);
+#ifdef QN_TANH_SFORM
+    // A/B variant: tanh(a + b) = T + S tb / (1 + T tb), S = 1 - T^2 from a second table; the correction can be as
+    // large as the result (n = 1, b < 0), so its quotient needs the cubic Newton step
+    const double S = lds_tab[QN_TANH_TAB_N + 1 + __double2loint(zm)];
+    const double den = fma(T, tb, 1.0);
+    const double y0 = __builtin_amdgcn_rcp(den);
+    const double e0 = fma(-den, y0, 1.0);
+    const double y1 = fma(y0, fma(e0, e0, e0), y0);
+    const double r = fma(S, tb * y1, T);
+#else
     const double num = T + tb;
     const double den = fma(T, tb, 1.0);                                // in [0.97, 1.03]
     // quotient with ONE final rounding: y1 = 1/den to 2^-48, r0 = num y1, exact residual num - den r0 folded back
@@ -109,6 +128,7 @@ __device__ __forceinline__ double qn_tanh_f64_tab(double x, const double* __rest
     const double y1 = fma(y0, fma(-den, y0, 1.0), y0);
     const double r0 = num * y1;
     const double r = fma(fma(-den, r0, num), y1, r0);                  // >= 0
+#endif
     if constexpr (!NANSAFE) return __builtin_copysign(r, x);
     const int xh = __double2hiint(x);
     const int nanmask = (0x7ff00000 - (xh & 0x7fffffff)) >> 31;        // all ones iff x is NaN
