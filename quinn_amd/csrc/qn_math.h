@@ -78,21 +78,15 @@ __device__ __forceinline__ bool qn_bounded(double v) {
 //   tanh(b) = b + b^3 (-1/3 + 2/15 b^2 - 17/315 b^4 + 62/2835 b^6)   (next term 8e-18 relative at |b| = 1/32);
 //   tanh(a + b) = (tanh a + tanh b) / (1 + tanh a tanh b): no cancellation (tanh a >= 0.0624 > |tanh b| for n >= 1,
 //   and for n = 0 the result is tanh b itself), quotient by v_rcp_f64 + a residual-corrected division.
+//   (A/B-tested on one box, tools/ab_run.sh: the variant T + (1 - T^2) tb / (1 + T tb) with a second table, one DP
+//   instruction fewer, runs at the same speed -- the kernel is no longer limited by the last VALU instruction.)
 // Same contract as qn_tanh_f64_impl: NANSAFE = false for arguments that cannot be NaN (+-inf included).
 #include "qn_tanh_table.h"
 static __device__ const double qn_tanh_table_g[QN_TANH_TAB_N] = {QN_TANH_TAB_VALUES};
-#ifdef QN_TANH_SFORM
-static __device__ const double qn_sech2_table_g[QN_TANH_TAB_N] = {QN_SECH2_TAB_VALUES};
-#define QN_TANH_LDS_DOUBLES (2 * (QN_TANH_TAB_N + 1))
-#else
 #define QN_TANH_LDS_DOUBLES (QN_TANH_TAB_N + 1)
-#endif
-// copy the table(s) into LDS (call with all threads of the block, then synchronise)
+// copy the table into LDS (call with all threads of the block, then synchronise)
 __device__ __forceinline__ void qn_tanh_table_stage(double* lds_tab, int tid, int nthreads) {
     for (int e = tid; e < QN_TANH_TAB_N; e += nthreads) lds_tab[e] = qn_tanh_table_g[e];
-#ifdef QN_TANH_SFORM
-    for (int e = tid; e < QN_TANH_TAB_N; e += nthreads) lds_tab[QN_TANH_TAB_N + 1 + e] = qn_sech2_table_g[e];
-#endif
 }
 template <bool NANSAFE>
 __device__ __forceinline__ double qn_tanh_f64_tab(double x, const double* __restrict__ lds_tab) {
@@ -109,16 +103,6 @@ __device__ __forceinline__ double qn_tanh_f64_tab(double x, const double* __rest
     q = fma(q, b2, 1.33333333333333333e-01);                           // 2/15
     q = fma(q, b2, -3.33333333333333333e-01);                          // -1/3
     const double tb = fma(b * b2, q, b);
-#ifdef QN_TANH_SFORM
-    // A/B variant: tanh(a + b) = T + S tb / (1 + T tb), S = 1 - T^2 from a second table; the correction can be as
-    // large as the result (n = 1, b < 0), so its quotient needs the cubic Newton step
-    const double S = lds_tab[QN_TANH_TAB_N + 1 + __double2loint(zm)];
-    const double den = fma(T, tb, 1.0);
-    const double y0 = __builtin_amdgcn_rcp(den);
-    const double e0 = fma(-den, y0, 1.0);
-    const double y1 = fma(y0, fma(e0, e0, e0), y0);
-    const double r = fma(S, tb * y1, T);
-#else
     const double num = T + tb;
     const double den = fma(T, tb, 1.0);                                // in [0.97, 1.03]
     // quotient with ONE final rounding: y1 = 1/den to 2^-48, r0 = num y1, exact residual num - den r0 folded back
@@ -128,7 +112,6 @@ __device__ __forceinline__ double qn_tanh_f64_tab(double x, const double* __rest
     const double y1 = fma(y0, fma(-den, y0, 1.0), y0);
     const double r0 = num * y1;
     const double r = fma(fma(-den, r0, num), y1, r0);                  // >= 0
-#endif
     if constexpr (!NANSAFE) return __builtin_copysign(r, x);
     const int xh = __double2hiint(x);
     const int nanmask = (0x7ff00000 - (xh & 0x7fffffff)) >> 31;        // all ones iff x is NaN
