@@ -10,6 +10,7 @@
 // LDS-resident weights.
 #include "qn_common.h"
 #include "qn_math.h"
+#include <type_traits>
 #include <algorithm>
 
 namespace {
@@ -455,20 +456,34 @@ __global__ __launch_bounds__(BLK) void k_gemm64(GemmArgs g, const T* __restrict_
                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sum += v[mi][ni][r];
-            if (__any(sum != sum)) {
+            if constexpr (std::is_same<T, double>::value) {
+                // float64: table-assisted tanh (qn_math.h); the operand tiles are free after the K loop, so the
+                // 321-entry table goes into Ps (workgroup-uniform branch: every thread reaches the barrier)
+                double* tab = reinterpret_cast<double*>(&Ps[0][0]);
+                qn_tanh_table_stage(tab, tid, BLK);
+                __syncthreads();
+                if (__any(sum != sum)) {
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
+                        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[mi][ni][r] = qn_tanh<T>(v[mi][ni][r]);
+                            for (int r = 0; r < 4; ++r) v[mi][ni][r] = qn_tanh_f64_tab<true>(v[mi][ni][r], tab);
+                } else {
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[mi][ni][r] = qn_tanh_f64_tab<false>(v[mi][ni][r], tab);
+                }
             } else {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[mi][ni][r] = qn_tanh_finite<T>(v[mi][ni][r]);
+                        for (int r = 0; r < 4; ++r) v[mi][ni][r] = qn_tanh<T>(v[mi][ni][r]);
             }
         } else if (g.act == QN_ACT_RELU) {
 #pragma unroll
