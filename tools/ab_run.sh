@@ -8,7 +8,10 @@ for i in $(seq $rounds); do
     out=$("$@" 2>/dev/null | tail -1)
     echo "$v $(echo "$out" | python3 -c 'import sys,json
 d=json.loads(sys.stdin.read())
-r=d.get("roofline",{})
-print(round(d.get("value",0)), r.get("kernel_ms"), d.get("extras",{}).get("grad_evals_per_s"))')"
+if "value" in d:
+    r=d.get("roofline",{})
+    print(round(d["value"]), r.get("kernel_ms"), d.get("extras",{}).get("grad_evals_per_s"))
+else:
+    print(json.dumps(d))')"
   done
 done
