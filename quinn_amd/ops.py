@@ -312,6 +312,8 @@ class BatchedMLP:
         sse = torch.empty(B, dtype=torch.float64, device=self.device)
         pred = torch.empty(B, Nb, o, dtype=self.tdt, device=self.device) if want_pred else None
         grad = torch.empty(B, self.p, dtype=self.tdt, device=self.device) if want_grad else None
+        if B == 0:                                   # nothing to evaluate (e.g. an empty shard of chains)
+            return sse, pred, grad
         bc = self._chunk(B, Nb, want_grad)
         ws = self._workspace(self.workspace_bytes(bc, Nb, want_grad))
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

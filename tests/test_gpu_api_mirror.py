@@ -72,3 +72,18 @@ def test_more_weight_vectors_than_one_launch_takes():
     pick = [0, 65534, 65535, 65536, 69999]
     ref = op.sse(W[pick]).cpu().numpy()
     assert np.array_equal(s[pick], ref) and np.isfinite(s).all()
+
+
+def test_empty_batch_and_argument_errors():
+    from quinn_amd.ops import MLPArch, BatchedMLP
+    from quinn_amd._lib import QuinnAmdError
+    arch = MLPArch((2, 8, 1), "tanh")
+    x, y = np.random.RandomState(0).rand(6, 2), np.zeros((6, 1))
+    op = BatchedMLP(arch, x, y)
+    s, g = op.sse_grad(np.zeros((0, arch.nparams)))
+    assert s.shape == (0,) and g.shape == (0, arch.nparams)
+    assert op.predict(np.zeros((0, arch.nparams))).shape == (0, 6, 1)
+    with pytest.raises(ValueError):
+        op.sse(np.zeros((3, arch.nparams + 1)))                  # wrong parameter count
+    with pytest.raises((QuinnAmdError, ValueError, RuntimeError)):
+        BatchedMLP(arch, np.zeros((0, 2)), np.zeros((0, 1))).sse(np.zeros((1, arch.nparams)))   # no data rows
