@@ -151,6 +151,18 @@ int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int
                    int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride, int64_t* step_ptr,
                    void* stream);
 
+/* qn_mcmc_accept_propose: qn_mcmc_accept that also writes the NEXT step's proposal from the state it has just decided
+ * (one launch and one pass over the state fewer per step): next_mode 0 = nothing more; 1 = prop_next = cur' + sd z +
+ * c1 z0 (qn_mcmc_propose); 2 = prop_next = cur' + delta[c, t_next, :] + s_iso z (qn_mcmc_apply_delta).  Same random
+ * numbers (streams of step + 1) and the same arithmetic as the separate kernels: results are bit-identical.
+ * prop_next may be the buffer `prop`. */
+int qn_mcmc_accept_propose(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int chain0,
+                           int64_t p, int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
+                           double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0, float* hist,
+                           int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride, int64_t* step_ptr,
+                           int next_mode, const double* sd, double c1, const double* delta, int t_next, double s_iso,
+                           double* prop_next, void* stream);
+
 /* qn_mcmc_propose_hist: the ADAPTED proposal of adaptive Metropolis (admcmc.py:52-70), drawn in sample
  *   space.  After an adaptation at step i the reference proposes from N(x, c (cov_i + 1e-8 I)) with
  *   cov_i the unbiased sample covariance of x_0..x_i and c = gamma 2.4^2 / p.  With the K distinct

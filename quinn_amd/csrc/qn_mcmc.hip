@@ -81,8 +81,8 @@ __global__ __launch_bounds__(BLK) void k_propose(const double* __restrict__ cur,
         normal2(ph, za, zb);
         const int64_t e0 = (int64_t)b * p + 2 * j;
         if (cur) {
-            out[e0] = cur[e0] + sd[e0] * za + c1 * z0;
-            if (2 * j + 1 < p) out[e0 + 1] = cur[e0 + 1] + sd[e0 + 1] * zb + c1 * z0;
+            out[e0] = fma(c1, z0, fma(sd[e0], za, cur[e0]));          // explicit: the fused accept kernel must match
+            if (2 * j + 1 < p) out[e0 + 1] = fma(c1, z0, fma(sd[e0 + 1], zb, cur[e0 + 1]));
         } else {
             out[e0] = za;
             if (2 * j + 1 < p) out[e0 + 1] = zb;
@@ -288,8 +288,8 @@ __global__ __launch_bounds__(BLK) void k_apply_delta(const double* __restrict__ 
     normal2(ph, za, zb);
     const double* d = delta + ((int64_t)b * TB + t) * p + j;
     const int64_t e0 = (int64_t)b * p + j;
-    out[e0] = cur[e0] + d[0] + s_iso * za;
-    if (j + 1 < p) out[e0 + 1] = cur[e0 + 1] + d[1] + s_iso * zb;
+    out[e0] = fma(s_iso, za, cur[e0] + d[0]);
+    if (j + 1 < p) out[e0 + 1] = fma(s_iso, zb, cur[e0 + 1] + d[1]);
 }
 
 struct AcceptArgs {
@@ -297,6 +297,17 @@ struct AcceptArgs {
     int chain0, nmcmc, kcap;
     int64_t p, pstride;
     uint64_t seed;
+};
+
+// Optional fusion of the NEXT step's proposal into the accept kernel (it already has the new state in registers):
+// the same formulas and the same random numbers (streams of step + 1) as k_propose / k_apply_delta, so a fused run
+// is bit-identical to an unfused one.  mode 0: none; 1: initial proposal cur + sd z + c1 z0; 2: cur + delta[t] + s_iso z.
+struct NextArgs {
+    int mode, t;
+    double c1, s_iso;
+    const double* sd;
+    const double* delta;
+    double* out;
 };
 
 // one workgroup per chain, 1024 threads: the row updates are latency-bound (a handful of dependent 8-byte
@@ -310,9 +321,16 @@ __global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __r
                                                 int64_t* __restrict__ nacc, const double* __restrict__ x0,
                                                 float* __restrict__ hist, int32_t* __restrict__ mult,
                                                 int32_t* __restrict__ kcur, double* __restrict__ sumx,
-                                                int64_t* __restrict__ step_ptr) {
+                                                int64_t* __restrict__ step_ptr, NextArgs nx) {
     const int b = blockIdx.x;
     const int64_t step = *step_ptr;
+    double z0n = 0.0;
+    if (nx.mode == 1 && nx.c1 != 0.0) {
+        Philox pz;
+        pz.gen(a.seed, 2 * (uint64_t)(step + 1) + 1, ctr_of(a.chain0 + b, 1, 0));
+        double dummy;
+        normal2(pz, z0n, dummy);
+    }
     const double plp = -(a.half_inv_sig2 * sse_prop[b] + a.lp_const);
     const double clp = cur_lp[b];
     const double mh = exp(plp - clp);                               // exp(current_U - proposed_U), mcmc.py:69-72
@@ -353,6 +371,16 @@ __global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __r
                 const double dv = v[u] - xv[u];
                 if (hrow) hrow[e] = (float)dv;
                 sumx[base + e] = sv[u] + dv;
+            }
+            if (nx.mode) {                                          // proposal of step + 1 from the new state
+                Philox pn;
+                pn.gen(a.seed, 2 * (uint64_t)(step + 1), ctr_of(a.chain0 + b, 0, (uint64_t)(e >> 1)));
+                double za, zb;
+                normal2(pn, za, zb);
+                const double z = (e & 1) ? zb : za;
+                // same association as k_propose / k_apply_delta: (cur + first term) + second term
+                nx.out[base + e] = nx.mode == 1 ? fma(nx.c1, z0n, fma(nx.sd[base + e], z, v[u]))
+                                                : fma(nx.s_iso, z, v[u] + nx.delta[((int64_t)b * TB + nx.t) * a.p + e]);
             }
         }
     }
@@ -477,8 +505,37 @@ extern "C" int qn_mcmc_accept(const double* prop, const double* sse_prop, double
     a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
     a.chain0 = chain0; a.nmcmc = nmcmc; a.kcap = kcap; a.p = p; a.pstride = pstride; a.seed = seed;
     (void)hipGetLastError();
+    NextArgs nx;
+    nx.mode = 0; nx.t = 0; nx.c1 = 0.0; nx.s_iso = 0.0; nx.sd = nullptr; nx.delta = nullptr; nx.out = nullptr;
     hipLaunchKernelGGL(k_accept, dim3(C), dim3(ABLK), 0, static_cast<hipStream_t>(stream), a, prop, sse_prop, cur, cur_lp,
-                       best, best_lp, chain, lps, alphas, nacc, x0, hist, mult, kcur, sumx, step_ptr);
+                       best, best_lp, chain, lps, alphas, nacc, x0, hist, mult, kcur, sumx, step_ptr, nx);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
+
+extern "C" int qn_mcmc_accept_propose(const double* prop, const double* sse_prop, double sigma, int n_rows, int C,
+                                      int chain0, int64_t p, int nmcmc, uint64_t seed, double* cur, double* cur_lp,
+                                      double* best, double* best_lp, double* chain, double* lps, double* alphas,
+                                      int64_t* nacc, const double* x0, float* hist, int32_t* mult, int32_t* kcur,
+                                      double* sumx, int kcap, int64_t pstride, int64_t* step_ptr, int next_mode,
+                                      const double* sd, double c1, const double* delta, int t_next, double s_iso,
+                                      double* prop_next, void* stream) {
+    if (!prop || !sse_prop || !cur || !cur_lp || !best || !best_lp || !lps || !alphas || !nacc || !step_ptr ||
+        C <= 0 || chain0 < 0 || p <= 0 || sigma <= 0.0 || (hist && (!x0 || !mult || !kcur || !sumx || kcap <= 0 || pstride < p)) ||
+        next_mode < 0 || next_mode > 2 || (next_mode && !prop_next) || (next_mode == 1 && !sd) ||
+        (next_mode == 2 && (!delta || t_next < 0 || t_next >= TB))) {
+        qn_set_error("qn_mcmc_accept_propose: bad argument");
+        return QN_EINVAL;
+    }
+    AcceptArgs a;
+    a.half_inv_sig2 = 0.5 / (sigma * sigma);
+    a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
+    a.chain0 = chain0; a.nmcmc = nmcmc; a.kcap = kcap; a.p = p; a.pstride = pstride; a.seed = seed;
+    NextArgs nx;
+    nx.mode = next_mode; nx.t = t_next; nx.c1 = c1; nx.s_iso = s_iso; nx.sd = sd; nx.delta = delta; nx.out = prop_next;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_accept, dim3(C), dim3(ABLK), 0, static_cast<hipStream_t>(stream), a, prop, sse_prop, cur, cur_lp,
+                       best, best_lp, chain, lps, alphas, nacc, x0, hist, mult, kcur, sumx, step_ptr, nx);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }

@@ -44,7 +44,7 @@ from ..ops import BatchedMLP
 
 class DeviceAMCMC:
     def __init__(self, op: BatchedMLP, sigma, gamma=0.1, t0=100, tadapt=1000, cov_ini=None, seed=0,
-                 use_graph=False, max_history_bytes=64 << 30, chain0=0):
+                 use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=True):
         if op.dtype != "float64":
             raise NotImplementedError("the device AMCMC engine runs the float64 operator")
         self.op, self.sigma = op, float(sigma)
@@ -54,6 +54,7 @@ class DeviceAMCMC:
         self.seed = int(seed) & (2 ** 63 - 1)
         self.use_graph = use_graph
         self.max_history_bytes = int(max_history_bytes)
+        self.fuse_propose = bool(fuse_propose)     # next step's proposal written by the accept kernel
         self.chain0 = int(chain0)      # global id of this engine's first chain (random streams are keyed by it)
         self._L = _lib.lib()
 
@@ -81,8 +82,19 @@ class DeviceAMCMC:
                                                self.chain0, p, self.seed, s['step'].data_ptr(), out.data_ptr(), self._stream()),
                    "qn_mcmc_apply_delta")
 
-    def _accept(self, s, prop, sse, nmcmc):
+    def _accept(self, s, prop, sse, nmcmc, nxt=None):
         C, p = prop.shape
+        if nxt is not None:
+            mode, sd, c1, delta, t, s_iso = nxt
+            _lib.check(self._L.qn_mcmc_accept_propose(
+                prop.data_ptr(), sse.data_ptr(), self.sigma, self.op.N, C, self.chain0, p, nmcmc, self.seed,
+                s['cur'].data_ptr(), s['cur_lp'].data_ptr(), s['best'].data_ptr(), s['best_lp'].data_ptr(),
+                s['chain'].data_ptr() if s['chain'] is not None else None, s['lps'].data_ptr(), s['alphas'].data_ptr(),
+                s['nacc'].data_ptr(), s['x0'].data_ptr(), s['hist'].data_ptr(), s['mult'].data_ptr(),
+                s['kcur'].data_ptr(), s['sumx'].data_ptr(), s['hist'].shape[1], s['hist'].shape[2], s['step'].data_ptr(),
+                mode, sd.data_ptr() if sd is not None else None, c1, delta.data_ptr() if delta is not None else None,
+                int(t), s_iso, prop.data_ptr(), self._stream()), "qn_mcmc_accept_propose")
+            return
         _lib.check(self._L.qn_mcmc_accept(
             prop.data_ptr(), sse.data_ptr(), self.sigma, self.op.N, C, self.chain0, p, nmcmc, self.seed, s['cur'].data_ptr(),
             s['cur_lp'].data_ptr(), s['best'].data_ptr(), s['best_lp'].data_ptr(),
@@ -120,7 +132,7 @@ class DeviceAMCMC:
         s['lps'][:, 0] = cur_lp
         std0 = torch.sqrt(0.09 * s['x0'].abs())
         prop = torch.empty(C, p, dtype=f64, device=dev)
-        state = {'snap': None, 'L': None}
+        state = {'snap': None, 'L': None, 'have_prop': False}
         if self.cov_ini is not None:
             state['L'] = torch.linalg.cholesky(torch.as_tensor(np.asarray(self.cov_ini), dtype=f64, device=dev))
             z = torch.empty(C, p, dtype=f64, device=dev)
@@ -129,21 +141,39 @@ class DeviceAMCMC:
         G = TB                                                              # steps per captured graph
         coef = delta = None
 
-        def step_initial():
+        fuse = self.fuse_propose
+
+        def run_initial(n, last_fused):
+            """n steps with the initial proposal; with fusion every accept but the last also writes the next
+            step's proposal (last_fused: the step after these n is an initial-proposal step too)."""
             if state['L'] is not None:                                      # user-supplied initial covariance
-                self._propose(None, None, 0.0, s['step'], z)
-                prop.copy_(s['cur'] + z @ state['L'].T)
-            else:
-                self._propose(s['cur'], std0, 0.1, s['step'], prop)
-            self._accept(s, prop, self.op.sse(prop), nmcmc)
+                for _ in range(n):
+                    self._propose(None, None, 0.0, s['step'], z)
+                    prop.copy_(s['cur'] + z @ state['L'].T)
+                    self._accept(s, prop, self.op.sse(prop), nmcmc)
+                return False
+            have = state['have_prop']
+            for k in range(n):
+                if not have:
+                    self._propose(s['cur'], std0, 0.1, s['step'], prop)
+                nxt = (1, std0, 0.1, None, 0, 0.0) if fuse and (k + 1 < n or last_fused) else None
+                self._accept(s, prop, self.op.sse(prop), nmcmc, nxt)
+                have = nxt is not None
+            return have
 
         def block_adapted(nsteps):
             # increments of TB consecutive steps in ONE pass over the history (they do not depend on the chain's
-            # state), then nsteps <= TB steps; the block starts at the device step counter
+            # state), then nsteps <= TB steps; the block starts at the device step counter.  With fusion the accept
+            # kernel of step t writes the proposal of step t + 1 (inside the block)
             self._propose_hist_block(s, state['snap'], coef, delta)
+            snap = state['snap']
+            have = False
             for t in range(nsteps):
-                self._apply_delta(s, state['snap'], delta, t, prop)
-                self._accept(s, prop, self.op.sse(prop), nmcmc)
+                if not have:
+                    self._apply_delta(s, snap, delta, t, prop)
+                nxt = (2, None, 0.0, delta, t + 1, snap['s_iso']) if fuse and t + 1 < nsteps else None
+                self._accept(s, prop, self.op.sse(prop), nmcmc, nxt)
+                have = nxt is not None
 
         def capture(fn):
             g = torch.cuda.CUDAGraph()
@@ -168,12 +198,12 @@ class DeviceAMCMC:
             adapted = state['snap'] is not None
             nfull, rest = divmod(nrun, G)
             if self.use_graph and nfull > 0 and (adapted or state['L'] is None):   # (torch matmul path: not captured)
-                # G steps = 4 G launches (+3 for the block kernels) captured once and replayed: the launch gaps of
-                # dependent kernels, ~6 us each when issued one by one, mostly disappear
+                # G steps captured once and replayed (no faster than direct launches at cfg2; kept as an option)
                 key = 'adapted' if adapted else 'initial'
                 if graphs[key] is None:
                     graphs[key] = capture((lambda: block_adapted(G)) if adapted
-                                          else (lambda: [step_initial() for _ in range(G)]))
+                                          else (lambda: run_initial(G, False)))
+                state['have_prop'] = False
                 for _ in range(nfull):
                     graphs[key].replay()
             else:
@@ -182,9 +212,9 @@ class DeviceAMCMC:
                 while rest > 0:
                     block_adapted(min(rest, TB))
                     rest -= min(rest, TB)
-            else:
-                for _ in range(rest):
-                    step_initial()
+            elif rest > 0:
+                # the run of initial-proposal steps ends at an adaptation (new regime) or at the end of the chain
+                state['have_prop'] = run_initial(rest, False)
             i += nrun
             if verbose:
                 print('%d / %d completed, acceptance rate %lg' % (i, nmcmc, float(s['nacc'].double().mean()) / i))

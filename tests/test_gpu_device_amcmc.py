@@ -182,6 +182,25 @@ def test_chains_do_not_depend_on_how_they_are_split():
     assert (whole['accrate'] > 0).all()
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_next_proposal_is_bit_identical(graph):
+    """qn_mcmc_accept_propose (next step's proposal written by the accept kernel) uses the same random numbers and
+    arithmetic as the separate kernels: identical chains, through initial and adapted proposals and block edges."""
+    from quinn_amd.mcmc.device_amcmc import DeviceAMCMC
+    from quinn_amd.ops import MLPArch, BatchedMLP
+    x, y = _problem(6)
+    arch = MLPArch((1, 8, 8, 1), "tanh")
+    op = BatchedMLP(arch, x, y)
+    C, nmcmc = 5, 333
+    ini = np.stack([np.random.RandomState(900 + c).rand(arch.nparams) for c in range(C)])
+    kw = dict(gamma=0.1, t0=40, tadapt=100, seed=21, use_graph=graph)
+    a = DeviceAMCMC(op, 0.2, fuse_propose=False, **kw).run(nmcmc, ini)
+    b = DeviceAMCMC(op, 0.2, fuse_propose=True, **kw).run(nmcmc, ini)
+    for k in ('chain', 'logpost', 'alphas', 'accrate', 'mapparams', 'maxpost'):
+        assert torch.equal(a[k], b[k]), k
+    assert (a['accrate'] > 0).all()
+
+
 def test_device_engine_matches_host_sampler_in_distribution():
     x, y = _problem(1)
     torch.manual_seed(1)
