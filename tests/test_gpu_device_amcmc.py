@@ -143,9 +143,9 @@ def test_history_of_distinct_states_matches_the_chain():
     captured = {}
     orig = eng._accept
 
-    def spy(s, prop, sse, n):
+    def spy(s, *args, **kw):
         captured['s'] = s
-        return orig(s, prop, sse, n)
+        return orig(s, *args, **kw)
     eng._accept = spy
     r = eng.run(nmcmc, ini)
     s = captured['s']
