@@ -151,14 +151,6 @@ int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int
                    int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride, int64_t* step_ptr,
                    void* stream);
 
-/* qn_mcmc_accept_mb: qn_mcmc_accept spread over several blocks per chain (grid chunks x chains); arrive [C] int32 is
- * scratch of the kernel, zero before the first call (it resets itself).  Same results. */
-int qn_mcmc_accept_mb(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int chain0, int64_t p,
-                      int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp, double* chain,
-                      double* lps, double* alphas, int64_t* nacc, const double* x0, float* hist, int32_t* mult,
-                      int32_t* kcur, double* sumx, int kcap, int64_t pstride, int32_t* arrive, int64_t* step_ptr,
-                      void* stream);
-
 /* qn_mcmc_accept_propose: qn_mcmc_accept that also writes the NEXT step's proposal from the state it has just decided
  * (one launch and one pass over the state fewer per step): next_mode 0 = nothing more; 1 = prop_next = cur' + sd z +
  * c1 z0 (qn_mcmc_propose); 2 = prop_next = cur' + delta[c, t_next, :] + s_iso z (qn_mcmc_apply_delta).  Same random

@@ -414,81 +414,6 @@ __global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __r
     }
 }
 
-// ---- multi-block variant of the accept kernel: grid (chunks, chains), 256 threads, 4 elements per thread.  Every
-// block of a chain takes the same decision from the same scalars (read at entry); the LAST block of the chain to
-// finish (arrival counter arrive[c], self-resetting) writes the chain's scalars back; the last chain advances the
-// step counter.  Selected by the engine with accept_blocks='multi'.
-constexpr int ACH = 4 * BLK;            // elements per block
-__global__ __launch_bounds__(BLK) void k_accept_mb(AcceptArgs a, const double* __restrict__ prop,
-                                                const double* __restrict__ sse_prop, double* __restrict__ cur,
-                                                double* __restrict__ cur_lp, double* __restrict__ best,
-                                                double* __restrict__ best_lp, double* __restrict__ chain,
-                                                double* __restrict__ lps, double* __restrict__ alphas,
-                                                int64_t* __restrict__ nacc, const double* __restrict__ x0,
-                                                float* __restrict__ hist, int32_t* __restrict__ mult,
-                                                int32_t* __restrict__ kcur, double* __restrict__ sumx,
-                                                int32_t* __restrict__ arrive, int64_t* __restrict__ step_ptr) {
-    const int b = blockIdx.y;
-    const int64_t step = *step_ptr;
-    const double plp = -(a.half_inv_sig2 * sse_prop[b] + a.lp_const);
-    const double clp = cur_lp[b];
-    const double mh = exp(plp - clp);                               // exp(current_U - proposed_U), mcmc.py:69-72
-    Philox ph;
-    ph.gen(a.seed, 2 * (uint64_t)step + 1, ctr_of(a.chain0 + b, 2, 0));
-    const double u = u01(ph.c[0], ph.c[1]);
-    const bool take = u < mh;                                       // NaN -> reject, inf -> accept, as `u < mh_prob`
-    const double nlp = take ? plp : clp;
-    const bool better = take && nlp >= best_lp[b];
-    const int64_t base = (int64_t)b * a.p;
-    double* crow = chain ? chain + ((int64_t)b * (a.nmcmc + 1) + step + 1) * a.p : nullptr;
-    // history of DISTINCT states (shifted by x0, float32) with multiplicities, and the running sum of all
-    // samples: what the adapted proposal is drawn from (k_propose_hist)
-    const int kc = hist ? kcur[b] : 0;
-    const int knew = take ? kc + 1 : kc;
-    float* hrow = (hist && take && knew < a.kcap) ? hist + ((int64_t)b * a.kcap + knew) * a.pstride : nullptr;
-    const int64_t e1 = ((int64_t)blockIdx.x + 1) * ACH < a.p ? ((int64_t)blockIdx.x + 1) * ACH : a.p;
-    for (int64_t e = (int64_t)blockIdx.x * ACH + threadIdx.x; e < e1; e += BLK) {
-        const double v = take ? prop[base + e] : cur[base + e];
-        if (take) cur[base + e] = v;
-        if (better) best[base + e] = v;
-        if (crow) crow[e] = v;
-        if (hist) {
-            const double dv = v - x0[base + e];
-            if (hrow) hrow[e] = (float)dv;
-            sumx[base + e] += dv;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const bool chain_last = atomicAdd(reinterpret_cast<unsigned int*>(arrive + b), 1u) == gridDim.x - 1;
-        if (chain_last) {
-            arrive[b] = 0;
-            if (hist) {
-                if (take) {
-                    kcur[b] = knew;                                 // knew >= kcap: history full, the host checks
-                    if (knew < a.kcap) mult[(int64_t)b * a.kcap + knew] = 1;
-                } else if (kc < a.kcap) {
-                    mult[(int64_t)b * a.kcap + kc] += 1;
-                }
-            }
-            cur_lp[b] = nlp;
-            if (better) best_lp[b] = nlp;
-            lps[(int64_t)b * (a.nmcmc + 1) + step + 1] = nlp;
-            alphas[(int64_t)b * (a.nmcmc + 1) + step + 1] = mh;
-            if (take) nacc[b] += 1;
-            // the step counter is advanced by the last CHAIN to finish (one contended atomic per chain, not per block;
-            // every block has read the counter at entry, before its chain could be counted)
-            __threadfence();
-            const unsigned int arrived = atomicAdd(reinterpret_cast<unsigned int*>(step_ptr + 1), 1u);
-            if (arrived == gridDim.y - 1) {
-                reinterpret_cast<unsigned int*>(step_ptr + 1)[0] = 0u;
-                *step_ptr = step + 1;
-            }
-        }
-    }
-}
-
 }  // namespace
 
 extern "C" int qn_mcmc_propose(const double* cur, const double* sd, double c1, int C, int chain0, int64_t p,
@@ -584,29 +509,6 @@ extern "C" int qn_mcmc_accept(const double* prop, const double* sse_prop, double
     nx.mode = 0; nx.t = 0; nx.c1 = 0.0; nx.s_iso = 0.0; nx.sd = nullptr; nx.delta = nullptr; nx.out = nullptr;
     hipLaunchKernelGGL(k_accept, dim3(C), dim3(ABLK), 0, static_cast<hipStream_t>(stream), a, prop, sse_prop, cur, cur_lp,
                        best, best_lp, chain, lps, alphas, nacc, x0, hist, mult, kcur, sumx, step_ptr, nx);
-    QN_HIP_CHECK(hipGetLastError());
-    return QN_OK;
-}
-
-extern "C" int qn_mcmc_accept_mb(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int chain0,
-                                 int64_t p, int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best,
-                                 double* best_lp, double* chain, double* lps, double* alphas, int64_t* nacc,
-                                 const double* x0, float* hist, int32_t* mult, int32_t* kcur, double* sumx, int kcap,
-                                 int64_t pstride, int32_t* arrive, int64_t* step_ptr, void* stream) {
-    if (!prop || !sse_prop || !cur || !cur_lp || !best || !best_lp || !lps || !alphas || !nacc || !step_ptr || !arrive ||
-        C <= 0 || C > 65535 || chain0 < 0 || p <= 0 || sigma <= 0.0 ||
-        (hist && (!x0 || !mult || !kcur || !sumx || kcap <= 0 || pstride < p))) {
-        qn_set_error("qn_mcmc_accept_mb: bad argument");
-        return QN_EINVAL;
-    }
-    AcceptArgs a;
-    a.half_inv_sig2 = 0.5 / (sigma * sigma);
-    a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
-    a.chain0 = chain0; a.nmcmc = nmcmc; a.kcap = kcap; a.p = p; a.pstride = pstride; a.seed = seed;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(k_accept_mb, dim3((unsigned)((p + ACH - 1) / ACH), C), dim3(BLK), 0, static_cast<hipStream_t>(stream),
-                       a, prop, sse_prop, cur, cur_lp, best, best_lp, chain, lps, alphas, nacc, x0, hist, mult, kcur, sumx,
-                       arrive, step_ptr);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }

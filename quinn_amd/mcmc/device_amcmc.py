@@ -44,8 +44,7 @@ from ..ops import BatchedMLP
 
 class DeviceAMCMC:
     def __init__(self, op: BatchedMLP, sigma, gamma=0.1, t0=100, tadapt=1000, cov_ini=None, seed=0,
-                 use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=False,
-                 accept_blocks='single'):
+                 use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=False):
         if op.dtype != "float64":
             raise NotImplementedError("the device AMCMC engine runs the float64 operator")
         self.op, self.sigma = op, float(sigma)
@@ -58,7 +57,6 @@ class DeviceAMCMC:
         # next step's proposal written by the accept kernel (bit-identical; A/B on one box: 2-3 % SLOWER than the
         # separate proposal kernel, which spreads over the whole chip while the accept kernel runs one block per chain)
         self.fuse_propose = bool(fuse_propose)
-        self.accept_blocks = accept_blocks         # 'single': one 1024-thread block per chain; 'multi': chunks x chains
         self.chain0 = int(chain0)      # global id of this engine's first chain (random streams are keyed by it)
         self._L = _lib.lib()
 
@@ -99,15 +97,6 @@ class DeviceAMCMC:
                 mode, sd.data_ptr() if sd is not None else None, c1, delta.data_ptr() if delta is not None else None,
                 int(t), s_iso, prop.data_ptr(), self._stream()), "qn_mcmc_accept_propose")
             return
-        if self.accept_blocks == 'multi':
-            _lib.check(self._L.qn_mcmc_accept_mb(
-                prop.data_ptr(), sse.data_ptr(), self.sigma, self.op.N, C, self.chain0, p, nmcmc, self.seed,
-                s['cur'].data_ptr(), s['cur_lp'].data_ptr(), s['best'].data_ptr(), s['best_lp'].data_ptr(),
-                s['chain'].data_ptr() if s['chain'] is not None else None, s['lps'].data_ptr(), s['alphas'].data_ptr(),
-                s['nacc'].data_ptr(), s['x0'].data_ptr(), s['hist'].data_ptr(), s['mult'].data_ptr(),
-                s['kcur'].data_ptr(), s['sumx'].data_ptr(), s['hist'].shape[1], s['hist'].shape[2],
-                s['arrive'].data_ptr(), s['step'].data_ptr(), self._stream()), "qn_mcmc_accept_mb")
-            return
         _lib.check(self._L.qn_mcmc_accept(
             prop.data_ptr(), sse.data_ptr(), self.sigma, self.op.N, C, self.chain0, p, nmcmc, self.seed, s['cur'].data_ptr(),
             s['cur_lp'].data_ptr(), s['best'].data_ptr(), s['best_lp'].data_ptr(),
@@ -137,7 +126,6 @@ class DeviceAMCMC:
              'mult': torch.zeros(C, kcap, dtype=torch.int32, device=dev),
              'kcur': torch.zeros(C, dtype=torch.int32, device=dev),
              'sumx': torch.zeros(C, p, dtype=f64, device=dev),
-             'arrive': torch.zeros(C, dtype=torch.int32, device=dev),
              'step': torch.zeros(2, dtype=torch.int64, device=dev)}
         s['hist'][:, 0] = 0.0                                               # row 0 = x_0 - x_0
         s['mult'][:, 0] = 1

@@ -21,9 +21,7 @@ UG = os.environ.get("USE_GRAPH", "0") == "1"
 res = {"use_graph": UG, "nmcmc": NMCMC}
 FUSE = os.environ.get("QN_FUSE", "0") == "1"
 res["fuse_propose"] = FUSE
-res["accept_blocks"] = os.environ.get("QN_ACCEPT", "single")
-eng = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=1000, seed=1, use_graph=UG, fuse_propose=FUSE,
-                  accept_blocks=os.environ.get("QN_ACCEPT", "single"))
+eng = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=1000, seed=1, use_graph=UG, fuse_propose=FUSE)
 eng.run(20, ini, store_chain=True)                      # warm-up (first launches)
 # warm the caching allocator with the run's two large buffers (chain f64, state history f32): a fresh
 # hipMalloc of ~33 GB costs several hundred ms and is not part of the stepping rate
