@@ -945,8 +945,7 @@ void qn_arrive_free(qn_arrive_state* s) {
     delete s;
 }
 static unsigned int* arrive_for(qn_arrive_state* s, hipStream_t st) {
-    static const bool off = std::getenv("QN_TWO_KERNEL_SUM") != nullptr;      // A/B switch: separate k_sum_partials launch
-    if (!s || off) return nullptr;
+    if (!s) return nullptr;
     std::lock_guard<std::mutex> lock(s->mu);
     for (auto& kv : s->slots)
         if (kv.first == st) return kv.second;
