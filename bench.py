@@ -187,9 +187,7 @@ def main():
                 out = run(batches[i])
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        # captured on the stream that ran the warm-up: the library keeps its arrival counters per stream and does
-        # not allocate while a capture is in progress
-        with torch.cuda.graph(graph, stream=side):
+        with torch.cuda.graph(graph):
             for i in range(args.graph):
                 out = run(batches[i % NBATCH])
         graph.replay()

@@ -58,7 +58,6 @@ extern "C" int qn_mlp_desc_create(const int* dims, int ndims, int act, int has_b
     d->p = off;
     d->kind = QN_KIND_MLP;
     d->padded = nullptr;
-    d->arrive = qn_arrive_new();
     // hidden widths <= 64 that are not one common 16 / 32 / 64: zero-padded twin for the fused kernels
     if (d->nlayers >= 2) {
         int hmax = 0;
@@ -81,7 +80,6 @@ extern "C" int qn_mlp_desc_create(const int* dims, int ndims, int act, int has_b
             q->p = o2;
             q->hmax = H > q->dims[q->nlayers] ? H : q->dims[q->nlayers];
             q->padded = nullptr;
-            q->arrive = qn_arrive_new();
             d->padded = q;
         }
     }
@@ -125,19 +123,12 @@ extern "C" int qn_rnet_desc_create(int indim, int rdim, int outdim, int nsteps, 
     d->rn_offBB = off; if (has_bias) off += (int64_t)npar * rdim;
     d->p = off;
     d->padded = nullptr;
-    d->arrive = nullptr;
     *out = d;
     return QN_OK;
 }
 
 extern "C" int qn_mlp_desc_destroy(qn_desc* d) {
-    if (d) {
-        if (d->padded) {
-            qn_arrive_free(d->padded->arrive);
-            delete d->padded;
-        }
-        qn_arrive_free(d->arrive);
-    }
+    if (d) delete d->padded;
     delete d;
     return QN_OK;
 }

@@ -26,12 +26,7 @@ struct qn_desc {
     // ---- MLP whose hidden widths are <= 64 but not all equal to 16 / 32 / 64: the same network with every hidden
     // layer zero-padded to one of those widths, which the fused kernels take (qn_api.hip: pad -> fused -> unpad)
     qn_desc* padded;
-    // ---- arrival counters of the fused forward kernel's in-kernel final sum: one zeroed block of device memory per
-    // stream that has used this descriptor (qn_fused.hip); the only device memory the library owns
-    struct qn_arrive_state* arrive;
 };
-struct qn_arrive_state* qn_arrive_new();
-void qn_arrive_free(struct qn_arrive_state*);
 enum { QN_KIND_MLP = 0, QN_KIND_RNET = 1 };
 
 void qn_set_error(const char* fmt, ...);

@@ -26,8 +26,6 @@
 #include <cstdlib>
 #include <type_traits>
 #include <mutex>
-#include <utility>
-#include <vector>
 #include <unordered_set>
 
 namespace {
@@ -43,8 +41,6 @@ struct FusedArgs {
     int B, N, Nb, d, o, nhid, act, has_bias;
     int nsplit, rows_per_split, iters;
     int64_t dbg_off;     // diagnostic builds: offset (doubles, from the partials) of a 12-word scratch
-    unsigned int* arrive;   // forward kernel: per-chain arrival counters (zero between launches) or NULL
-    double* sse_out;        // forward kernel with arrive != NULL: the last block of a chain writes sse_out[b]
 };
 
 __host__ __device__ constexpr int swz(int j) { return ((j & 1) << 4) | (((j >> 1) & 7) << 1); }
@@ -293,21 +289,6 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
         double s = 0.0;
         for (int w = 0; w < NT / 64; ++w) s += red[w];
         partial[(int64_t)b * a.nsplit + split] = s;
-        if (a.arrive) {
-            // in-kernel final sum: the LAST row-split of a chain to arrive adds the nsplit partials in index order
-            // (bitwise the same value as k_sum_partials) -- one launch and its gap less per evaluation.  Device-scope
-            // release / acquire around the arrival count: the partials cross XCDs (separate L2s).
-            __threadfence();
-            const unsigned int old = atomicAdd(a.arrive + b, 1u);
-            if (old == (unsigned int)a.nsplit - 1u) {
-                a.arrive[b] = 0u;
-                __threadfence();
-                double tot = 0.0;
-                for (int k = 0; k < a.nsplit; ++k)
-                    tot += __hip_atomic_load(partial + (int64_t)b * a.nsplit + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a.sse_out[b] = tot;
-            }
-        }
     }
 }
 
@@ -933,37 +914,6 @@ int arm_lds(const void* fn) {
 
 }  // namespace
 
-// ---- per-(descriptor, stream) arrival counters (65536 zeroed words each), allocated on first use outside a capture
-struct qn_arrive_state {
-    std::mutex mu;
-    std::vector<std::pair<hipStream_t, unsigned int*>> slots;
-};
-qn_arrive_state* qn_arrive_new() { return new qn_arrive_state(); }
-void qn_arrive_free(qn_arrive_state* s) {
-    if (!s) return;
-    for (auto& kv : s->slots) (void)hipFree(kv.second);
-    delete s;
-}
-static unsigned int* arrive_for(qn_arrive_state* s, hipStream_t st) {
-    if (!s) return nullptr;
-    std::lock_guard<std::mutex> lock(s->mu);
-    for (auto& kv : s->slots)
-        if (kv.first == st) return kv.second;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return nullptr;                     // first use inside a graph capture: no allocation, two-kernel path
-    }
-    unsigned int* ptr = nullptr;
-    if (hipMalloc(&ptr, 65536 * sizeof(unsigned int)) != hipSuccess || hipMemset(ptr, 0, 65536 * sizeof(unsigned int)) != hipSuccess) {
-        (void)hipGetLastError();
-        if (ptr) (void)hipFree(ptr);
-        return nullptr;
-    }
-    s->slots.emplace_back(st, ptr);
-    return ptr;
-}
-
 bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
     int H, nhid;
     if (dtype != QN_F64) return false;
@@ -994,7 +944,6 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
     FusedArgs a;
     a.p = d->p; a.B = B; a.N = N; a.Nb = Nb; a.d = d->dims[0]; a.o = d->dims[d->nlayers]; a.nhid = nhid;
     a.act = d->act; a.has_bias = d->has_bias;
-    a.arrive = nullptr; a.sse_out = nullptr;
     plan(d, B, Nb, want_grad, &a);
     const size_t npart = qn_align((size_t)B * a.nsplit * sizeof(double));
     const size_t need = npart + (want_grad ? qn_align((size_t)B * a.nsplit * d->p * sizeof(double)) : 0);
@@ -1015,14 +964,8 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
             return QN_EUNSUPPORTED;
         }
         if (int rc = arm_lds(reinterpret_cast<const void*>(kern))) return rc;
-        a.arrive = arrive_for(d->arrive, st);
-        a.sse_out = sse;
         hipLaunchKernelGGL(kern, grid, dim3(WG), lds_bytes, st, a, (const double*)W,
                            (const double*)X, (const double*)Y, row_idx, (double*)pred, partial);
-        if (a.arrive) {                     // the kernel wrote sse itself
-            QN_HIP_CHECK(hipGetLastError());
-            return QN_OK;
-        }
     } else {
         bwd_fn kern = pick_bwd(H, nhid);
         if (!kern) {

@@ -177,20 +177,9 @@ class DeviceAMCMC:
                 self._accept(s, prop, self.op.sse(prop), nmcmc, nxt)
                 have = nxt is not None
 
-        side = None
-
         def capture(fn):
-            # capture on a stream that has already run the operator once: the library keeps per-stream arrival
-            # counters and does not allocate them while a capture is in progress
-            nonlocal side
-            if side is None:
-                side = torch.cuda.Stream(device=dev)
-                side.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(side):
-                    self.op.sse(s['cur'])
-                torch.cuda.current_stream(dev).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g):
                 fn()
             return g
 
