@@ -853,7 +853,13 @@ constexpr int G_FWD = 2;
 void plan(const qn_desc* d, int B, int Nb, int want_grad, FusedArgs* a) {
     // rows one workgroup covers per iteration; target workgroups per chip: 2/CU forward, 1/CU backward
     const int rows_it = want_grad ? ROWS_IT : (WG / 64) * 16 * G_FWD;
-    const int target = want_grad ? 256 : 512;
+#ifndef QN_FWD_TARGET
+#define QN_FWD_TARGET 512
+#endif
+#ifndef QN_BWD_TARGET
+#define QN_BWD_TARGET 256
+#endif
+    const int target = want_grad ? QN_BWD_TARGET : QN_FWD_TARGET;
     const int max_split = (Nb + rows_it - 1) / rows_it;
     int nsplit = (target + B - 1) / B;
     if (nsplit > max_split) nsplit = max_split;
