@@ -10,14 +10,15 @@ from quinn_amd.nns.mlp import MLP
 from quinn_amd.solvers.nn_vi import NN_VI
 from quinn_amd.solvers.nn_ens import NN_Ens
 import quinn_amd.nns.nnfit as nf
-out = {}
+DT = os.environ.get("QN_DTYPE", "float64")      # float32: the layer-wise kernels in single precision (master weights stay float64)
+out = {"dtype": DT}
 rs = np.random.RandomState(0)
 # ---- cfg3
 N = 8192
 x = rs.rand(N, 2) * 2 * np.pi - np.pi
 y = np.sin(x).sum(axis=1, keepdims=True) + 0.02 * rs.randn(N, 1)
 torch.manual_seed(0)
-vi = NN_VI(MLP(2, 1, (128, 128, 128), activ='tanh'), rng='device')
+vi = NN_VI(MLP(2, 1, (128, 128, 128), activ='tanh'), rng='device', dtype=DT)
 vi.fit(x, y, val=[x[:1024], y[:1024]], datanoise=0.02, lrate=0.01, nsam=128, nepochs=1, freq_out=1000)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 vi.fit(x, y, val=[x[:1024], y[:1024]], datanoise=0.02, lrate=0.01, nsam=128, nepochs=5, freq_out=1000)
@@ -28,7 +29,7 @@ out["cfg3_vi_mc_sample_evals_per_s"] = (128 * 2 + 128 * 1024 / N) / el     # tra
 N = 16384
 x = rs.rand(N, 1) * 2 * np.pi - np.pi
 y = np.sin(x) + 0.02 * rs.randn(N, 1)
-ens = NN_Ens(MLP(1, 1, (256, 256, 256, 256), activ='tanh'), nens=512, dfrac=0.8)
+ens = NN_Ens(MLP(1, 1, (256, 256, 256, 256), activ='tanh'), nens=512, dfrac=0.8, dtype=DT)
 ens.fit(x, y, val=[x[:2048], y[:2048]], lrate=0.01, nepochs=1, perm_mode='device', freq_out=1000)
 def timed(ne):
     torch.cuda.synchronize(); t0 = time.perf_counter()
