@@ -225,14 +225,23 @@ int run_padded(const qn_desc* d, const double* W, const void* X, const void* Y, 
 }
 }  // namespace
 
+static bool use_rnet_fused(const qn_desc* d, int want_grad, int dtype) {
+    return d->kind == QN_KIND_RNET && g_forced_path.load() != QN_PATH_GENERIC && qn_rnet_fused_supported(d, want_grad, dtype);
+}
+
 extern "C" int qn_mlp_path(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
     if (!d) return QN_EINVAL;
+    if (d->kind == QN_KIND_RNET) return use_rnet_fused(d, want_grad, dtype) ? QN_PATH_FUSED : QN_PATH_GENERIC;
     return use_fused(d, B, Nb, want_grad, dtype) ? QN_PATH_FUSED : QN_PATH_GENERIC;
 }
 
 extern "C" size_t qn_workspace_bytes(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
     if (!d || B <= 0 || Nb <= 0) return 0;
-    if (d->kind == QN_KIND_RNET) return qn_rnet_workspace(d, B, Nb, want_grad, dtype);
+    if (d->kind == QN_KIND_RNET) {      // sized for either family so that qn_set_path never invalidates a caller's buffer
+        const size_t g = qn_rnet_workspace(d, B, Nb, want_grad, dtype);
+        const size_t f = qn_rnet_fused_supported(d, want_grad, dtype) ? qn_rnet_fused_workspace(d, B, Nb, want_grad) : 0;
+        return g > f ? g : f;
+    }
     // sized for either family so that qn_set_path never invalidates a caller's buffer
     size_t g = qn_generic_workspace(d, B, Nb, want_grad, dtype);
     size_t f = fused_ok(d, B, Nb, want_grad, dtype) ? fused_ws(d, B, Nb, want_grad, dtype) : 0;
@@ -268,8 +277,15 @@ static int run(const char* fn, const qn_desc* d, int dtype, const void* W, const
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int want_grad = gradW != nullptr;
-    if (d->kind == QN_KIND_RNET)
+    if (d->kind == QN_KIND_RNET) {
+        if (g_forced_path.load() == QN_PATH_FUSED && !qn_rnet_fused_supported(d, want_grad, dtype)) {
+            qn_set_error("%s: fused path forced but not supported for this residual network", fn);
+            return QN_EUNSUPPORTED;
+        }
+        if (use_rnet_fused(d, want_grad, dtype))
+            return qn_rnet_fused_run(d, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
         return qn_rnet_run(d, dtype, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
+    }
     if (g_forced_path.load() == QN_PATH_FUSED && !fused_ok(d, B, Nb, want_grad, dtype)) {
         qn_set_error("%s: fused path forced but not supported for this shape", fn);
         return QN_EUNSUPPORTED;

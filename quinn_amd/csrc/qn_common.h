@@ -56,6 +56,12 @@ int qn_rnet_run(const qn_desc* d, int dtype, const void* W, const void* X, const
                 const int32_t* row_idx, int B, int N, int Nb, double* sse, void* pred,
                 void* gradW, void* ws, size_t ws_bytes, hipStream_t st);
 
+// ---- small residual networks, one launch: qn_rnet.hip
+bool qn_rnet_fused_supported(const qn_desc* d, int want_grad, int dtype);
+size_t qn_rnet_fused_workspace(const qn_desc* d, int B, int Nb, int want_grad);
+int qn_rnet_fused_run(const qn_desc* d, const void* W, const void* X, const void* Y, const int32_t* row_idx, int B, int N,
+                      int Nb, double* sse, void* pred, void* gradW, void* ws, size_t ws_bytes, hipStream_t st);
+
 // ---- fused MFMA path with LDS-resident weights: qn_fused.hip
 bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtype);
 size_t qn_fused_workspace(const qn_desc* d, int B, int Nb, int want_grad, int dtype);

@@ -93,6 +93,56 @@ def test_random_rnets_vs_oracle(case, dtype):
                                    atol=gt)
 
 
+FUSED_SPECS = [  # small residual networks the single-launch kernels take (qn_rnet.hip): spec, N, B
+    (RNetSpec(3, 3, "poly", 0, 1, 1, layer_pre=True, layer_post=True), 300, 5),        # examples/ex_ufit.py
+    (RNetSpec(5, 3, "nonpar", 0, 2, 1, layer_pre=True, layer_post=True), 77, 3),
+    (RNetSpec(3, 4, "lin", 0), 130, 2),                                               # no pre / post layer
+    (RNetSpec(4, 15, "nonpar", 0, 2, 3, layer_pre=True, layer_post=True), 513, 2),     # 16 steps
+    (RNetSpec(8, 6, "poly", 2, 4, 4, layer_pre=True, layer_post=True), 65, 4),         # widest: smaller blocks
+    (RNetSpec(6, 2, "cubic", 0, 2, 2, layer_pre=True, layer_post=True, bias=False, nonlin=False), 40, 3),
+    (RNetSpec(4, 3, "quad", 0, 2, 1, mlp=True, layer_pre=True, layer_post=True), 1, 2),  # one row, plain layers
+    (RNetSpec(2, 1, "const", 0, 2, 4, layer_post=True), 33, 70),                       # post only, many chains
+]
+
+
+@pytest.mark.parametrize("use_idx", [False, True])
+@pytest.mark.parametrize("case", FUSED_SPECS, ids=[f"r{c[0].rdim}L{c[0].nlayers}{c[0].wp_kind}" for c in FUSED_SPECS])
+def test_single_launch_kernels_equal_layerwise_and_oracle(case, use_idx):
+    from quinn_amd import _lib
+    spec, N, B = case
+    rs = np.random.RandomState(spec.rdim * 17 + spec.nlayers + N)
+    x = rs.uniform(-2, 2, (N, spec.d))
+    y = rs.randn(N, spec.o)
+    W = 0.4 * rs.randn(B, spec.nparams)
+    idx = rs.randint(0, N, size=(B, max(1, N // 2 + 1))).astype(np.int32) if use_idx else None
+    op = BatchedMLP(MLPArch.from_module(_net_from_spec(spec)), x, y)
+    L = _lib.lib()
+    assert op.path(B, N, True) == _lib.PATH_FUSED
+    res = {}
+    for path in (_lib.PATH_GENERIC, _lib.PATH_FUSED):
+        old = L.qn_set_path(path)
+        try:
+            s, g = op.sse_grad(W, row_idx=idx)
+            s2, pr = op.sse_pred(W, row_idx=idx)
+        finally:
+            L.qn_set_path(old)
+        res[path] = (s.cpu().numpy(), g.cpu().numpy(), s2.cpu().numpy(), pr.cpu().numpy())
+    a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_FUSED]
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-12)
+    np.testing.assert_allclose(b[2], b[0], rtol=1e-13)
+    assert np.abs(b[1] - a[1]).max() <= 1e-10 * max(np.abs(a[1]).max(), 1e-300)
+    np.testing.assert_allclose(b[3], a[3], rtol=1e-11, atol=1e-12)
+    if idx is None:
+        mod = mlp_ref.build_module(spec)
+        for k in range(min(B, 2)):
+            np.testing.assert_allclose(b[0][k], mlp_ref.sse(mod, W[k], x, y), rtol=1e-11)
+            ref_g = -mlp_ref.logpostgrad(mod, W[k], x, [v for v in y], 1.0) * 2.0
+            assert np.max(np.abs(b[1][k] - ref_g)) / np.abs(ref_g).max() < 1e-10
+    # run-to-run bitwise determinism of the fused gradient
+    s3, g3 = op.sse_grad(W, row_idx=idx)
+    assert np.array_equal(g3.cpu().numpy(), b[1]) and np.array_equal(s3.cpu().numpy(), b[0])
+
+
 def test_minibatch_rows_per_member():
     """row_idx gathers (the ensemble trainer's minibatches) on an RNet."""
     spec = RNetSpec(6, 2, "quad", 0, 2, 1, layer_pre=True, layer_post=True)
