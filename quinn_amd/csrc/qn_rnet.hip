@@ -113,10 +113,11 @@ __device__ __forceinline__ void forward_row(const RnFusedArgs& a, const double* 
         }
         if (GRAD) {
 #pragma unroll
-            for (int j = 0; j < R; ++j) {
-                stash[(size_t)((2 * i) * R + j) * T] = out[j];          // out_i
-                stash[(size_t)((2 * i + 1) * R + j) * T] = th[j];       // act(z_i)
-            }
+            for (int j = 0; j < R; ++j)
+                if (j < a.r) {
+                    stash[(size_t)((2 * i) * a.r + j) * T] = out[j];          // out_i
+                    stash[(size_t)((2 * i + 1) * a.r + j) * T] = th[j];       // act(z_i)
+                }
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) out[j] = a.mlp ? th[j] : fma(h, th[j], out[j]);
@@ -180,15 +181,15 @@ __global__ __launch_bounds__(256) void k_rnet_bwd(RnFusedArgs a, const double* _
                                                   double* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
-    const int T = a.T, per = R * R + R;
+    const int T = a.T, per = R * R + R, r = a.r, perr = r * r + r;   // per: padded image stride; perr: actual entries
     double* tab = lds + ((img_doubles<R>(a.S) + 1) & ~1);
     double* red = tab + QN_TANH_LDS_DOUBLES + 1;                 // 8 doubles
-    double* stash = red + 8;                                     // [2 S R][T]
-    double* accW = stash + (size_t)2 * a.S * R * T;              // [S * per][T]
+    double* stash = red + 8;                                     // [2 S r][T]
+    double* accW = stash + (size_t)2 * a.S * r * T;              // [S * perr][T]
     const int b = blockIdx.y, tid = threadIdx.x;
     stage<R>(a, W + (int64_t)b * a.p, lds, tid, T);
     qn_tanh_table_stage(tab, tid, T);
-    for (int e = tid; e < a.S * per * T; e += T) accW[e] = 0.0;
+    for (int e = tid; e < a.S * perr * T; e += T) accW[e] = 0.0;
     __syncthreads();
     const double* Wpre = lds;
     const double* Weff = lds + R * DOMAX + R;
@@ -256,21 +257,23 @@ __global__ __launch_bounds__(256) void k_rnet_bwd(RnFusedArgs a, const double* _
             double oi[R], dz[R];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                oi[j] = mystash[(size_t)((2 * i) * R + j) * T];
-                const double th = mystash[(size_t)((2 * i + 1) * R + j) * T];
-                dz[j] = sc * g[j] * act_d(th, a.act);
+                oi[j] = j < r ? mystash[(size_t)((2 * i) * r + j) * T] : 0.0;
+                const double th = j < r ? mystash[(size_t)((2 * i + 1) * r + j) * T] : 0.0;
+                dz[j] = j < r ? sc * g[j] * act_d(th, a.act) : 0.0;
             }
-            double* ai = myacc + (size_t)i * per * T;
+            double* ai = myacc + (size_t)i * perr * T;
             double gn[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) gn[k] = a.mlp ? 0.0 : g[k];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                ai[(size_t)(R * R + j) * T] += dz[j];
+                if (j < r) {
+                    ai[(size_t)(r * r + j) * T] += dz[j];
 #pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    ai[(size_t)(j * R + k) * T] = fma(dz[j], oi[k], ai[(size_t)(j * R + k) * T]);
-                    gn[k] = fma(Wi[j * R + k], dz[j], gn[k]);
+                    for (int k = 0; k < R; ++k) {
+                        if (k < r) ai[(size_t)(j * r + k) * T] = fma(dz[j], oi[k], ai[(size_t)(j * r + k) * T]);
+                        gn[k] = fma(Wi[j * R + k], dz[j], gn[k]);
+                    }
                 }
             }
 #pragma unroll
@@ -280,8 +283,8 @@ __global__ __launch_bounds__(256) void k_rnet_bwd(RnFusedArgs a, const double* _
         if (a.pre) {
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                const double o0 = mystash[(size_t)j * T];
-                const double dzp = g[j] * act_d(o0, a.act);
+                const double o0 = j < r ? mystash[(size_t)j * T] : 0.0;
+                const double dzp = j < r ? g[j] * act_d(o0, a.act) : 0.0;
                 gbpre[j] += dzp;
 #pragma unroll
                 for (int k = 0; k < DOMAX; ++k) gWpre[j][k] = fma(dzp, x[k], gWpre[j][k]);
@@ -293,10 +296,20 @@ __global__ __launch_bounds__(256) void k_rnet_bwd(RnFusedArgs a, const double* _
     const int nimg = img_doubles<R>(a.S);
     double* dst = slab + ((int64_t)b * a.nblk + blockIdx.x) * nimg;
     // step gradients: entry e summed over the T thread-private columns (fixed order)
-    for (int e = tid; e < a.S * per; e += T) {
-        const double* rowp = accW + (size_t)e * T;
+    for (int e = tid; e < a.S * per; e += T) {                   // e in the padded image layout [S][R*R + R]
+        const int i = e / per, q = e % per;
+        int src = -1;                                             // row of the compact accumulator [S][r*r + r]
+        if (q < R * R) {
+            const int j = q / R, k = q % R;
+            if (j < r && k < r) src = i * perr + j * r + k;
+        } else if (q - R * R < r) {
+            src = i * perr + r * r + (q - R * R);
+        }
         double s = 0.0;
-        for (int t = 0; t < T; ++t) s += rowp[(t + e) % T];        // rotate the start: no bank conflict between threads
+        if (src >= 0) {
+            const double* rowp = accW + (size_t)src * T;
+            for (int t = 0; t < T; ++t) s += rowp[(t + e) % T];    // rotate the start: no bank conflict between threads
+        }
         dst[R * DOMAX + R + e] = s;
     }
     // pre / post gradients: registers -> wave sums -> LDS scratch (reuse the stash) -> fixed-order sum over waves
@@ -394,14 +407,14 @@ int pad_r(int r) { return r <= 4 ? 4 : 8; }
 template <int R> size_t fwd_lds(int S) {
     return sizeof(double) * (size_t)(((img_doubles<R>(S) + 1) & ~1) + QN_TANH_LDS_DOUBLES + 1 + 8);
 }
-template <int R> size_t bwd_lds(int S, int T) {
-    return fwd_lds<R>(S) + sizeof(double) * (size_t)(2 * S * R + S * (R * R + R)) * T;
+template <int R> size_t bwd_lds(int S, int T, int r) {
+    return fwd_lds<R>(S) + sizeof(double) * (size_t)(2 * S * r + S * (r * r + r)) * T;
 }
 constexpr size_t LDS_BUDGET = 150 * 1024;
 
-template <int R> int pick_T(int S) {
+template <int R> int pick_T(int S, int r) {
     for (int T : {256, 128, 64})
-        if (bwd_lds<R>(S, T) <= LDS_BUDGET) return T;
+        if (bwd_lds<R>(S, T, r) <= LDS_BUDGET) return T;
     return 0;
 }
 
@@ -427,7 +440,7 @@ template <int R>
 int run(const qn_desc* d, RnFusedArgs& a, const double* W, const double* X, const double* Y, const int32_t* row_idx,
         double* sse, double* pred, double* gradW, void* ws, size_t ws_bytes, hipStream_t st) {
     const bool grad = gradW != nullptr;
-    a.T = grad ? pick_T<R>(a.S) : 256;
+    a.T = grad ? pick_T<R>(a.S, a.r) : 256;
     a.nblk = blocks_for(a.B, a.Nb, a.T);
     const size_t npart = qn_align((size_t)a.B * a.nblk * sizeof(double));
     const size_t nslab = grad ? qn_align((size_t)a.B * a.nblk * img_doubles<R>(a.S) * sizeof(double)) : 0;
@@ -454,7 +467,7 @@ int run(const qn_desc* d, RnFusedArgs& a, const double* W, const double* X, cons
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             armed = true;
         }
-        hipLaunchKernelGGL(k_rnet_bwd<R>, dim3(a.nblk, a.B), dim3(a.T), bwd_lds<R>(a.S, a.T), st, a, W, X, Y, row_idx, pred,
+        hipLaunchKernelGGL(k_rnet_bwd<R>, dim3(a.nblk, a.B), dim3(a.T), bwd_lds<R>(a.S, a.T, a.r), st, a, W, X, Y, row_idx, pred,
                            partial, slab);
         int gx = (int)((a.p + 255) / 256);
         if (gx > 16) gx = 16;
@@ -472,12 +485,12 @@ bool qn_rnet_fused_supported(const qn_desc* d, int want_grad, int dtype) {
     if (d->rn_r > RMAX || d->dims[0] > DOMAX || d->dims[2] > DOMAX) return false;
     if (d->act != QN_ACT_TANH && d->act != QN_ACT_IDENTITY) return false;
     if (!want_grad) return true;
-    return (pad_r(d->rn_r) == 4 ? pick_T<4>(d->rn_steps) : pick_T<8>(d->rn_steps)) > 0;
+    return (pad_r(d->rn_r) == 4 ? pick_T<4>(d->rn_steps, d->rn_r) : pick_T<8>(d->rn_steps, d->rn_r)) > 0;
 }
 
 size_t qn_rnet_fused_workspace(const qn_desc* d, int B, int Nb, int want_grad) {
     const int R = pad_r(d->rn_r);
-    const int T = want_grad ? (R == 4 ? pick_T<4>(d->rn_steps) : pick_T<8>(d->rn_steps)) : 256;
+    const int T = want_grad ? (R == 4 ? pick_T<4>(d->rn_steps, d->rn_r) : pick_T<8>(d->rn_steps, d->rn_r)) : 256;
     const int nblk = blocks_for(B, Nb, T ? T : 256);
     const int nimg = R == 4 ? img_doubles<4>(d->rn_steps) : img_doubles<8>(d->rn_steps);
     return qn_align((size_t)B * nblk * sizeof(double)) + (want_grad ? qn_align((size_t)B * nblk * nimg * sizeof(double)) : 0) + 256;

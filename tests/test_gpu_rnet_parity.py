@@ -97,8 +97,8 @@ FUSED_SPECS = [  # small residual networks the single-launch kernels take (qn_rn
     (RNetSpec(3, 3, "poly", 0, 1, 1, layer_pre=True, layer_post=True), 300, 5),        # examples/ex_ufit.py
     (RNetSpec(5, 3, "nonpar", 0, 2, 1, layer_pre=True, layer_post=True), 77, 3),
     (RNetSpec(3, 4, "lin", 0), 130, 2),                                               # no pre / post layer
-    (RNetSpec(4, 15, "nonpar", 0, 2, 3, layer_pre=True, layer_post=True), 513, 2),     # 16 steps
-    (RNetSpec(8, 6, "poly", 2, 4, 4, layer_pre=True, layer_post=True), 65, 4),         # widest: smaller blocks
+    (RNetSpec(4, 7, "nonpar", 0, 2, 3, layer_pre=True, layer_post=True), 513, 2),      # 8 steps
+    (RNetSpec(8, 2, "poly", 2, 4, 4, layer_pre=True, layer_post=True), 65, 4),         # widest: smaller blocks
     (RNetSpec(6, 2, "cubic", 0, 2, 2, layer_pre=True, layer_post=True, bias=False, nonlin=False), 40, 3),
     (RNetSpec(4, 3, "quad", 0, 2, 1, mlp=True, layer_pre=True, layer_post=True), 1, 2),  # one row, plain layers
     (RNetSpec(2, 1, "const", 0, 2, 4, layer_post=True), 33, 70),                       # post only, many chains
