@@ -253,3 +253,20 @@ def test_descriptor_argument_checks():
         BatchedMLP(RNetArch(2, 3, 1, 2, ((1.0,), (1.0,)), layer_pre=False, layer_post=True), np.zeros((1, 2)), None)
     with pytest.raises(Exception):
         BatchedMLP(RNetArch(3, 3, 3, 17, tuple((1.0,) for _ in range(17))), np.zeros((1, 3)), None)
+
+
+@pytest.mark.parametrize("sampler,sp", [("amcmc", {'gamma': 0.1, 't0': 50, 'tadapt': 100}), ("hmc", {'epsilon': 0.01, 'L': 3})])
+def test_device_engines_run_on_the_ex_ufit_network(sampler, sp):
+    """engine='device' (states, proposals and history on the GPU) with the residual network of examples/ex_ufit.py."""
+    rs = np.random.RandomState(3)
+    x = rs.rand(14, 1) * 2 * np.pi - np.pi
+    y = np.sin(x) + 0.02 * rs.randn(14, 1)
+    torch.manual_seed(5)
+    solver = NN_MCMC(R.RNet(3, 3, wp_function=R.Poly(0), indim=1, outdim=1, layer_pre=True, layer_post=True), verbose=False)
+    solver.fit(x, y, zflag=False, datanoise=0.2, nmcmc=400, sampler=sampler, sampler_params=sp, seeds=list(range(6)),
+               engine='device')
+    r = solver.mcmc_results
+    assert r['chain'].shape == (6, 401, 22) and np.isfinite(r['logpost']).all()
+    assert (np.asarray(r['accrate']) > 0.02).all()
+    assert (r['logpost'][:, -100:].mean(axis=1) > r['logpost'][:, 0]).all()      # climbed from the random start
+    assert solver.predict_ens(x, nens=5, nburn=100, chain=0).shape == (5, 14, 1)
