@@ -294,6 +294,206 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
 
 
 // =============================================================================================
+// Streaming forward for H = 128 (float64).  One 128 x 128 float64 matrix is 128 KB, so the image of
+// ALL layers no longer fits the 160 KB of LDS; this kernel keeps the thin pieces (first / last layer,
+// every bias) resident and streams the hidden matrices through ONE 128 KB swizzled buffer: each
+// layer's matrix is copied from L2 into the buffer between two barriers before its MFMA loop.  A workgroup is
+// 8 waves (2 per SIMD), 128 data rows per iteration, one workgroup per CU; activations stay in
+// registers between layers exactly as in k_fused_fwd_f64.  Per iteration and layer the MFMAs take
+// ~33 k cycles per SIMD, the restaging ~1 k cycles of LDS writes plus two barriers.
+constexpr int HS = 128;
+constexpr int NTS = 512;
+__host__ __device__ inline int stream_thin_doubles(int dp, int o, int nhid) {
+    return HS * dp + HS + (nhid - 1) * HS + o * HS + o + 16;      // + 8 wave sums, flag, padding
+}
+__host__ __device__ inline int stream_lds_doubles(int dp, int o, int nhid) {
+    return ((stream_thin_doubles(dp, o, nhid) + 1) & ~1) + ((TANH_TAB + 1) & ~1) + HS * HS;
+}
+
+template <int ACT, int DP>
+__global__ __launch_bounds__(NTS, 1) void k_fused_fwd_stream_f64(FusedArgs a, const double* __restrict__ W,
+                                                                  const double* __restrict__ X,
+                                                                  const double* __restrict__ Y,
+                                                                  const int32_t* __restrict__ row_idx,
+                                                                  double* __restrict__ pred_out,
+                                                                  double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    constexpr int H = HS, T = H / 16, NT = NTS, PER = H * H / NT;
+    const int b = blockIdx.y, split = blockIdx.x;
+    const int d = a.d, o = a.o, NH = a.nhid;
+    const int nb = a.has_bias ? 1 : 0;
+    const int offW0 = 0, offb0 = H * DP, offbh = offb0 + H;
+    const int offWl = offbh + (NH - 1) * H, offbl = offWl + o * H;
+    double* red = lds + ((offbl + o + 1) & ~1);
+    int* flag = reinterpret_cast<int*>(red + 8);
+    double* tab = lds + ((stream_thin_doubles(DP, o, NH) + 1) & ~1);
+    double* Wbuf = tab + ((TANH_TAB + 1) & ~1);
+    const double* tanh_tab = tab;
+    const double* Wb = W + (int64_t)b * a.p;
+    const int tid = threadIdx.x;
+    const int64_t gb0 = (int64_t)H * d, gHH = gb0 + nb * H, blk = (int64_t)H * H + nb * H;
+    const int64_t gWl = gHH + (int64_t)(NH - 1) * blk, gbl = gWl + (int64_t)o * H;
+
+    qn_tanh_table_stage(tab, tid, NT);
+    {
+        int bad = 0;
+        auto chk = [&](double v) { bad |= !qn_bounded(v); return v; };
+        for (int e = tid; e < H * DP; e += NT) {
+            const int j = e / DP, k = e % DP;
+            lds[offW0 + e] = k < d ? chk(Wb[j * d + k]) : 0.0;
+        }
+        for (int e = tid; e < H; e += NT) lds[offb0 + e] = nb ? chk(Wb[gb0 + e]) : 0.0;
+        for (int layer = 1; layer < NH; ++layer)
+            for (int e = tid; e < H; e += NT)
+                lds[offbh + (layer - 1) * H + e] = nb ? chk(Wb[gHH + (layer - 1) * blk + H * H + e]) : 0.0;
+        for (int e = tid; e < o * H; e += NT) lds[offWl + e] = chk(Wb[gWl + e]);
+        for (int e = tid; e < o; e += NT) lds[offbl + e] = nb ? chk(Wb[gbl + e]) : 0.0;
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        if (bad) *flag = 1;                       // sticky: set again by any hidden matrix staged later
+    }
+
+    // copy one hidden matrix (L2-resident after the first workgroup touched it) into the swizzled
+    // buffer, PB loads in flight per thread; element e = tid + u NT of the row-major [H][H] block
+    constexpr int PB = 16;
+    auto stage_w = [&](int layer) {
+        const double* src = Wb + gHH + (int64_t)(layer - 1) * blk;
+        int bad = 0;
+        int tl = tid;
+        asm volatile("" : "+v"(tl));              // addresses are recomputed here, not kept live across the row loop
+#pragma unroll
+        for (int u0 = 0; u0 < PER; u0 += PB) {
+            double v[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) v[u] = src[tl + (u0 + u) * NT];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int e = tl + (u0 + u) * NT;
+                const int j = e / H, i = e % H;
+                Wbuf[j * H + (i ^ swz(j))] = v[u];
+                bad |= !qn_bounded(v[u]);
+            }
+        }
+        if (bad) *flag = 1;
+    };
+    const bool restage = NH > 2;                  // with one hidden matrix it is staged once
+    if (NH == 2) stage_w(1);
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    const int fl = swz(c);
+    double sse = 0.0;
+
+    double xn[DP], yn[OMAX];
+    int nrow_n = 0, xbad_n = 0;
+    bool valid_n = false;
+    auto fetch = [&](int it) {
+        xbad_n = 0;
+        const int n = split * a.rows_per_split + (it * (NT / 64) + wave) * 16 + c;
+        valid_n = n < a.Nb;
+        nrow_n = n;
+        const int nn = valid_n ? n : 0;
+        const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            xn[k] = k < d ? X[rr * d + k] : 0.0;
+            xbad_n |= !qn_bounded(xn[k]);
+        }
+#pragma unroll
+        for (int qo = 0; qo < OMAX; ++qo) yn[qo] = qo < o ? Y[rr * o + qo] : 0.0;
+    };
+    fetch(0);
+    for (int it = 0; it < a.iters; ++it) {
+        double act[T][4];
+        double xk[DP], yk[OMAX];
+        const bool valid = valid_n;
+        const int nrow = nrow_n;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) xk[k] = xn[k];
+#pragma unroll
+        for (int qo = 0; qo < OMAX; ++qo) yk[qo] = yn[qo];
+        const bool xbad = __any(xbad_n);
+        if (it + 1 < a.iters) fetch(it + 1);
+        auto first_layer = [&](auto tag) {
+            constexpr bool NS = decltype(tag)::value;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = 16 * t + q + 4 * i;
+                    double z = lds[offb0 + j];
+#pragma unroll
+                    for (int k = 0; k < DP; ++k) z = fma(lds[offW0 + j * DP + k], xk[k], z);
+                    act[t][i] = act_apply<ACT, NS>(z, tanh_tab);
+                }
+        };
+        if (ACT == QN_ACT_TANH && !(xbad || *flag != 0)) first_layer(std::false_type{});
+        else first_layer(std::true_type{});
+        for (int layer = 1; layer < NH; ++layer) {
+            if (restage) {
+                __syncthreads();                  // every wave is done with the previous matrix
+                stage_w(layer);
+                __syncthreads();
+            }
+            const bool nan_possible = xbad || *flag != 0;
+            const double* bl = lds + offbh + (layer - 1) * H;
+            int fls = fl;
+            asm volatile("" : "+v"(fls));         // same for the 32 swizzled fragment columns
+            v4d acc[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t][i] = bl[16 * t + q + 4 * i];
+#pragma unroll
+            for (int s = 0; s < H / 4; ++s) {
+                const int col = (4 * s + q) ^ fls;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const double aw = Wbuf[(16 * t + c) * H + col];
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, act[s >> 2][s & 3], acc[t], 0, 0, 0);
+                }
+            }
+            auto epilogue = [&](auto tag) {
+                constexpr bool NS = decltype(tag)::value;
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) act[t][i] = act_apply<ACT, NS>(acc[t][i], tanh_tab);
+            };
+            if (ACT == QN_ACT_TANH && !nan_possible) epilogue(std::false_type{});
+            else epilogue(std::true_type{});
+        }
+#pragma unroll
+        for (int qo = 0; qo < OMAX; ++qo) {
+            if (qo >= o) break;
+            double part = 0.0;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) part = fma(lds[offWl + qo * H + 16 * t + q + 4 * i], act[t][i], part);
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            const double pr = part + lds[offbl + qo];
+            const double res = pr - yk[qo];
+            if (valid && q == 0) {
+                sse += res * res;
+                if (pred_out) pred_out[((int64_t)b * a.Nb + nrow) * o + qo] = pr;
+            }
+        }
+    }
+    sse = wave_sum(sse);
+    if (lane == 0) red[wave] = sse;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < NT / 64; ++w) s += red[w];
+        partial[(int64_t)b * a.nsplit + split] = s;
+    }
+}
+
+// =============================================================================================
 // Fused forward + backward (float64): gradient of the SSE w.r.t. every weight, per chain.
 //
 // One workgroup = 4 waves = 64 data rows per iteration (one 16-row group per wave), one chain.
@@ -850,16 +1050,20 @@ bool uniform_hidden(const qn_desc* d, int* H, int* nhid) {
 
 constexpr int G_FWD = 2;
 
+bool streams(const qn_desc* d, int want_grad) { return !want_grad && d->nlayers >= 2 && d->dims[1] == HS; }
+
 void plan(const qn_desc* d, int B, int Nb, int want_grad, FusedArgs* a) {
     // rows one workgroup covers per iteration; target workgroups per chip: 2/CU forward, 1/CU backward
-    const int rows_it = want_grad ? ROWS_IT : (WG / 64) * 16 * G_FWD;
+    // (and streaming forward: its 128 KB matrix buffer leaves room for one workgroup per CU)
+    const bool stream = streams(d, want_grad);
+    const int rows_it = want_grad ? ROWS_IT : (stream ? (NTS / 64) * 16 : (WG / 64) * 16 * G_FWD);
 #ifndef QN_FWD_TARGET
 #define QN_FWD_TARGET 512
 #endif
 #ifndef QN_BWD_TARGET
 #define QN_BWD_TARGET 256
 #endif
-    const int target = want_grad ? QN_BWD_TARGET : QN_FWD_TARGET;
+    const int target = want_grad || stream ? QN_BWD_TARGET : QN_FWD_TARGET;
     const int max_split = (Nb + rows_it - 1) / rows_it;
     int nsplit = (target + B - 1) / B;
     if (nsplit > max_split) nsplit = max_split;
@@ -873,6 +1077,7 @@ void plan(const qn_desc* d, int B, int Nb, int want_grad, FusedArgs* a) {
 }
 
 size_t lds_need(int H, int d, int o, int nhid, int want_grad) {
+    if (H == HS) return sizeof(double) * (size_t)(stream_lds_doubles(padded_d(d), o, nhid) + 2);
     return sizeof(double) * (size_t)((want_grad ? bwd_lds_doubles(H, 4, o, nhid) : lds_doubles(H, padded_d(d), o, nhid)) +
                                      2 + TANH_TAB);
 }
@@ -893,6 +1098,11 @@ fwd_fn pick_fwd(int H, int act, int dp) {
     QN_PICK(HH, QN_ACT_RELU, 4) QN_PICK(HH, QN_ACT_IDENTITY, 2) QN_PICK(HH, QN_ACT_IDENTITY, 4)
     QN_PICK_H(16) QN_PICK_H(32) QN_PICK_H(64)
 #undef QN_PICK_H
+#undef QN_PICK
+#define QN_PICK(AA, DD)                                                                        \
+    if (H == HS && act == AA && dp == DD) return k_fused_fwd_stream_f64<AA, DD>;
+    QN_PICK(QN_ACT_TANH, 2) QN_PICK(QN_ACT_TANH, 4) QN_PICK(QN_ACT_RELU, 2)
+    QN_PICK(QN_ACT_RELU, 4) QN_PICK(QN_ACT_IDENTITY, 2) QN_PICK(QN_ACT_IDENTITY, 4)
 #undef QN_PICK
     return nullptr;
 }
@@ -924,7 +1134,11 @@ bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtyp
     int H, nhid;
     if (dtype != QN_F64) return false;
     if (!uniform_hidden(d, &H, &nhid)) return false;
-    if (H != 16 && H != 32 && H != 64) return false;
+#ifdef QN_NO_STREAM
+    if (H == HS) return false;                       // A/B builds: layer-wise path at H = 128
+#endif
+    if (H == HS && want_grad) return false;          // the streaming kernel is forward-only
+    if (H != 16 && H != 32 && H != 64 && H != HS) return false;
     if (d->dims[0] > DMAX || d->dims[d->nlayers] > OMAX) return false;
     if (want_grad && !pick_bwd(H, nhid)) return false;
     return lds_need(H, d->dims[0], d->dims[d->nlayers], nhid, want_grad) <= 160 * 1024;
@@ -970,7 +1184,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
             return QN_EUNSUPPORTED;
         }
         if (int rc = arm_lds(reinterpret_cast<const void*>(kern))) return rc;
-        hipLaunchKernelGGL(kern, grid, dim3(WG), lds_bytes, st, a, (const double*)W,
+        hipLaunchKernelGGL(kern, grid, dim3(H == HS ? NTS : WG), lds_bytes, st, a, (const double*)W,
                            (const double*)X, (const double*)Y, row_idx, (double*)pred, partial);
     } else {
         bwd_fn kern = pick_bwd(H, nhid);

@@ -67,6 +67,57 @@ def test_fused_equals_generic(case):
     np.testing.assert_allclose(b[3], a[3], rtol=1e-11, atol=1e-12)
 
 
+def _stream_cases():
+    """Hidden width 128: forward-only streaming kernel (one 128 KB matrix buffer in LDS, restaged per layer)."""
+    out = []
+    rs = np.random.RandomState(5)
+    for k, (NH, d, o) in enumerate([(1, 1, 1), (2, 2, 1), (3, 2, 1), (4, 4, 4), (3, 3, 2), (6, 1, 3)]):
+        act = ["tanh", "relu", "identity"][k % 3]
+        out.append(((d,) + (128,) * NH + (o,), act, k != 3, int(rs.choice([1, 127, 129, 700])), int(rs.randint(1, 5)),
+                    k % 2 == 1))
+    return out
+
+
+@pytest.mark.parametrize("case", _stream_cases(),
+                         ids=lambda c: f"{c[0]}-{c[1]}-b{int(c[2])}-N{c[3]}-B{c[4]}-idx{int(c[5])}")
+def test_streaming_forward_equals_generic(case):
+    dims, act, bias, N, B, use_idx = case
+    rs = np.random.RandomState(sum(dims) + N * 7 + B)
+    arch = MLPArch(dims, act, bias)
+    x, y = rs.randn(N, dims[0]), rs.randn(N, dims[-1])
+    W = rs.randn(B, arch.nparams) / np.sqrt(128)
+    idx = rs.randint(0, N, size=(B, max(1, N // 2 + 3))) if use_idx else None
+    op = BatchedMLP(arch, x, y)
+    L = _lib.lib()
+    Nb = N if idx is None else idx.shape[1]
+    assert op.path(B, Nb, False) == _lib.PATH_FUSED
+    assert op.path(B, Nb, True) == _lib.PATH_GENERIC
+    res = {}
+    for path in (_lib.PATH_GENERIC, _lib.PATH_FUSED):
+        old = L.qn_set_path(path)
+        try:
+            s = op.sse(W, row_idx=idx)
+            s2, pr = op.sse_pred(W, row_idx=idx)
+        finally:
+            L.qn_set_path(old)
+        res[path] = (s.cpu().numpy(), s2.cpu().numpy(), pr.cpu().numpy())
+    a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_FUSED]
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-12)
+    np.testing.assert_allclose(b[1], a[1], rtol=1e-12)
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-11, atol=1e-12)
+    # non-finite weights in a streamed matrix switch the block to the NaN-propagating tanh
+    if act == "tanh" and len(dims) > 3:
+        W2 = W.copy()
+        W2[0, arch.nparams // 2] = np.inf
+        old = L.qn_set_path(_lib.PATH_GENERIC)
+        try:
+            ref = op.sse(W2, row_idx=idx).cpu().numpy()
+        finally:
+            L.qn_set_path(old)
+        got = op.sse(W2, row_idx=idx).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-12, equal_nan=True)
+
+
 @pytest.mark.parametrize("where", ["weight_nan", "weight_inf", "weight_huge", "bias_nan", "x_nan", "x_inf", "y_nan"])
 @pytest.mark.parametrize("grad", [False, True])
 def test_non_finite_inputs_follow_the_reference(where, grad):
