@@ -296,11 +296,9 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
 // =============================================================================================
 // Streaming forward for H = 128 (float64).  One 128 x 128 float64 matrix is 128 KB, so the image of
 // ALL layers no longer fits the 160 KB of LDS; this kernel keeps the thin pieces (first / last layer,
-// every bias) resident and streams the hidden matrices through ONE 128 KB swizzled buffer: each
-// layer's matrix is copied from L2 into the buffer between two barriers before its MFMA loop.  A workgroup is
+// every bias) resident and streams the hidden matrices through ONE 128 KB buffer.  A workgroup is
 // 8 waves (2 per SIMD), 128 data rows per iteration, one workgroup per CU; activations stay in
-// registers between layers exactly as in k_fused_fwd_f64.  Per iteration and layer the MFMAs take
-// ~33 k cycles per SIMD, the restaging ~1 k cycles of LDS writes plus two barriers.
+// registers between layers exactly as in k_fused_fwd_f64.
 constexpr int HS = 128;
 constexpr int NTS = 512;
 __host__ __device__ inline int stream_thin_doubles(int dp, int o, int nhid) {
@@ -310,34 +308,66 @@ __host__ __device__ inline int stream_lds_doubles(int dp, int o, int nhid) {
     return ((stream_thin_doubles(dp, o, nhid) + 1) & ~1) + ((TANH_TAB + 1) & ~1) + HS * HS;
 }
 
+// The matrix buffer is two K-halves ([128 rows][64 columns] each) filled by
+// LDS-DMA (global_load_lds_dwordx4: no registers, asynchronous): while the matrix cores work on one half,
+// the other half receives the columns needed next.  One wave-instruction writes 1 KiB = 2 rows of a
+// half, lane-linear, so the XOR swizzle is applied to the SOURCE column of each lane.  Two barriers
+// per layer (one per half); every DMA has a whole half-phase (~16 k cycles) to land.
+constexpr int HK = HS / 2;
+
+__device__ __forceinline__ void glds16(const double* src, double* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
 template <int ACT, int DP>
 __global__ __launch_bounds__(NTS, 1) void k_fused_fwd_stream_f64(FusedArgs a, const double* __restrict__ W,
-                                                                  const double* __restrict__ X,
-                                                                  const double* __restrict__ Y,
-                                                                  const int32_t* __restrict__ row_idx,
-                                                                  double* __restrict__ pred_out,
-                                                                  double* __restrict__ partial) {
+                                                                   const double* __restrict__ X,
+                                                                   const double* __restrict__ Y,
+                                                                   const int32_t* __restrict__ row_idx,
+                                                                   double* __restrict__ pred_out,
+                                                                   double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
-    constexpr int H = HS, T = H / 16, NT = NTS, PER = H * H / NT;
+    constexpr int H = HS, T = H / 16, NT = NTS;
     const int b = blockIdx.y, split = blockIdx.x;
     const int d = a.d, o = a.o, NH = a.nhid;
     const int nb = a.has_bias ? 1 : 0;
     const int offW0 = 0, offb0 = H * DP, offbh = offb0 + H;
     const int offWl = offbh + (NH - 1) * H, offbl = offWl + o * H;
     double* red = lds + ((offbl + o + 1) & ~1);
-    int* flag = reinterpret_cast<int*>(red + 8);
     double* tab = lds + ((stream_thin_doubles(DP, o, NH) + 1) & ~1);
     double* Wbuf = tab + ((TANH_TAB + 1) & ~1);
     const double* tanh_tab = tab;
     const double* Wb = W + (int64_t)b * a.p;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int64_t gb0 = (int64_t)H * d, gHH = gb0 + nb * H, blk = (int64_t)H * H + nb * H;
     const int64_t gWl = gHH + (int64_t)(NH - 1) * blk, gbl = gWl + (int64_t)o * H;
 
+    // one K-half of a hidden matrix: 64 wave-instructions of 2 rows x 64 columns, 8 per wave
+    auto dma_half = [&](int layer, int half) {
+        const double* src = Wb + gHH + (int64_t)(layer - 1) * blk + half * HK;
+        double* dst = Wbuf + half * (H * HK);
+        int ll = lane;
+        asm volatile("" : "+v"(ll));              // source offsets are recomputed here, not kept live
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int chunk = wave * 8 + u;
+            const int j = 2 * chunk + (ll >> 5);
+            const int kk = (2 * (ll & 31)) ^ swz(j);
+            glds16(src + j * H + kk, dst + chunk * 128);
+        }
+    };
+    const bool restage = NH > 2;                  // with one hidden matrix it is staged once
+    if (NH > 1) {
+        dma_half(1, 0);
+        if (!restage) dma_half(1, 1);
+    }
+
     qn_tanh_table_stage(tab, tid, NT);
+    int bad = 0;
     {
-        int bad = 0;
         auto chk = [&](double v) { bad |= !qn_bounded(v); return v; };
         for (int e = tid; e < H * DP; e += NT) {
             const int j = e / DP, k = e % DP;
@@ -349,39 +379,15 @@ __global__ __launch_bounds__(NTS, 1) void k_fused_fwd_stream_f64(FusedArgs a, co
                 lds[offbh + (layer - 1) * H + e] = nb ? chk(Wb[gHH + (layer - 1) * blk + H * H + e]) : 0.0;
         for (int e = tid; e < o * H; e += NT) lds[offWl + e] = chk(Wb[gWl + e]);
         for (int e = tid; e < o; e += NT) lds[offbl + e] = nb ? chk(Wb[gbl + e]) : 0.0;
-        if (tid == 0) *flag = 0;
-        __syncthreads();
-        if (bad) *flag = 1;                       // sticky: set again by any hidden matrix staged later
-    }
-
-    // copy one hidden matrix (L2-resident after the first workgroup touched it) into the swizzled
-    // buffer, PB loads in flight per thread; element e = tid + u NT of the row-major [H][H] block
-    constexpr int PB = 16;
-    auto stage_w = [&](int layer) {
-        const double* src = Wb + gHH + (int64_t)(layer - 1) * blk;
-        int bad = 0;
-        int tl = tid;
-        asm volatile("" : "+v"(tl));              // addresses are recomputed here, not kept live across the row loop
-#pragma unroll
-        for (int u0 = 0; u0 < PER; u0 += PB) {
-            double v[PB];
-#pragma unroll
-            for (int u = 0; u < PB; ++u) v[u] = src[tl + (u0 + u) * NT];
-#pragma unroll
-            for (int u = 0; u < PB; ++u) {
-                const int e = tl + (u0 + u) * NT;
-                const int j = e / H, i = e % H;
-                Wbuf[j * H + (i ^ swz(j))] = v[u];
-                bad |= !qn_bounded(v[u]);
-            }
+        // the hidden matrices reach LDS by DMA, not through registers: scan them once for unbounded values
+        for (int layer = 1; layer < NH; ++layer) {
+            const double* src = Wb + gHH + (int64_t)(layer - 1) * blk;
+#pragma unroll 8
+            for (int e = tid; e < H * H; e += NT) bad |= !qn_bounded(src[e]);
         }
-        if (bad) *flag = 1;
-    };
-    const bool restage = NH > 2;                  // with one hidden matrix it is staged once
-    if (NH == 2) stage_w(1);
-    __syncthreads();
+    }
+    const bool w_unbounded = block_or(bad, red + 8);       // ends with a barrier (and vmcnt(0): first DMA landed)
 
-    const int lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, c = lane & 15;
     const int fl = swz(c);
     double sse = 0.0;
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(NTS, 1) void k_fused_fwd_stream_f64(FusedArgs a, co
         for (int k = 0; k < DP; ++k) xk[k] = xn[k];
 #pragma unroll
         for (int qo = 0; qo < OMAX; ++qo) yk[qo] = yn[qo];
-        const bool xbad = __any(xbad_n);
+        const bool nan_possible = w_unbounded || __any(xbad_n);
         if (it + 1 < a.iters) fetch(it + 1);
         auto first_layer = [&](auto tag) {
             constexpr bool NS = decltype(tag)::value;
@@ -429,30 +435,34 @@ __global__ __launch_bounds__(NTS, 1) void k_fused_fwd_stream_f64(FusedArgs a, co
                     act[t][i] = act_apply<ACT, NS>(z, tanh_tab);
                 }
         };
-        if (ACT == QN_ACT_TANH && !(xbad || *flag != 0)) first_layer(std::false_type{});
+        if (ACT == QN_ACT_TANH && !nan_possible) first_layer(std::false_type{});
         else first_layer(std::true_type{});
         for (int layer = 1; layer < NH; ++layer) {
-            if (restage) {
-                __syncthreads();                  // every wave is done with the previous matrix
-                stage_w(layer);
-                __syncthreads();
-            }
-            const bool nan_possible = xbad || *flag != 0;
             const double* bl = lds + offbh + (layer - 1) * H;
             int fls = fl;
-            asm volatile("" : "+v"(fls));         // same for the 32 swizzled fragment columns
+            asm volatile("" : "+v"(fls));         // the 16 swizzled fragment columns are recomputed per layer
             v4d acc[T];
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[t][i] = bl[16 * t + q + 4 * i];
 #pragma unroll
-            for (int s = 0; s < H / 4; ++s) {
-                const int col = (4 * s + q) ^ fls;
+            for (int half = 0; half < 2; ++half) {
+                if (restage) {
+                    // this half has landed for every wave; every wave is done reading the other half
+                    __syncthreads();
+                    if (half == 0) dma_half(layer, 1);
+                    else if (layer + 1 < NH || it + 1 < a.iters) dma_half(layer + 1 < NH ? layer + 1 : 1, 0);
+                }
+                const double* Wh = Wbuf + half * (H * HK);
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const double aw = Wbuf[(16 * t + c) * H + col];
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, act[s >> 2][s & 3], acc[t], 0, 0, 0);
+                for (int s = 0; s < HK / 4; ++s) {
+                    const int col = (4 * s + q) ^ fls;
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        const double aw = Wh[(16 * t + c) * HK + col];
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, act[(16 * half + s) >> 2][s & 3], acc[t], 0, 0, 0);
+                    }
                 }
             }
             auto epilogue = [&](auto tag) {
