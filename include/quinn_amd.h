@@ -171,18 +171,19 @@ int qn_mcmc_accept_propose(const double* prop, const double* sse_prop, double si
  *   u_k, v_j iid N(0,1), wsnap = sqrt(w), s_lr = sqrt(c/(n-1)), s_iso = sqrt(c 1e-8), has exactly that
  *   covariance: a K x p GEMV over the stored states instead of a p x p factor (cfg2: K ~ 10^2..10^3
  *   rows of 34 KB per chain and step instead of 290-580 MB).  ksnap [C] = K per chain, msnap [C, p] =
- *   mean of (x - x0) at the adaptation, both frozen until the next adaptation.  pstride even, >= p. */
+ *   mean of (x - x0) at the adaptation, both frozen until the next adaptation.  pstride even, >= p
+ *   (a multiple of 4 for qn_mcmc_propose_hist_block). */
 int qn_mcmc_propose_hist(const double* cur, const float* hist, const float* wsnap, const int32_t* ksnap,
                          const double* msnap, double s_lr, double s_iso, int C, int chain0, int64_t p, int64_t pstride,
                          int kcap, uint64_t seed, const int64_t* step_ptr, double* out, void* stream);
 
-/* The same draw for qn_mcmc_hist_block_steps() (= 32) consecutive steps in one pass over the stored states:
+/* The same draw for TB = qn_mcmc_hist_block_steps() (= 64) consecutive steps in one pass over the stored states:
  * the increment of step t depends only on the frozen snapshot and on that step's random numbers (keyed
  * by the absolute step, exactly as in qn_mcmc_propose_hist), not on the chain's state, so
  *   delta[c, t, :] = s_lr * sum_k wsnap[c,k] u_k^(step0+t) (hist[c,k,:] - msnap[c,:])
- * for t = 0..31 reads the history once: HBM traffic per step / 32, a (32 x K).(K x p) product per chain
- * (float32 accumulation).  step_ptr != NULL: step0 is read from the device step counter when the kernels
- * run (a static launch, capturable in a HIP graph).  coef: scratch of C * (ceil4(kcap) + 1) * 32 float32; delta: [C, 32, p] float64.
+ * for t = 0..TB-1 reads the history once: HBM traffic per step / TB, a (TB x K).(K x p) product per chain
+ * (float32 matrix cores).  step_ptr != NULL: step0 is read from the device step counter when the kernels
+ * run (a static launch, capturable in a HIP graph).  coef: scratch of C * (ceil4(kcap) + 1) * TB float32; delta: [C, TB, p] float64.
  * qn_mcmc_apply_delta: out[c,:] = cur[c,:] + delta[c, t, :] + s_iso * v (the proposal of step step0 + t; v on the
  * stream of the CURRENT step *step_ptr, as in qn_mcmc_propose_hist; s_iso is unused by the block call). */
 int qn_mcmc_hist_block_steps(void);

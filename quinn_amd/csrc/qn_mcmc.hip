@@ -166,7 +166,11 @@ __global__ __launch_bounds__(BLK) void k_propose_hist(HistArgs a, const double* 
 // in ONE pass over the stored states: HBM traffic per step drops by TB and the kernel becomes a small
 // (TB x K) . (K x p) product per chain.  Random numbers are keyed by the absolute step exactly as in
 // k_propose_hist, so the increments do not depend on how steps are grouped.
-constexpr int TB = 32;           // steps per block
+#ifndef QN_TB
+#define QN_TB 64
+#endif
+constexpr int TB = QN_TB;        // steps per block
+static_assert(TB % 32 == 0, "k_hist_block_mfma works in tiles of 32 steps");
 constexpr int KB2 = 128;         // history rows per LDS chunk of coefficients
 struct HistBlockArgs {
     int chain0, kcap, kstride;   // coef [C][kstride][TB] (step fastest)
@@ -209,69 +213,94 @@ __global__ __launch_bounds__(BLK) void k_hist_coef_sum(HistBlockArgs a, const fl
     }
 }
 // delta[c][t][:] = s_lr * (sum_k coef[c][k][t] hist[c][k][:] - csum[c][t] mean[c][:])   (the isotropic part is
-// added per step by k_apply_delta).  2 columns per thread held as one packed float pair per step: the inner
-// loop is TB v_pk_fma_f32 per history row, coefficients broadcast from LDS.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(BLK, 2) void k_hist_block(HistBlockArgs a, const float* __restrict__ hist,
-                                                       const float* __restrict__ coef, const float* __restrict__ csum,
-                                                       const int32_t* __restrict__ ksnap,
-                                                       const double* __restrict__ msnap, double* __restrict__ delta) {
+// added per step by k_apply_delta): per chain a (TB x K) . (K x p) GEMM on the matrix cores
+// (v_mfma_f32_32x32x2_f32).  A wave owns 128 columns (4 tiles of 32; tile i holds columns 4 m + i, so a lane's
+// history operand for one row is ONE 16-byte load) and all TB steps; one MFMA k-step is a pair of history
+// rows (lanes 0-31 the even row, lanes 32-63 the odd one).  Coefficients come from the LDS chunk one float
+// per lane (A operand: lane -> step), not as a broadcast: the VALU version spends more LDS cycles on
+// broadcasting coefficients than the VALU spends on its FMAs (the earlier v_pk_fma_f32 version of this
+// kernel, TB = 32: 4.3 k steps/s at K ~ 3400 stored states per chain against 5.3 k with this one).
+typedef float v16f __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(BLK, 2) void k_hist_block_mfma(HistBlockArgs a, const float* __restrict__ hist,
+                                                            const float* __restrict__ coef,
+                                                            const float* __restrict__ csum,
+                                                            const int32_t* __restrict__ ksnap,
+                                                            const double* __restrict__ msnap,
+                                                            double* __restrict__ delta) {
+    constexpr int MT = TB / 32;          // tiles of 32 steps
+    constexpr int NTL = 4;               // tiles of 32 columns per wave
+#ifndef QN_HIST_RG
+#define QN_HIST_RG 8
+#endif
+    constexpr int RG = QN_HIST_RG;       // row pairs in flight
     __shared__ __attribute__((aligned(16))) float cs[KB2 * TB];
     const int b = blockIdx.y;
     const int K = ksnap[b] < a.kcap ? ksnap[b] : a.kcap;
-    const int64_t j = 2 * ((int64_t)blockIdx.x * BLK + threadIdx.x);
-    const bool live = j < a.p;
-    const float* hcol = hist + (int64_t)b * a.kcap * a.pstride + (live ? j : 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l32 = lane & 31, hi = lane >> 5;
+    const int64_t j = (((int64_t)blockIdx.x * (BLK / 64) + wave) * 32 + l32) * NTL;    // this lane's 4 columns
+    const bool live = j < a.pstride;                                                   // pstride % 4 == 0
+    const float* hcol = hist + (int64_t)b * a.kcap * a.pstride + (live ? j : 0) + (int64_t)hi * a.pstride;
     const float* cb = coef + (int64_t)b * a.kstride * TB;
-    v2f acc[TB];
+    v16f acc[MT][NTL];
 #pragma unroll
-    for (int t = 0; t < TB; ++t) acc[t] = (v2f){0.f, 0.f};
-    constexpr int RG = 8;
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
     for (int k0 = 0; k0 < K; k0 += KB2) {
         const int kn = K - k0 < KB2 ? K - k0 : KB2;
-        const int knp = (kn + RG - 1) / RG * RG;                           // rows padded to a group: zero coefficients
-        for (int e = threadIdx.x * 4; e < knp * TB; e += BLK * 4)          // contiguous [kn][TB] floats
+        const int knp = (kn + 2 * RG - 1) / (2 * RG) * (2 * RG);           // rows padded to a group: zero coefficients
+        for (int e = threadIdx.x * 4; e < knp * TB; e += BLK * 4)
             *reinterpret_cast<float4*>(cs + e) = e < kn * TB ? *reinterpret_cast<const float4*>(cb + (int64_t)k0 * TB + e)
-                                                             : (float4){0.f, 0.f, 0.f, 0.f};
+                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
         const float* h = hcol + (int64_t)k0 * a.pstride;
-        // rows in groups of RG: the next group's RG loads (8 B per lane each) are in flight while the current
-        // group is multiplied -- one row ahead keeps far too few bytes in flight to stream from HBM
-        v2f hn[RG];
+        float4 hn[RG];
 #pragma unroll
-        for (int u = 0; u < RG; ++u) hn[u] = u < kn ? *reinterpret_cast<const v2f*>(h + (int64_t)u * a.pstride) : (v2f){0.f, 0.f};
-        for (int kk = 0; kk < kn; kk += RG) {
-            v2f hv[RG];
+        for (int u = 0; u < RG; ++u)
+            hn[u] = (live && 2 * u + hi < kn) ? *reinterpret_cast<const float4*>(h + (int64_t)(2 * u) * a.pstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int kk = 0; kk < kn; kk += 2 * RG) {
+            float4 hv[RG];
 #pragma unroll
             for (int u = 0; u < RG; ++u) hv[u] = hn[u];
 #pragma unroll
             for (int u = 0; u < RG; ++u)
-                hn[u] = kk + RG + u < kn ? *reinterpret_cast<const v2f*>(h + (int64_t)(kk + RG + u) * a.pstride)
-                                         : (v2f){0.f, 0.f};
+                hn[u] = (live && kk + 2 * RG + 2 * u + hi < kn)
+                            ? *reinterpret_cast<const float4*>(h + (int64_t)(kk + 2 * RG + 2 * u) * a.pstride) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int u = 0; u < RG; ++u) {                                  // rows >= kn: zero row times zero coefficients
-                const float4* c4 = reinterpret_cast<const float4*>(cs + (kk + u) * TB);
+                const float* c = cs + (kk + 2 * u + hi) * TB + l32;
 #pragma unroll
-                for (int t4 = 0; t4 < TB / 4; ++t4) {
-                    const float4 cv = c4[t4];
-                    acc[4 * t4 + 0] = __builtin_elementwise_fma((v2f){cv.x, cv.x}, hv[u], acc[4 * t4 + 0]);
-                    acc[4 * t4 + 1] = __builtin_elementwise_fma((v2f){cv.y, cv.y}, hv[u], acc[4 * t4 + 1]);
-                    acc[4 * t4 + 2] = __builtin_elementwise_fma((v2f){cv.z, cv.z}, hv[u], acc[4 * t4 + 2]);
-                    acc[4 * t4 + 3] = __builtin_elementwise_fma((v2f){cv.w, cv.w}, hv[u], acc[4 * t4 + 3]);
+                for (int m = 0; m < MT; ++m) {
+                    const float av = c[32 * m];
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hv[u].x, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hv[u].y, acc[m][1], 0, 0, 0);
+                    acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hv[u].z, acc[m][2], 0, 0, 0);
+                    acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hv[u].w, acc[m][3], 0, 0, 0);
                 }
             }
         }
         __syncthreads();
     }
-    if (!live) return;
-    const double m0 = msnap[(int64_t)b * a.p + j], m1 = j + 1 < a.p ? msnap[(int64_t)b * a.p + j + 1] : 0.0;
+    if (j >= a.p) return;
+    // C/D layout: lane holds column (lane & 31), rows 8 (r >> 2) + 4 (lane >> 5) + (r & 3)
+    const double* mrow = msnap + (int64_t)b * a.p;
+    const double mj0 = mrow[j], mj1 = mrow[j + 1 < a.p ? j + 1 : j], mj2 = mrow[j + 2 < a.p ? j + 2 : j],
+                 mj3 = mrow[j + 3 < a.p ? j + 3 : j];
 #pragma unroll
-    for (int t = 0; t < TB; ++t) {
-        const double sA = (double)csum[(int64_t)b * TB + t];
-        double* d = delta + ((int64_t)b * TB + t) * a.p + j;
-        d[0] = a.s_lr * ((double)acc[t].x - sA * m0);
-        if (j + 1 < a.p) d[1] = a.s_lr * ((double)acc[t].y - sA * m1);
-    }
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = 32 * m + 8 * (r >> 2) + 4 * hi + (r & 3);
+            const double sA = (double)csum[(int64_t)b * TB + t];
+            double* d = delta + ((int64_t)b * TB + t) * a.p + j;
+            d[0] = a.s_lr * ((double)acc[m][0][r] - sA * mj0);
+            if (j + 1 < a.p) d[1] = a.s_lr * ((double)acc[m][1][r] - sA * mj1);
+            if (j + 2 < a.p) d[2] = a.s_lr * ((double)acc[m][2][r] - sA * mj2);
+            if (j + 3 < a.p) d[3] = a.s_lr * ((double)acc[m][3][r] - sA * mj3);
+        }
 }
 // out[c][:] = cur[c][:] + delta[c][t][:] + s_iso * v,  v ~ N(0, I) on the stream of the current step
 __global__ __launch_bounds__(BLK) void k_apply_delta(const double* __restrict__ cur, const double* __restrict__ delta,
@@ -457,8 +486,8 @@ extern "C" int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap,
                                           int64_t p, int64_t pstride, int kcap, uint64_t seed, int64_t step0,
                                           const int64_t* step_ptr, float* coef, double* delta, void* stream) {
     if (!hist || !wsnap || !ksnap || !msnap || !coef || !delta || C <= 0 || C > 65535 || chain0 < 0 || p <= 0 || kcap <= 0 ||
-        pstride < p || (pstride & 1) || step0 < 0) {
-        qn_set_error("qn_mcmc_propose_hist_block: bad argument (pstride must be even and >= p)");
+        pstride < p || (pstride & 3) || step0 < 0) {
+        qn_set_error("qn_mcmc_propose_hist_block: bad argument (pstride must be a multiple of 4 and >= p)");
         return QN_EINVAL;
     }
     HistBlockArgs a;
@@ -471,7 +500,7 @@ extern "C" int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap,
                        coef);
     float* csum = coef + (int64_t)C * a.kstride * TB;                  // [C][TB] behind the coefficients
     hipLaunchKernelGGL(k_hist_coef_sum, dim3(C), dim3(BLK), 0, st, a, (const float*)coef, ksnap, csum);
-    hipLaunchKernelGGL(k_hist_block, dim3((int)(((p + 1) / 2 + BLK - 1) / BLK), C), dim3(BLK), 0, st, a, hist,
+    hipLaunchKernelGGL(k_hist_block_mfma, dim3((int)((p + 4 * BLK / 2 - 1) / (4 * BLK / 2)), C), dim3(BLK), 0, st, a, hist,
                        (const float*)coef, (const float*)csum, ksnap, msnap, delta);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;

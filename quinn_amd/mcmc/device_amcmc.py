@@ -7,7 +7,7 @@ proposal's ingredients and the chain history in HBM and never synchronises with 
 
   * one MH step = proposal kernel (in-kernel Philox normals) -> batched log-posterior kernel ->
     `qn_mcmc_accept` (accept test, state / MAP / history update); the step counter lives in device
-    memory, so a run of steps is a static launch sequence; `use_graph=True` captures 32 steps at a time in
+    memory, so a run of steps is a static launch sequence; `use_graph=True` captures a block of steps at a time in
     ONE HIP graph and replays it (measured at cfg2: no faster than direct launches -- the host keeps the
     queue full either way -- so direct launching is the default);
   * initial proposal covariance 0.01 + diag(0.09|x0|) (admcmc.py:65) = diagonal + rank one:
@@ -25,8 +25,9 @@ proposal's ingredients and the chain history in HBM and never synchronises with 
     is 290-580 MB per chain and step plus an O(p^3) factorisation per adaptation.  An adaptation is a
     snapshot of (K, sqrt(w), mean): a few elementwise torch ops, no SYRK, no Cholesky;
   * delta does not depend on the chain's state, only on the frozen snapshot and the step's random
-    numbers, so the increments of the next 32 steps are formed in ONE pass over the history
-    (`qn_mcmc_propose_hist_block`: a (32 x K).(K x p) product per chain, HBM traffic per step / 32) and
+    numbers, so the increments of the next TB = 64 steps are formed in ONE pass over the history
+    (`qn_mcmc_propose_hist_block`: a (TB x K).(K x p) product per chain on the float32 matrix cores, HBM
+    traffic per step / TB) and
     a step's proposal is `cur + delta[t]`.
 
 Same target distribution and the same adaptation schedule as the reference; the random streams

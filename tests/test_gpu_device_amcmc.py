@@ -108,7 +108,7 @@ def test_sample_space_proposal_kernel_covariance_and_history_tracking():
                                       mean.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p,
                                       pstride, kcap, 1234, step.data_ptr(), out2.data_ptr(), None), "propose_hist")
     assert torch.equal(out, out2)
-    # the 32-step block kernel: same random numbers per absolute step (float32 accumulation), so its
+    # the block kernel (TB steps per pass over the history): same random numbers per absolute step (float32 accumulation), so its
     # increment for step 17 equals the single-step kernel's up to rounding; and each step's covariance is right
     TB = L.qn_mcmc_hist_block_steps()
     coef = torch.empty(C * ((kcap + 3) // 4 * 4 + 1) * TB, dtype=torch.float32, device=dev)
@@ -122,6 +122,15 @@ def test_sample_space_proposal_kernel_covariance_and_history_tracking():
     torch.cuda.synchronize()
     scale = float(np.sqrt(np.diag(target).max()))
     assert (out3 - out).abs().max().item() < 1e-4 * scale              # step 10 + 7 = 17, the step drawn above
+    for t in range(TB):                                                  # every step of the block against the single-step kernel
+        step[0] = 10 + t
+        _lib.check(L.qn_mcmc_propose_hist(cur.data_ptr(), hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(),
+                                          mean.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p,
+                                          pstride, kcap, 1234, step.data_ptr(), out2.data_ptr(), None), "propose_hist")
+        _lib.check(L.qn_mcmc_apply_delta(cur.data_ptr(), delta.data_ptr(), t, float(np.sqrt(c * 1e-8)), C, 0, p, 1234,
+                                         step.data_ptr(), out3.data_ptr(), None), "apply_delta")
+        assert (out3 - out2).abs().max().item() < 1e-4 * scale, t
+    step[0] = 17
     dl = delta.cpu().numpy()
     for t in (0, 13, TB - 1):                                            # (the 1e-8 isotropic floor is added per step)
         assert np.abs(np.cov(dl[:, t].T) - target).max() < 0.05 * np.abs(target).max()
