@@ -45,7 +45,7 @@ from ..ops import BatchedMLP
 
 class DeviceAMCMC:
     def __init__(self, op: BatchedMLP, sigma, gamma=0.1, t0=100, tadapt=1000, cov_ini=None, seed=0,
-                 use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=False):
+                 use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=False, groups=1):
         if op.dtype != "float64":
             raise NotImplementedError("the device AMCMC engine runs the float64 operator")
         self.op, self.sigma = op, float(sigma)
@@ -59,6 +59,11 @@ class DeviceAMCMC:
         # separate proposal kernel, which spreads over the whole chip while the accept kernel runs one block per chain)
         self.fuse_propose = bool(fuse_propose)
         self.chain0 = int(chain0)      # global id of this engine's first chain (random streams are keyed by it)
+        # groups > 1: the chains are split into that many independent groups, each on its own HIP stream, enqueued
+        # block by block from this one host thread: a group's small kernels (accept, apply-delta, partial sums --
+        # a fifth of a step at cfg2, one workgroup per chain) overlap the other groups' forward kernels
+        self.groups = max(1, int(groups))
+        self._subs = None
         self._L = _lib.lib()
 
     # -- kernel wrappers (enqueue on the current stream) ---------------------------------------------
@@ -107,8 +112,54 @@ class DeviceAMCMC:
             s['step'].data_ptr(), self._stream()), "qn_mcmc_accept")
 
     def run(self, nmcmc, param_ini, store_chain=True, verbose=False):
+        ini = torch.as_tensor(np.asarray(param_ini), dtype=torch.float64, device=self.dev).reshape(-1, self.op.p)
+        C, p = ini.shape
+        G = min(self.groups, C)
+        if G <= 1:
+            gen = self._run_gen(nmcmc, ini, store_chain, verbose)
+            while True:
+                try:
+                    next(gen)
+                except StopIteration as e:
+                    return e.value
+        # ---- several groups of chains side by side
+        bounds = [C * g // G for g in range(G + 1)]
+        pstride = (p + 3) // 4 * 4
+        if C * (nmcmc + 1) * pstride * 4 > self.max_history_bytes:
+            raise MemoryError(f"state history {C} x {nmcmc + 1} x {pstride} float32 exceeds max_history_bytes="
+                              f"{self.max_history_bytes}: run fewer steps per call or raise the limit")
+        if self._subs is None or [e.chain0 - self.chain0 for e in self._subs[0]] != bounds[:-1]:
+            op = self.op
+            engs = [DeviceAMCMC(BatchedMLP(op.arch, op.X, op.Y, device=op.device, dtype=op.dtype), self.sigma, self.gamma,
+                                self.t0, self.tadapt, self.cov_ini, self.seed, self.use_graph, self.max_history_bytes,
+                                self.chain0 + bounds[g], self.fuse_propose) for g in range(G)]
+            self._subs = (engs, [torch.cuda.Stream(device=self.dev) for _ in range(G)])
+        engs, streams = self._subs
+        chain = torch.empty(C, nmcmc + 1, p, dtype=torch.float64, device=self.dev) if store_chain else None
+        gens = [engs[g]._run_gen(nmcmc, ini[bounds[g]:bounds[g + 1]], store_chain, verbose and g == 0,
+                                 chain_out=None if chain is None else chain[bounds[g]:bounds[g + 1]]) for g in range(G)]
+        main = torch.cuda.current_stream(self.dev)
+        for st in streams:
+            st.wait_stream(main)
+        res, live = [None] * G, list(range(G))
+        while live:
+            for g in list(live):
+                with torch.cuda.stream(streams[g]):
+                    try:
+                        next(gens[g])
+                    except StopIteration as e:
+                        res[g] = e.value
+                        live.remove(g)
+        for st in streams:
+            main.wait_stream(st)
+        out = {k: torch.cat([r[k] for r in res]) for k in ('mapparams', 'maxpost', 'accrate', 'logpost', 'alphas')}
+        out['chain'] = chain
+        return out
+
+    def _run_gen(self, nmcmc, param_ini, store_chain=True, verbose=False, chain_out=None):
+        """The run as a generator: yields after every block of at most TB enqueued steps (nothing is awaited)."""
         dev, f64 = self.dev, torch.float64
-        cur = torch.as_tensor(np.asarray(param_ini), dtype=f64, device=dev).clone().reshape(-1, self.op.p)
+        cur = torch.as_tensor(param_ini, dtype=f64, device=dev).clone().reshape(-1, self.op.p)
         C, p = cur.shape
         n = self.op.N
         const = (n / 2) * np.log(2 * np.pi) + n * np.log(self.sigma)
@@ -119,7 +170,8 @@ class DeviceAMCMC:
             raise MemoryError(f"state history {C} x {kcap} x {pstride} float32 exceeds max_history_bytes="
                               f"{self.max_history_bytes}: run fewer steps per call or raise the limit")
         s = {'cur': cur, 'cur_lp': cur_lp, 'best': cur.clone(), 'best_lp': cur_lp.clone(), 'x0': cur.clone(),
-             'chain': torch.empty(C, nmcmc + 1, p, dtype=f64, device=dev) if store_chain else None,
+             'chain': (chain_out if chain_out is not None else torch.empty(C, nmcmc + 1, p, dtype=f64, device=dev))
+                      if store_chain else None,
              'lps': torch.empty(C, nmcmc + 1, dtype=f64, device=dev),
              'alphas': torch.zeros(C, nmcmc + 1, dtype=f64, device=dev),
              'nacc': torch.zeros(C, dtype=torch.int64, device=dev),
@@ -209,15 +261,21 @@ class DeviceAMCMC:
                 state['have_prop'] = False
                 for _ in range(nfull):
                     graphs[key].replay()
+                    yield
             else:
                 rest = nrun
             if adapted:
                 while rest > 0:
                     block_adapted(min(rest, TB))
                     rest -= min(rest, TB)
-            elif rest > 0:
+                    yield
+            else:
                 # the run of initial-proposal steps ends at an adaptation (new regime) or at the end of the chain
-                state['have_prop'] = run_initial(rest, False)
+                while rest > 0:
+                    nb = min(rest, TB)
+                    state['have_prop'] = run_initial(nb, rest > nb)
+                    rest -= nb
+                    yield
             i += nrun
             if verbose:
                 print('%d / %d completed, acceptance rate %lg' % (i, nmcmc, float(s['nacc'].double().mean()) / i))

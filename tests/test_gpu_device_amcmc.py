@@ -189,6 +189,13 @@ def test_chains_do_not_depend_on_how_they_are_split():
     for k in ('chain', 'logpost', 'alphas', 'accrate', 'mapparams'):
         assert torch.equal(whole[k], torch.cat([a[k], b[k]])), k
     assert (whole['accrate'] > 0).all()
+    # groups=3: the same chains as three groups on three HIP streams inside ONE engine (blocks of steps
+    # enqueued round robin), with and without a stored chain
+    grouped = DeviceAMCMC(op, 0.2, groups=3, **kw).run(nmcmc, ini)
+    for k in ('chain', 'logpost', 'alphas', 'accrate', 'mapparams', 'maxpost'):
+        assert torch.equal(whole[k], grouped[k]), k
+    nochain = DeviceAMCMC(op, 0.2, groups=2, **kw).run(nmcmc, ini, store_chain=False)
+    assert nochain['chain'] is None and torch.equal(nochain['logpost'], whole['logpost'])
 
 
 @pytest.mark.parametrize("graph", [False, True])
