@@ -58,19 +58,24 @@ extern "C" int qn_mlp_desc_create(const int* dims, int ndims, int act, int has_b
     d->p = off;
     d->kind = QN_KIND_MLP;
     d->padded = nullptr;
-    // hidden widths <= 64 that are not one common 16 / 32 / 64: zero-padded twin for the fused kernels
+    // zero-padded twin of the network (hidden units only; padded units stay exactly 0):
+    //   widths <= 64 that are not one common 16 / 32 / 64   -> that common width, for the fused kernels
+    //   widths <= 128 with one that is no multiple of 64     -> 128 everywhere (streaming fused forward, MFMA GEMMs)
+    //   wider, with a width that is no multiple of 64        -> every width rounded up to a multiple of 64, so that
+    //                                                           the layer-wise path runs its MFMA GEMMs, not the VALU kernels
     if (d->nlayers >= 2) {
         int hmax = 0;
-        bool uniform = true;
+        bool uniform = true, mult64 = true;
         for (int l = 1; l < d->nlayers; ++l) {
             hmax = d->dims[l] > hmax ? d->dims[l] : hmax;
             uniform = uniform && d->dims[l] == d->dims[1];
+            mult64 = mult64 && d->dims[l] % 64 == 0;
         }
-        const int H = hmax <= 16 ? 16 : hmax <= 32 ? 32 : 64;
-        if (hmax <= 64 && !(uniform && hmax == H)) {
+        const int H = hmax <= 16 ? 16 : hmax <= 32 ? 32 : hmax <= 64 ? 64 : 128;
+        if (hmax <= 64 ? !(uniform && hmax == H) : !mult64) {
             qn_desc* q = new qn_desc(*d);
             int64_t o2 = 0;
-            for (int l = 1; l < q->nlayers; ++l) q->dims[l] = H;
+            for (int l = 1; l < q->nlayers; ++l) q->dims[l] = hmax <= 128 ? H : (d->dims[l] + 63) / 64 * 64;
             for (int l = 0; l < q->nlayers; ++l) {
                 q->offW[l] = o2;
                 o2 += (int64_t)q->dims[l] * q->dims[l + 1];
@@ -78,7 +83,8 @@ extern "C" int qn_mlp_desc_create(const int* dims, int ndims, int act, int has_b
                 if (q->has_bias) o2 += q->dims[l + 1];
             }
             q->p = o2;
-            q->hmax = H > q->dims[q->nlayers] ? H : q->dims[q->nlayers];
+            q->hmax = 0;
+            for (int l = 1; l <= q->nlayers; ++l) q->hmax = q->dims[l] > q->hmax ? q->dims[l] : q->hmax;
             q->padded = nullptr;
             d->padded = q;
         }
@@ -149,6 +155,16 @@ static size_t fused_ws(const qn_desc* d, int B, int Nb, int want_grad, int dtype
     if (d->padded) tot += (want_grad ? 2 : 1) * qn_align((size_t)B * d->padded->p * sizeof(double));
     return tot;
 }
+// layer-wise kernels on the padded twin (hidden widths > 64 that are no multiples of 64): MFMA GEMMs instead of VALU
+// kernels.  Not under a forced path: QN_PATH_GENERIC stays the exact-width reference the tests compare against.
+static bool use_padded_generic(const qn_desc* d) {
+    return d->kind == QN_KIND_MLP && d->padded && d->padded->dims[1] > 64 && g_forced_path.load() == QN_PATH_AUTO;
+}
+static size_t padded_generic_ws(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
+    const size_t el = dtype == QN_F32 ? sizeof(float) : sizeof(double);
+    return qn_generic_workspace(d->padded, B, Nb, want_grad, dtype) +
+           (want_grad ? 2 : 1) * qn_align((size_t)B * d->padded->p * el);
+}
 
 // ---- zero-padding of hidden layers (weights in, gradients out); one thread per element, layer found by offset
 namespace {
@@ -157,13 +173,13 @@ struct PadMap {
     int hin[QN_MAX_LAYERS], hout[QN_MAX_LAYERS], Hin[QN_MAX_LAYERS], Hout[QN_MAX_LAYERS];
     int64_t off[QN_MAX_LAYERS + 1], offp[QN_MAX_LAYERS + 1], p, pp;
 };
-__global__ void k_pad_weights(PadMap m, const double* __restrict__ W, double* __restrict__ Wp) {
+template <typename T> __global__ void k_pad_weights(PadMap m, const T* __restrict__ W, T* __restrict__ Wp) {
     const int b = blockIdx.y;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m.pp; e += (int64_t)gridDim.x * blockDim.x) {
         int l = 0;
         while (l + 1 < m.L && e >= m.offp[l + 1]) ++l;
         const int64_t loc = e - m.offp[l], nW = (int64_t)m.Hout[l] * m.Hin[l];
-        double v = 0.0;
+        T v = 0;
         if (loc < nW) {
             const int j = (int)(loc / m.Hin[l]), i = (int)(loc % m.Hin[l]);
             if (j < m.hout[l] && i < m.hin[l]) v = W[(int64_t)b * m.p + m.off[l] + (int64_t)j * m.hin[l] + i];
@@ -174,7 +190,7 @@ __global__ void k_pad_weights(PadMap m, const double* __restrict__ W, double* __
         Wp[(int64_t)b * m.pp + e] = v;
     }
 }
-__global__ void k_unpad_grad(PadMap m, const double* __restrict__ Gp, double* __restrict__ G) {
+template <typename T> __global__ void k_unpad_grad(PadMap m, const T* __restrict__ Gp, T* __restrict__ G) {
     const int b = blockIdx.y;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m.p; e += (int64_t)gridDim.x * blockDim.x) {
         int l = 0;
@@ -197,31 +213,44 @@ PadMap pad_map(const qn_desc* d) {
     m.off[d->nlayers] = d->p; m.offp[d->nlayers] = q->p;
     return m;
 }
-// pad -> fused kernels on the padded twin -> unpad the gradient
-int run_padded(const qn_desc* d, const double* W, const void* X, const void* Y, const int32_t* row_idx, int B, int N,
-               int Nb, double* sse, void* pred, double* gradW, void* ws, size_t ws_bytes, hipStream_t st) {
+// pad -> kernels on the padded twin (fused, or layer-wise when `generic`) -> unpad the gradient
+template <typename T>
+int run_padded_t(const qn_desc* d, bool generic, int dtype, const T* W, const void* X, const void* Y,
+                 const int32_t* row_idx, int B, int N, int Nb, double* sse, void* pred, T* gradW, void* ws,
+                 size_t ws_bytes, hipStream_t st) {
     const qn_desc* q = d->padded;
-    const size_t wbytes = qn_align((size_t)B * q->p * sizeof(double));
+    const size_t wbytes = qn_align((size_t)B * q->p * sizeof(T));
     const size_t head = (gradW ? 2 : 1) * wbytes;
     if (head > ws_bytes) {
         qn_set_error("workspace too small: need more than %zu bytes, got %zu", head, ws_bytes);
         return QN_EWORKSPACE;
     }
-    double* Wp = static_cast<double*>(ws);
-    double* Gp = gradW ? reinterpret_cast<double*>(static_cast<char*>(ws) + wbytes) : nullptr;
+    T* Wp = static_cast<T*>(ws);
+    T* Gp = gradW ? reinterpret_cast<T*>(static_cast<char*>(ws) + wbytes) : nullptr;
     const PadMap m = pad_map(d);
     (void)hipGetLastError();
     int gx = (int)((q->p + 255) / 256);
-    hipLaunchKernelGGL(k_pad_weights, dim3(gx > 64 ? 64 : gx, B), dim3(256), 0, st, m, W, Wp);
-    const int rc = qn_fused_run(q, QN_F64, Wp, X, Y, row_idx, B, N, Nb, sse, pred, Gp, static_cast<char*>(ws) + head,
-                                ws_bytes - head, st);
+    hipLaunchKernelGGL(k_pad_weights<T>, dim3(gx > 64 ? 64 : gx, B), dim3(256), 0, st, m, W, Wp);
+    const int rc = generic ? qn_generic_run(q, dtype, Wp, X, Y, row_idx, B, N, Nb, sse, pred, Gp,
+                                            static_cast<char*>(ws) + head, ws_bytes - head, st)
+                           : qn_fused_run(q, dtype, Wp, X, Y, row_idx, B, N, Nb, sse, pred, Gp,
+                                          static_cast<char*>(ws) + head, ws_bytes - head, st);
     if (rc) return rc;
     if (gradW) {
         gx = (int)((d->p + 255) / 256);
-        hipLaunchKernelGGL(k_unpad_grad, dim3(gx > 64 ? 64 : gx, B), dim3(256), 0, st, m, (const double*)Gp, gradW);
+        hipLaunchKernelGGL(k_unpad_grad<T>, dim3(gx > 64 ? 64 : gx, B), dim3(256), 0, st, m, (const T*)Gp, gradW);
     }
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
+}
+int run_padded(const qn_desc* d, bool generic, int dtype, const void* W, const void* X, const void* Y,
+               const int32_t* row_idx, int B, int N, int Nb, double* sse, void* pred, void* gradW, void* ws,
+               size_t ws_bytes, hipStream_t st) {
+    if (dtype == QN_F32)
+        return run_padded_t<float>(d, generic, dtype, (const float*)W, X, Y, row_idx, B, N, Nb, sse, pred, (float*)gradW,
+                                   ws, ws_bytes, st);
+    return run_padded_t<double>(d, generic, dtype, (const double*)W, X, Y, row_idx, B, N, Nb, sse, pred, (double*)gradW,
+                                ws, ws_bytes, st);
 }
 }  // namespace
 
@@ -246,6 +275,10 @@ extern "C" size_t qn_workspace_bytes(const qn_desc* d, int B, int Nb, int want_g
     size_t g = qn_generic_workspace(d, B, Nb, want_grad, dtype);
     size_t f = fused_ok(d, B, Nb, want_grad, dtype) ? fused_ws(d, B, Nb, want_grad, dtype) : 0;
     if (g_forced_path.load() == QN_PATH_AUTO && f) return f;
+    if (use_padded_generic(d)) {
+        const size_t pg = padded_generic_ws(d, B, Nb, want_grad, dtype);
+        g = pg > g ? pg : g;
+    }
     return g > f ? g : f;
 }
 
@@ -292,9 +325,11 @@ static int run(const char* fn, const qn_desc* d, int dtype, const void* W, const
     }
     if (use_fused(d, B, Nb, want_grad, dtype)) {
         if (d->padded)
-            return run_padded(d, (const double*)W, X, Y, row_idx, B, N, Nb, sse, pred, (double*)gradW, ws, ws_bytes, st);
+            return run_padded(d, false, dtype, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
         return qn_fused_run(d, dtype, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
     }
+    if (use_padded_generic(d))
+        return run_padded(d, true, dtype, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
     return qn_generic_run(d, dtype, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
 }
 

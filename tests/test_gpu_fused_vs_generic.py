@@ -118,6 +118,38 @@ def test_streaming_forward_equals_generic(case):
         np.testing.assert_allclose(got, ref, rtol=1e-12, equal_nan=True)
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("dims", [(2, 100, 100, 1), (1, 70, 128, 90, 1), (3, 200, 300, 2), (1, 65, 1), (4, 129, 64, 4),
+                                  (1, 100, 100, 100, 5)])
+def test_wide_ragged_widths_run_on_the_padded_twin(dims, dtype):
+    """Hidden widths above 64 that are no multiples of 64: the default path pads them (to 128, or to multiples of 64)
+    and runs the MFMA kernels on the twin; the forced layer-wise path keeps the exact widths (VALU kernels)."""
+    rs = np.random.RandomState(sum(dims))
+    arch = MLPArch(dims, "tanh")
+    N, B = 333, 3
+    x, y = rs.randn(N, dims[0]), rs.randn(N, dims[-1])
+    W = rs.randn(B, arch.nparams) / np.sqrt(max(dims))
+    idx = rs.randint(0, N, size=(B, 150))
+    op = BatchedMLP(arch, x, y, dtype=dtype)
+    L = _lib.lib()
+    res = {}
+    for path in (_lib.PATH_GENERIC, _lib.PATH_AUTO):
+        old = L.qn_set_path(path)
+        try:
+            s, g = op.sse_grad(W)
+            s2, pr = op.sse_pred(W, row_idx=idx)
+        finally:
+            L.qn_set_path(old)
+        res[path] = (s.cpu().numpy(), g.double().cpu().numpy(), s2.cpu().numpy(), pr.double().cpu().numpy())
+    a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_AUTO]
+    rt, gt = (1e-11, 1e-10) if dtype == "float64" else (2e-4, 2e-3)
+    np.testing.assert_allclose(b[0], a[0], rtol=rt)
+    np.testing.assert_allclose(b[2], a[2], rtol=rt)
+    assert np.abs(b[1] - a[1]).max() <= gt * np.abs(a[1]).max()
+    np.testing.assert_allclose(b[3], a[3], rtol=rt * 10, atol=rt * 10)
+    assert b[1].shape == (B, arch.nparams)
+
+
 @pytest.mark.parametrize("where", ["weight_nan", "weight_inf", "weight_huge", "bias_nan", "x_nan", "x_inf", "y_nan"])
 @pytest.mark.parametrize("grad", [False, True])
 def test_non_finite_inputs_follow_the_reference(where, grad):

@@ -10,7 +10,8 @@ rs = np.random.RandomState(0)
 N, B = 4096, 64
 x = rs.rand(N, 1) * 6 - 3; y = np.sin(x)
 out = {}
-for dims in [(1, 11, 11, 11, 1), (1, 50, 50, 50, 1), (1, 20, 40, 10, 1), (1, 64, 64, 64, 1)]:
+for dims in [(1, 11, 11, 11, 1), (1, 50, 50, 50, 1), (1, 20, 40, 10, 1), (1, 64, 64, 64, 1),
+             (1, 100, 100, 100, 1), (1, 200, 200, 200, 1), (1, 500, 500, 1)]:   # > 64: padded to 128 / multiples of 64
     arch = MLPArch(dims, "tanh")
     op = BatchedMLP(arch, x, y)
     W = op.weights(0.1 * rs.randn(B, arch.nparams))
