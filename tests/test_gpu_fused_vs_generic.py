@@ -120,7 +120,7 @@ def test_streaming_forward_equals_generic(case):
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("dims", [(2, 100, 100, 1), (1, 70, 128, 90, 1), (3, 200, 300, 2), (1, 65, 1), (4, 129, 64, 4),
-                                  (1, 100, 100, 100, 5)])
+                                  (1, 100, 100, 100, 5), (6, 50, 50, 7), (1, 40, 64, 33, 1), (2, 64, 64, 64, 64, 2)])
 def test_wide_ragged_widths_run_on_the_padded_twin(dims, dtype):
     """Hidden widths above 64 that are no multiples of 64: the default path pads them (to 128, or to multiples of 64)
     and runs the MFMA kernels on the twin; the forced layer-wise path keeps the exact widths (VALU kernels)."""
