@@ -8,12 +8,14 @@ def timeit(fn, n):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
 rs = np.random.RandomState(0)
 N, B = 4096, 64
-x = rs.rand(N, 1) * 6 - 3; y = np.sin(x)
+DT = os.environ.get("QN_DTYPE", "float64")
 out = {}
 for dims in [(1, 11, 11, 11, 1), (1, 50, 50, 50, 1), (1, 20, 40, 10, 1), (1, 64, 64, 64, 1),
-             (1, 100, 100, 100, 1), (1, 200, 200, 200, 1), (1, 500, 500, 1)]:   # > 64: padded to 128 / multiples of 64
+             (1, 100, 100, 100, 1), (1, 200, 200, 200, 1), (1, 500, 500, 1),    # > 64: padded to 128 / multiples of 64
+             (6, 50, 50, 50, 7), (6, 33, 33, 7)]:                                # fused kernels do not apply: layer-wise on the twin
     arch = MLPArch(dims, "tanh")
-    op = BatchedMLP(arch, x, y)
+    x = rs.rand(N, dims[0]) * 6 - 3; y = np.sin(x).sum(axis=1, keepdims=True) * np.ones((1, dims[-1]))
+    op = BatchedMLP(arch, x, y, dtype=DT)
     W = op.weights(0.1 * rs.randn(B, arch.nparams))
     r = {}
     for name, path in (("generic", _lib.PATH_GENERIC), ("auto", _lib.PATH_AUTO)):
