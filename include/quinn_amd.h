@@ -61,7 +61,9 @@ size_t qn_workspace_bytes(const qn_desc* desc, int B, int Nb, int want_grad, int
 
 /* Which kernel family the next call with these sizes would run (QN_PATH_GENERIC/FUSED). */
 int qn_mlp_path(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
-/* Force a kernel family (QN_PATH_AUTO restores dispatch). Returns the previous setting. */
+/* Force a kernel family (QN_PATH_AUTO restores dispatch). Returns the previous setting.  QN_PATH_GENERIC is the
+ * layer-wise family at the EXACT layer widths; under QN_PATH_AUTO hidden widths that are no multiples of 64 run on a
+ * zero-padded twin of the network (padded units stay exactly 0, results equal the unpadded network's). */
 int qn_set_path(int path);
 
 /* sse_out[b] = sum_{n,o} (Y[r(b,n),o] - f_{W[b]}(X[r(b,n),:])[o])^2 for b < B.
