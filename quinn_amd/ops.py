@@ -66,6 +66,8 @@ class MLPArch:
         if RNetArch.matches(nnmodel):
             return RNetArch.from_module(nnmodel)
         seq = nnmodel
+        if isinstance(seq, torch.nn.Linear):                   # a bare linear model (reference examples/ex_lreg_mcmc.py:54)
+            seq = torch.nn.Sequential(seq)
         if not isinstance(seq, torch.nn.Sequential):
             seq = getattr(nnmodel, "nnmodel", None)
         if not isinstance(seq, torch.nn.Sequential):

@@ -71,6 +71,33 @@ def test_nn_mcmc_predict_map():                              # :84-100
 
 
 # ------------------------------------------------------------------ test_solvers.py: NN_RMS
+def test_linear_model_of_ex_lreg_mcmc():
+    """examples/ex_lreg_mcmc.py:54-71: the 'network' is a bare torch.nn.Linear(1, 1); AMCMC with gamma=0.1 on 10 points.
+    The posterior of a linear-Gaussian model is known in closed form: check the log-posterior / gradient against it
+    and the chain's mean against the least-squares solution."""
+    rs = np.random.RandomState(0)
+    x = rs.rand(10, 1) * 4 - 2
+    y = np.sin(x) + 0.1 * rs.randn(10, 1)
+    nnet = torch.nn.Linear(1, 1, bias=True)
+    uq = NN_MCMC(nnet, verbose=False)
+    assert uq.pdim == 2
+    w = np.array([0.7, -0.2])                                         # [weight, bias] (parameters() order)
+    lpinfo = {'model': nnet, 'xd': x, 'yd': [yy for yy in y], 'ltype': 'classical', 'lparams': {'sigma': 0.1}}
+    r = y - (w[0] * x + w[1])
+    want = -(0.5 * float((r ** 2).sum()) / 0.01 + 5 * np.log(2 * np.pi) + 10 * np.log(0.1))
+    assert abs(uq.logpost(w, lpinfo) - want) < 1e-10 * abs(want)
+    g = uq.logpostgrad(w, lpinfo)
+    np.testing.assert_allclose(g, [float((r * x).sum()) / 0.01, float(r.sum()) / 0.01], rtol=1e-10)
+    uq.fit(x, y, zflag=False, datanoise=0.1, nmcmc=3000, sampler='amcmc', sampler_params={'gamma': 0.1})
+    assert uq.samples.shape == (3001, 2)
+    A = np.hstack([x, np.ones_like(x)])
+    ls = np.linalg.lstsq(A, y, rcond=None)[0].ravel()
+    post_sd = np.sqrt(np.diag(0.01 * np.linalg.inv(A.T @ A)))
+    assert (np.abs(uq.samples[1000:].mean(axis=0) - ls) < 0.5 * post_sd).all()
+    assert uq.predict_MAP(x).shape == (10, 1)
+    assert uq.predict_ens(x, nens=5, nburn=1000).shape == (5, 10, 1)
+
+
 def test_nn_rms_creation():                                  # :201-207
     rms = NN_RMS(MLP(1, 1, (5,), activ='tanh'), nens=2, datanoise=0.1, priorsigma=1.0)
     assert rms.datanoise == 0.1 and rms.priorsigma == 1.0
