@@ -42,6 +42,78 @@ class MLPBase(torch.nn.Module):
         return op.predict(flatten_module(model)[None, :], x)[0].double().cpu().numpy()
 
 
+    def printParams(self):
+        """Names and values of the trainable parameters (nnbase.py:118-122)."""
+        for name, param in self.named_parameters():
+            if param.requires_grad:
+                print(name, param.data)
+
+    def printParamNames(self):
+        """Names and shapes of the trainable parameters (nnbase.py:125-129)."""
+        for name, param in self.named_parameters():
+            if param.requires_grad:
+                print(name, param.data.shape)
+
+    def predict_plot(self, xx_list, yy_list, labels=None, colors=None, iouts=None):
+        """Predicted-vs-data ('diagonal') figure per output, saved as `fitdiag_o<iout>.png` (nnbase.py:132-173;
+        the probabilistic counterpart is `QUiNNBase.predict_plot`)."""
+        import matplotlib
+        matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+        assert len(xx_list) == len(yy_list)
+        preds = [self.predict(xx) for xx in xx_list]
+        nset, nout = len(xx_list), preds[0].shape[1]
+        labels = labels or [f'Set {i + 1}' for i in range(nset)]
+        colors = colors or (['b', 'g', 'r', 'c', 'm', 'y'] * nset)[:nset]
+        assert len(labels) == nset and len(colors) == nset
+        for iout in (range(nout) if iouts is None else iouts):
+            plt.figure(figsize=(10, 10))
+            lo = min(float(yy[:, iout].min()) for yy in yy_list)
+            hi = max(float(yy[:, iout].max()) for yy in yy_list)
+            plt.plot([lo, hi], [lo, hi], 'k--', linewidth=1)
+            for pr, yy, lab, col in zip(preds, yy_list, labels, colors):
+                plt.plot(yy[:, iout], pr[:, iout], col + 'o', markersize=13, markeredgecolor='w', label=lab)
+            plt.xlabel(f'Model output # {iout + 1}')
+            plt.ylabel(f'Fit output # {iout + 1}')
+            plt.legend()
+            plt.savefig(f'fitdiag_o{iout}.png')
+            plt.close()
+
+    def plot_1d_fits(self, xx_list, yy_list, domain=None, ngr=111, true_model=None, labels=None, colors=None):
+        """One-dimensional slices of the fit through the middle of the domain, one figure per (input, output), saved
+        as `fit_d<idim>_o<iout>.png` (nnbase.py:176-237)."""
+        import matplotlib
+        matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+        assert len(xx_list) == len(yy_list)
+        nset = len(xx_list)
+        labels = labels or [f'Set {i + 1}' for i in range(nset)]
+        colors = colors or (['b', 'g', 'r', 'c', 'm', 'y'] * nset)[:nset]
+        assert len(labels) == nset and len(colors) == nset
+        if domain is None:
+            xall = np.vstack(xx_list)
+            domain = np.stack([xall.min(axis=0), xall.max(axis=0)], axis=1)
+        domain = np.asarray(domain, dtype=np.float64)
+        ndim, nout = xx_list[0].shape[1], yy_list[0].shape[1]
+        for idim in range(ndim):
+            unit = np.full((ngr, ndim), 0.5)
+            unit[:, idim] = np.linspace(0.0, 1.0, ngr)
+            xgrid = domain[:, 0] + unit * (domain[:, 1] - domain[:, 0])
+            ygrid = self.predict(xgrid)
+            truth = true_model(xgrid, 0.0) if true_model is not None else None
+            for iout in range(nout):
+                for xx, yy, lab, col in zip(xx_list, yy_list, labels, colors):
+                    plt.plot(xx[:, idim], yy[:, iout], col + 'o', markersize=13, markeredgecolor='w', label=lab)
+                if truth is not None:
+                    plt.plot(xgrid[:, idim], truth[:, iout], 'k-', label='Truth', alpha=0.5)
+                plt.plot(xgrid[:, idim], ygrid[:, iout], 'm-', linewidth=5, label='Mean Pred.')
+                plt.legend()
+                plt.xlabel(f'Input # {idim + 1}')
+                plt.ylabel(f'Output # {iout + 1}')
+                plt.savefig(f'fit_d{idim}_o{iout}.png')
+                plt.clf()
+
+
 class MLP(MLPBase):
     def __init__(self, indim, outdim, hls, biasorno=True, activ='relu', bnorm=False, bnlearn=True,
                  dropout=0.0, final_transform=None, device='cpu'):

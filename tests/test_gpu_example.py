@@ -43,3 +43,30 @@ def test_plot_helpers_write_the_reference_file_names(tmp_path, monkeypatch):
     ens.predict_plot([x[:15], x[15:]], [y[:15], y[15:]], nmc=3, plot_qt=False, labels=['Training', 'Validation'])
     assert (tmp_path / "fit_d0_o0_ens.png").stat().st_size > 0
     assert (tmp_path / "fitdiag_o0.png").stat().st_size > 0
+
+
+def test_ex_fit_call_pattern(tmp_path, monkeypatch, capsys):
+    """examples/ex_fit.py:56-91 / ex_fit_2d.py: a deterministic `MLP(...).fit(...)` followed by `plot_1d_fits` and
+    `predict_plot` of the network itself (nnbase.py:95-237)."""
+    pytest.importorskip("matplotlib")
+    from quinn_amd.nns.mlp import MLP
+    monkeypatch.chdir(tmp_path)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.double)
+    try:
+        rs = np.random.RandomState(1)
+        x = rs.rand(24, 2) * 2 - 1
+        y = np.sin(3 * x[:, :1]) + x[:, 1:] ** 2
+        nnet = MLP(2, 1, (11, 11, 11), biasorno=True, activ='tanh', bnorm=False, bnlearn=True, dropout=0.0, device='cpu')
+        before = float(((nnet.predict(x) - y) ** 2).mean())
+        nnet.fit(x[:18], y[:18], val=[x[18:], y[18:]], lrate=0.01, batch_size=None, nepochs=150, freq_out=1000)
+        assert nnet.trained and float(((nnet.predict(x) - y) ** 2).mean()) < before
+        nnet.plot_1d_fits([x[:18], x[18:]], [y[:18], y[18:]], labels=['Training', 'Validation'],
+                          true_model=lambda xx, noise: np.sin(3 * xx[:, :1]) + xx[:, 1:] ** 2)
+        nnet.predict_plot([x[:18], x[18:]], [y[:18], y[18:]], labels=['Training', 'Validation'])
+        for f in ('fit_d0_o0.png', 'fit_d1_o0.png', 'fitdiag_o0.png'):
+            assert (tmp_path / f).stat().st_size > 0
+        nnet.printParamNames()
+        assert 'torch.Size' in capsys.readouterr().out
+    finally:
+        torch.set_default_dtype(old)
