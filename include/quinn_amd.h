@@ -125,9 +125,11 @@ int qn_adam_batched(double* W, const void* G, double* m, double* v, const double
 
 /* Device-resident Metropolis-Hastings step (throughput engine of the adaptive Metropolis sampler,
  * quinn/mcmc/admcmc.py:38-74 + quinn/mcmc/mcmc.py:65-85), two kernels around the batched
- * log-posterior.  `step_ptr` points to TWO int64 words in device memory: [0] the step counter
- * (read by both kernels, advanced by qn_mcmc_accept), [1] scratch (must start at 0); keeping the
- * counter on the device makes one step a static HIP graph.
+ * log-posterior.  The step counter lives in device memory (keeping it there makes a run of steps a static
+ * launch sequence / HIP graph).  It is DOUBLE-BUFFERED by the parity of the step, like the other per-chain
+ * scalars qn_mcmc_accept maintains: the accept call of a step reads slot `parity` and writes slot 1 - parity, so
+ * its workgroups (several per chain) never see a half-updated state and need no fence or atomic.  The proposal
+ * kernels take a pointer to the CURRENT slot (`step_ptr` of qn_mcmc_propose* / qn_mcmc_apply_delta = base + parity).
  *
  * qn_mcmc_propose: out[c,:] = cur[c,:] + sd[c,:] * z + c1 * z0_c with z ~ N(0,I), z0_c ~ N(0,1)
  *   (the initial proposal covariance c1^2 + diag(sd^2) = 0.01 + diag(0.09|x0|), admcmc.py:65);
@@ -142,16 +144,18 @@ int qn_mcmc_propose(const double* cur, const double* sd, double c1, int C, int c
  *   lp = -(0.5 sse/sigma^2 + (n_rows/2) log 2pi + n_rows log sigma); mh = exp(lp - cur_lp[c]);
  *   accept iff u_c < mh (mcmc.py:72-75); updates cur, cur_lp, best / best_lp (MAP, mcmc.py:79-81),
  *   nacc, writes chain[c, step+1, :] (optional), lps[c, step+1], alphas[c, step+1]; then advances the
- *   counter.  With hist != NULL it also maintains what the adapted proposal is drawn from
+ *   counter.  cur_lp, best_lp, kcur: [2, C] and step_ptr: [2] -- slot `parity` (0 / 1) is read, slot 1 - parity
+ *   written; the caller alternates parity from step to step (slot 0 holds the initial state for parity 0).
+ *   With hist != NULL it also maintains what the adapted proposal is drawn from
  *   (qn_mcmc_propose_hist): hist [C, kcap, pstride] float32 = the DISTINCT states visited, minus x0
  *   (row 0 = the start, a new row per accepted move), mult [C, kcap] their multiplicities in the
- *   chain so far, kcur [C] the index of the current state's row, sumx [C, p] the running sum of
+ *   chain so far, kcur [2, C] the index of the current state's row, sumx [C, p] the running sum of
  *   (x_i - x0) over all samples.  kcur[c] >= kcap means the history is full (rows are not stored). */
 int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int chain0, int64_t p,
                    int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
                    double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0, float* hist,
                    int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride, int64_t* step_ptr,
-                   void* stream);
+                   int parity, void* stream);
 
 /* qn_mcmc_accept_propose: qn_mcmc_accept that also writes the NEXT step's proposal from the state it has just decided
  * (one launch and one pass over the state fewer per step): next_mode 0 = nothing more; 1 = prop_next = cur' + sd z +
@@ -163,7 +167,7 @@ int qn_mcmc_accept_propose(const double* prop, const double* sse_prop, double si
                            double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0, float* hist,
                            int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride, int64_t* step_ptr,
                            int next_mode, const double* sd, double c1, const double* delta, int t_next, double s_iso,
-                           double* prop_next, void* stream);
+                           double* prop_next, int parity, void* stream);
 
 /* qn_mcmc_propose_hist: the ADAPTED proposal of adaptive Metropolis (admcmc.py:52-70), drawn in sample
  *   space.  After an adaptation at step i the reference proposes from N(x, c (cov_i + 1e-8 I)) with

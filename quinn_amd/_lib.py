@@ -104,10 +104,10 @@ def lib():
     L.qn_mcmc_apply_delta.argtypes = [vp, vp, i32, f64, i32, i32, i64, u64, vp, vp, vp]
     L.qn_mcmc_apply_delta.restype = i32
     L.qn_mcmc_accept.argtypes = [vp, vp, f64, i32, i32, i32, i64, i32, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                 vp, i32, i64, vp, vp]
+                                 vp, i32, i64, vp, i32, vp]
     L.qn_mcmc_accept.restype = i32
     L.qn_mcmc_accept_propose.argtypes = [vp, vp, f64, i32, i32, i32, i64, i32, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                         vp, vp, vp, i32, i64, vp, i32, vp, f64, vp, i32, f64, vp, vp]
+                                         vp, vp, vp, i32, i64, vp, i32, vp, f64, vp, i32, f64, vp, i32, vp]
     L.qn_mcmc_accept_propose.restype = i32
     L.qn_debug_tanh.argtypes = [vp, vp, i64, vp]
     L.qn_debug_tanh.restype = i32

@@ -324,6 +324,7 @@ __global__ __launch_bounds__(BLK) void k_apply_delta(const double* __restrict__ 
 struct AcceptArgs {
     double half_inv_sig2, lp_const;       // log-posterior = -(half_inv_sig2 * sse + lp_const)
     int chain0, nmcmc, kcap;
+    int par, C;                           // parity of this step: scalar state is read from slot par, written to slot 1 - par
     int64_t p, pstride;
     uint64_t seed;
 };
@@ -339,9 +340,19 @@ struct NextArgs {
     double* out;
 };
 
-// one workgroup per chain, 1024 threads: the row updates are latency-bound (a handful of dependent 8-byte
-// accesses per element), so what counts is loads in flight per chain -- 256 threads took 41 us at p = 8513
-constexpr int ABLK = 1024;
+// A chain's rows are spread over gridDim.x workgroups (2048 elements each).  The row updates are latency-bound (a
+// handful of dependent 8-byte accesses per element), so what counts is loads in flight per chain: one 256-thread
+// workgroup per chain took 41 us at p = 8513, one 1024-thread workgroup 15 us.  Every workgroup of a chain takes
+// the accept decision itself, from the chain's scalar state (current / best log-posterior, number of stored
+// states, step counter), which is DOUBLE-BUFFERED by the parity of the step: all workgroups read slot `par`,
+// workgroup 0 of the chain writes slot 1 - par, so no workgroup can see a half-updated state and no fence,
+// atomic or arrival counter is needed.
+#ifdef QN_ACCEPT_ONE_WG
+constexpr int ABLK = 1024;               // A/B builds: the earlier geometry, one workgroup per chain
+#else
+constexpr int ABLK = 512;
+#endif
+constexpr int AUB = 4;                    // elements per thread in flight
 __global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __restrict__ prop,
                                                 const double* __restrict__ sse_prop, double* __restrict__ cur,
                                                 double* __restrict__ cur_lp, double* __restrict__ best,
@@ -351,8 +362,9 @@ __global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __r
                                                 float* __restrict__ hist, int32_t* __restrict__ mult,
                                                 int32_t* __restrict__ kcur, double* __restrict__ sumx,
                                                 int64_t* __restrict__ step_ptr, NextArgs nx) {
-    const int b = blockIdx.x;
-    const int64_t step = *step_ptr;
+    const int b = blockIdx.y, part = blockIdx.x;
+    const int64_t step = step_ptr[a.par];
+    const int so = a.par * a.C + b, sn = (1 - a.par) * a.C + b;     // old / new slot of the per-chain scalars
     double z0n = 0.0;
     if (nx.mode == 1 && nx.c1 != 0.0) {
         Philox pz;
@@ -361,30 +373,33 @@ __global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __r
         normal2(pz, z0n, dummy);
     }
     const double plp = -(a.half_inv_sig2 * sse_prop[b] + a.lp_const);
-    const double clp = cur_lp[b];
+    const double clp = cur_lp[so];
     const double mh = exp(plp - clp);                               // exp(current_U - proposed_U), mcmc.py:69-72
     Philox ph;
     ph.gen(a.seed, 2 * (uint64_t)step + 1, ctr_of(a.chain0 + b, 2, 0));
     const double u = u01(ph.c[0], ph.c[1]);
     const bool take = u < mh;                                       // NaN -> reject, inf -> accept, as `u < mh_prob`
     const double nlp = take ? plp : clp;
-    const bool better = take && nlp >= best_lp[b];
+    const double blp = best_lp[so];
+    const bool better = take && nlp >= blp;
     const int64_t base = (int64_t)b * a.p;
     double* crow = chain ? chain + ((int64_t)b * (a.nmcmc + 1) + step + 1) * a.p : nullptr;
     // history of DISTINCT states (shifted by x0, float32) with multiplicities, and the running sum of all
     // samples: what the adapted proposal is drawn from (k_propose_hist)
-    const int kc = hist ? kcur[b] : 0;
+    const int kc = hist ? kcur[so] : 0;
     const int knew = take ? kc + 1 : kc;
     float* hrow = (hist && take && knew < a.kcap) ? hist + ((int64_t)b * a.kcap + knew) * a.pstride : nullptr;
     // batches of UB elements per thread: all loads of a batch are issued before its first store, so the
     // (independent) elements overlap their memory latency instead of paying it one after the other
-    constexpr int UB = 4;
-    for (int64_t e0 = threadIdx.x; e0 < a.p; e0 += (int64_t)UB * ABLK) {
+    constexpr int UB = AUB;
+    const int64_t chunk = ((a.p + gridDim.x - 1) / gridDim.x + 1) & ~(int64_t)1;
+    const int64_t lo = part * chunk, hi = lo + chunk < a.p ? lo + chunk : a.p;
+    for (int64_t e0 = lo + threadIdx.x; e0 < hi; e0 += (int64_t)UB * ABLK) {
         double v[UB], xv[UB], sv[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int64_t e = e0 + (int64_t)u * ABLK;
-            const bool in = e < a.p;
+            const bool in = e < hi;
             v[u] = in ? (take ? prop[base + e] : cur[base + e]) : 0.0;
             xv[u] = (in && hist) ? x0[base + e] : 0.0;
             sv[u] = (in && hist) ? sumx[base + e] : 0.0;
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __r
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int64_t e = e0 + (int64_t)u * ABLK;
-            if (e >= a.p) break;
+            if (e >= hi) break;
             if (take) cur[base + e] = v[u];
             if (better) best[base + e] = v[u];
             if (crow) crow[e] = v[u];
@@ -413,33 +428,21 @@ __global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __r
             }
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    if (part == 0 && threadIdx.x == 0) {
         if (hist) {
+            kcur[sn] = knew;                                        // knew >= kcap: history full, the host checks
             if (take) {
-                kcur[b] = knew;                                     // knew >= kcap: history full, the host checks
                 if (knew < a.kcap) mult[(int64_t)b * a.kcap + knew] = 1;
             } else if (kc < a.kcap) {
                 mult[(int64_t)b * a.kcap + kc] += 1;
             }
         }
-        cur_lp[b] = nlp;
-        if (better) best_lp[b] = nlp;
+        cur_lp[sn] = nlp;
+        best_lp[sn] = better ? nlp : blp;
         lps[(int64_t)b * (a.nmcmc + 1) + step + 1] = nlp;
         alphas[(int64_t)b * (a.nmcmc + 1) + step + 1] = mh;
         if (take) nacc[b] += 1;
-    }
-    // the step counter is advanced by the last block to get here (all blocks have read it already:
-    // it is read at kernel entry and the increment happens after a device-scope arrival count)
-    __shared__ int last;
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned int arrived = atomicAdd(reinterpret_cast<unsigned int*>(step_ptr + 1), 1u);
-        last = arrived == (unsigned int)(gridDim.x - 1);
-        if (last) {
-            reinterpret_cast<unsigned int*>(step_ptr + 1)[0] = 0u;
-            *step_ptr = step + 1;
-        }
+        if (b == 0) step_ptr[1 - a.par] = step + 1;
     }
 }
 
@@ -519,13 +522,21 @@ extern "C" int qn_mcmc_apply_delta(const double* cur, const double* delta, int t
     return QN_OK;
 }
 
+static int accept_parts(int64_t p) {
+#ifdef QN_ACCEPT_ONE_WG
+    return 1;
+#endif
+    const int64_t n = (p + ABLK * AUB - 1) / (ABLK * AUB);
+    return n > 16 ? 16 : (int)n;
+}
 extern "C" int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int chain0,
                               int64_t p, int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
                               double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0,
                               float* hist, int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride,
-                              int64_t* step_ptr, void* stream) {
+                              int64_t* step_ptr, int parity, void* stream) {
     if (!prop || !sse_prop || !cur || !cur_lp || !best || !best_lp || !lps || !alphas || !nacc || !step_ptr ||
-        C <= 0 || chain0 < 0 || p <= 0 || sigma <= 0.0 || (hist && (!x0 || !mult || !kcur || !sumx || kcap <= 0 || pstride < p))) {
+        C <= 0 || C > 65535 || chain0 < 0 || p <= 0 || sigma <= 0.0 || (parity != 0 && parity != 1) ||
+        (hist && (!x0 || !mult || !kcur || !sumx || kcap <= 0 || pstride < p))) {
         qn_set_error("qn_mcmc_accept: bad argument");
         return QN_EINVAL;
     }
@@ -533,10 +544,11 @@ extern "C" int qn_mcmc_accept(const double* prop, const double* sse_prop, double
     a.half_inv_sig2 = 0.5 / (sigma * sigma);
     a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
     a.chain0 = chain0; a.nmcmc = nmcmc; a.kcap = kcap; a.p = p; a.pstride = pstride; a.seed = seed;
+    a.par = parity; a.C = C;
     (void)hipGetLastError();
     NextArgs nx;
     nx.mode = 0; nx.t = 0; nx.c1 = 0.0; nx.s_iso = 0.0; nx.sd = nullptr; nx.delta = nullptr; nx.out = nullptr;
-    hipLaunchKernelGGL(k_accept, dim3(C), dim3(ABLK), 0, static_cast<hipStream_t>(stream), a, prop, sse_prop, cur, cur_lp,
+    hipLaunchKernelGGL(k_accept, dim3(accept_parts(p), C), dim3(ABLK), 0, static_cast<hipStream_t>(stream), a, prop, sse_prop, cur, cur_lp,
                        best, best_lp, chain, lps, alphas, nacc, x0, hist, mult, kcur, sumx, step_ptr, nx);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
@@ -548,9 +560,9 @@ extern "C" int qn_mcmc_accept_propose(const double* prop, const double* sse_prop
                                       int64_t* nacc, const double* x0, float* hist, int32_t* mult, int32_t* kcur,
                                       double* sumx, int kcap, int64_t pstride, int64_t* step_ptr, int next_mode,
                                       const double* sd, double c1, const double* delta, int t_next, double s_iso,
-                                      double* prop_next, void* stream) {
+                                      double* prop_next, int parity, void* stream) {
     if (!prop || !sse_prop || !cur || !cur_lp || !best || !best_lp || !lps || !alphas || !nacc || !step_ptr ||
-        C <= 0 || chain0 < 0 || p <= 0 || sigma <= 0.0 || (hist && (!x0 || !mult || !kcur || !sumx || kcap <= 0 || pstride < p)) ||
+        C <= 0 || C > 65535 || chain0 < 0 || p <= 0 || sigma <= 0.0 || (parity != 0 && parity != 1) || (hist && (!x0 || !mult || !kcur || !sumx || kcap <= 0 || pstride < p)) ||
         next_mode < 0 || next_mode > 2 || (next_mode && !prop_next) || (next_mode == 1 && !sd) ||
         (next_mode == 2 && (!delta || t_next < 0 || t_next >= TB))) {
         qn_set_error("qn_mcmc_accept_propose: bad argument");
@@ -560,10 +572,11 @@ extern "C" int qn_mcmc_accept_propose(const double* prop, const double* sse_prop
     a.half_inv_sig2 = 0.5 / (sigma * sigma);
     a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
     a.chain0 = chain0; a.nmcmc = nmcmc; a.kcap = kcap; a.p = p; a.pstride = pstride; a.seed = seed;
+    a.par = parity; a.C = C;
     NextArgs nx;
     nx.mode = next_mode; nx.t = t_next; nx.c1 = c1; nx.s_iso = s_iso; nx.sd = sd; nx.delta = delta; nx.out = prop_next;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_accept, dim3(C), dim3(ABLK), 0, static_cast<hipStream_t>(stream), a, prop, sse_prop, cur, cur_lp,
+    hipLaunchKernelGGL(k_accept, dim3(accept_parts(p), C), dim3(ABLK), 0, static_cast<hipStream_t>(stream), a, prop, sse_prop, cur, cur_lp,
                        best, best_lp, chain, lps, alphas, nacc, x0, hist, mult, kcur, sumx, step_ptr, nx);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;

@@ -70,24 +70,29 @@ class DeviceAMCMC:
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
-    def _propose(self, cur, sd, c1, step_ptr, out):
+    @staticmethod
+    def _step_ptr(s):
+        """Pointer to the CURRENT slot of the double-buffered device step counter (include/quinn_amd.h)."""
+        return s['step'].data_ptr() + 8 * s['par']
+
+    def _propose(self, cur, sd, c1, s, out):
         C, p = out.shape
         _lib.check(self._L.qn_mcmc_propose(cur.data_ptr() if cur is not None else None,
                                            sd.data_ptr() if sd is not None else None, c1, C, self.chain0, p, self.seed,
-                                           step_ptr.data_ptr(), out.data_ptr(), self._stream()), "qn_mcmc_propose")
+                                           self._step_ptr(s), out.data_ptr(), self._stream()), "qn_mcmc_propose")
 
     def _propose_hist_block(self, s, snap, coef, delta):
         C, _, p = delta.shape
         _lib.check(self._L.qn_mcmc_propose_hist_block(
             s['hist'].data_ptr(), snap['w'].data_ptr(), snap['k'].data_ptr(), snap['mean'].data_ptr(), snap['s_lr'],
-            snap['s_iso'], C, self.chain0, p, s['hist'].shape[2], s['hist'].shape[1], self.seed, 0, s['step'].data_ptr(),
+            snap['s_iso'], C, self.chain0, p, s['hist'].shape[2], s['hist'].shape[1], self.seed, 0, self._step_ptr(s),
             coef.data_ptr(),
             delta.data_ptr(), self._stream()), "qn_mcmc_propose_hist_block")
 
     def _apply_delta(self, s, snap, delta, t, out):
         C, p = out.shape
         _lib.check(self._L.qn_mcmc_apply_delta(s['cur'].data_ptr(), delta.data_ptr(), int(t), snap['s_iso'], C,
-                                               self.chain0, p, self.seed, s['step'].data_ptr(), out.data_ptr(), self._stream()),
+                                               self.chain0, p, self.seed, self._step_ptr(s), out.data_ptr(), self._stream()),
                    "qn_mcmc_apply_delta")
 
     def _accept(self, s, prop, sse, nmcmc, nxt=None):
@@ -101,7 +106,8 @@ class DeviceAMCMC:
                 s['nacc'].data_ptr(), s['x0'].data_ptr(), s['hist'].data_ptr(), s['mult'].data_ptr(),
                 s['kcur'].data_ptr(), s['sumx'].data_ptr(), s['hist'].shape[1], s['hist'].shape[2], s['step'].data_ptr(),
                 mode, sd.data_ptr() if sd is not None else None, c1, delta.data_ptr() if delta is not None else None,
-                int(t), s_iso, prop.data_ptr(), self._stream()), "qn_mcmc_accept_propose")
+                int(t), s_iso, prop.data_ptr(), s['par'], self._stream()), "qn_mcmc_accept_propose")
+            s['par'] ^= 1
             return
         _lib.check(self._L.qn_mcmc_accept(
             prop.data_ptr(), sse.data_ptr(), self.sigma, self.op.N, C, self.chain0, p, nmcmc, self.seed, s['cur'].data_ptr(),
@@ -109,7 +115,8 @@ class DeviceAMCMC:
             s['chain'].data_ptr() if s['chain'] is not None else None, s['lps'].data_ptr(), s['alphas'].data_ptr(),
             s['nacc'].data_ptr(), s['x0'].data_ptr(), s['hist'].data_ptr(), s['mult'].data_ptr(),
             s['kcur'].data_ptr(), s['sumx'].data_ptr(), s['hist'].shape[1], s['hist'].shape[2],
-            s['step'].data_ptr(), self._stream()), "qn_mcmc_accept")
+            s['step'].data_ptr(), s['par'], self._stream()), "qn_mcmc_accept")
+        s['par'] ^= 1              # the kernel read slot `par` of the per-chain scalars / step counter and wrote the other
 
     def run(self, nmcmc, param_ini, store_chain=True, verbose=False):
         ini = torch.as_tensor(np.asarray(param_ini), dtype=torch.float64, device=self.dev).reshape(-1, self.op.p)
@@ -169,7 +176,9 @@ class DeviceAMCMC:
         if C * kcap * pstride * 4 > self.max_history_bytes:
             raise MemoryError(f"state history {C} x {kcap} x {pstride} float32 exceeds max_history_bytes="
                               f"{self.max_history_bytes}: run fewer steps per call or raise the limit")
-        s = {'cur': cur, 'cur_lp': cur_lp, 'best': cur.clone(), 'best_lp': cur_lp.clone(), 'x0': cur.clone(),
+        # per-chain scalars the accept kernel maintains are double-buffered by step parity ([2, C]; slot `par` is current)
+        s = {'cur': cur, 'cur_lp': torch.stack([cur_lp, cur_lp]), 'best': cur.clone(),
+             'best_lp': torch.stack([cur_lp, cur_lp]), 'x0': cur.clone(), 'par': 0,
              'chain': (chain_out if chain_out is not None else torch.empty(C, nmcmc + 1, p, dtype=f64, device=dev))
                       if store_chain else None,
              'lps': torch.empty(C, nmcmc + 1, dtype=f64, device=dev),
@@ -177,7 +186,7 @@ class DeviceAMCMC:
              'nacc': torch.zeros(C, dtype=torch.int64, device=dev),
              'hist': torch.empty(C, kcap, pstride, dtype=torch.float32, device=dev),
              'mult': torch.zeros(C, kcap, dtype=torch.int32, device=dev),
-             'kcur': torch.zeros(C, dtype=torch.int32, device=dev),
+             'kcur': torch.zeros(2, C, dtype=torch.int32, device=dev),
              'sumx': torch.zeros(C, p, dtype=f64, device=dev),
              'step': torch.zeros(2, dtype=torch.int64, device=dev)}
         s['hist'][:, 0] = 0.0                                               # row 0 = x_0 - x_0
@@ -203,14 +212,14 @@ class DeviceAMCMC:
             step's proposal (last_fused: the step after these n is an initial-proposal step too)."""
             if state['L'] is not None:                                      # user-supplied initial covariance
                 for _ in range(n):
-                    self._propose(None, None, 0.0, s['step'], z)
+                    self._propose(None, None, 0.0, s, z)
                     prop.copy_(s['cur'] + z @ state['L'].T)
                     self._accept(s, prop, self.op.sse(prop), nmcmc)
                 return False
             have = state['have_prop']
             for k in range(n):
                 if not have:
-                    self._propose(s['cur'], std0, 0.1, s['step'], prop)
+                    self._propose(s['cur'], std0, 0.1, s, prop)
                 nxt = (1, std0, 0.1, None, 0, 0.0) if fuse and (k + 1 < n or last_fused) else None
                 self._accept(s, prop, self.op.sse(prop), nmcmc, nxt)
                 have = nxt is not None
@@ -242,7 +251,7 @@ class DeviceAMCMC:
             if i > self.t0 and i % self.tadapt == 0:
                 # adaptation (admcmc.py:66-67) = snapshot of the history x_0..x_i: n = i + 1 samples
                 scale = self.gamma * 2.4 ** 2 / p
-                state['snap'] = {'k': (s['kcur'] + 1).clone(), 'w': s['mult'].to(torch.float32).sqrt_(),
+                state['snap'] = {'k': (s['kcur'][s['par']] + 1).clone(), 'w': s['mult'].to(torch.float32).sqrt_(),
                                  'mean': s['sumx'] / (i + 1), 's_lr': float(np.sqrt(scale / i)),
                                  's_iso': float(np.sqrt(scale * 1e-8))}
                 graphs['adapted'] = None                                    # new snapshot tensors: recapture
@@ -279,5 +288,5 @@ class DeviceAMCMC:
             i += nrun
             if verbose:
                 print('%d / %d completed, acceptance rate %lg' % (i, nmcmc, float(s['nacc'].double().mean()) / i))
-        return {'chain': s['chain'], 'mapparams': s['best'], 'maxpost': s['best_lp'],
+        return {'chain': s['chain'], 'mapparams': s['best'], 'maxpost': s['best_lp'][s['par']].clone(),
                 'accrate': s['nacc'].double() / max(nmcmc, 1), 'logpost': s['lps'], 'alphas': s['alphas']}

@@ -160,6 +160,7 @@ def test_history_of_distinct_states_matches_the_chain():
     s = captured['s']
     chain = r['chain'].cpu().numpy()
     hist, mult, kcur, sumx = (s[k].cpu().numpy() for k in ('hist', 'mult', 'kcur', 'sumx'))
+    kcur = kcur[s['par']]                                   # per-chain scalars are double-buffered by step parity
     for c in range(C):
         moved = (chain[c, 1:] != chain[c, :-1]).any(axis=1)
         K = 1 + int(moved.sum())
