@@ -86,6 +86,16 @@ int qn_mlp_sse_fwd(const qn_desc* desc, int dtype, const void* W, const void* X,
                    const int32_t* row_idx, int B, int N, int Nb, double* sse_out, void* pred_out,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* The forward call without its final summation kernel, for a consumer that sums a handful of numbers itself
+ * (qn_mcmc_accept): sse_parts_out is [B, parts], parts = qn_mlp_sse_parts(desc, B, Nb, dtype) >= 1, and the plain
+ * left-to-right sum of row b is exactly (bit for bit) what qn_mlp_sse_fwd writes to sse_out[b].  parts > 1 only where
+ * the fused forward kernel runs unpadded (one partial per row split of a chain); otherwise parts = 1 and the call is
+ * qn_mlp_sse_fwd without predictions.  Saves one dependent ~5 us launch per Metropolis step. */
+int qn_mlp_sse_parts(const qn_desc* desc, int B, int Nb, int dtype);
+int qn_mlp_sse_fwd_parts(const qn_desc* desc, int dtype, const void* W, const void* X, const void* Y,
+                         const int32_t* row_idx, int B, int N, int Nb, double* sse_parts_out, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* As above plus gradW_out[b, :] = d sse_out[b] / d W[b, :]  ([B, p] dtype).  Replaces
  * NN_MCMC.logpostgrad -> NNWrap.calc_lossgrad (quinn/solvers/nn_mcmc.py:73-98,
  * quinn/nns/nnwrap.py:128-150) and loss.backward() in nnfit (quinn/nns/nnfit.py:163-165). */
@@ -140,7 +150,8 @@ int qn_adam_batched(double* W, const void* G, double* m, double* v, const double
 int qn_mcmc_propose(const double* cur, const double* sd, double c1, int C, int chain0, int64_t p, uint64_t seed,
                     const int64_t* step_ptr, double* out, void* stream);
 
-/* qn_mcmc_accept: for every chain c: log-posterior of the proposal from its SSE,
+/* qn_mcmc_accept: for every chain c: log-posterior of the proposal from its SSE (sse_prop [C, nparts]: summed left to
+ *   right, nparts = 1 for a plain [C] vector; see qn_mlp_sse_fwd_parts),
  *   lp = -(0.5 sse/sigma^2 + (n_rows/2) log 2pi + n_rows log sigma); mh = exp(lp - cur_lp[c]);
  *   accept iff u_c < mh (mcmc.py:72-75); updates cur, cur_lp, best / best_lp (MAP, mcmc.py:79-81),
  *   nacc, writes chain[c, step+1, :] (optional), lps[c, step+1], alphas[c, step+1]; then advances the
@@ -155,7 +166,7 @@ int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int
                    int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
                    double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0, float* hist,
                    int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride, int64_t* step_ptr,
-                   int parity, void* stream);
+                   int parity, int nparts, void* stream);
 
 /* qn_mcmc_accept_propose: qn_mcmc_accept that also writes the NEXT step's proposal from the state it has just decided
  * (one launch and one pass over the state fewer per step): next_mode 0 = nothing more; 1 = prop_next = cur' + sd z +
@@ -167,7 +178,7 @@ int qn_mcmc_accept_propose(const double* prop, const double* sse_prop, double si
                            double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0, float* hist,
                            int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride, int64_t* step_ptr,
                            int next_mode, const double* sd, double c1, const double* delta, int t_next, double s_iso,
-                           double* prop_next, int parity, void* stream);
+                           double* prop_next, int parity, int nparts, void* stream);
 
 /* qn_mcmc_propose_hist: the ADAPTED proposal of adaptive Metropolis (admcmc.py:52-70), drawn in sample
  *   space.  After an adaptation at step i the reference proposes from N(x, c (cov_i + 1e-8 I)) with

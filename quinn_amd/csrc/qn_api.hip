@@ -345,6 +345,24 @@ extern "C" int qn_mlp_sse_fwd(const qn_desc* d, int dtype, const void* W, const 
                workspace_bytes, stream);
 }
 
+extern "C" int qn_mlp_sse_parts(const qn_desc* d, int B, int Nb, int dtype) {
+    if (!d || B <= 0 || Nb <= 0) return QN_EINVAL;
+    if (d->kind == QN_KIND_MLP && !d->padded && use_fused(d, B, Nb, 0, dtype)) return qn_fused_parts(d, B, Nb);
+    return 1;
+}
+
+extern "C" int qn_mlp_sse_fwd_parts(const qn_desc* d, int dtype, const void* W, const void* X, const void* Y,
+                                    const int32_t* row_idx, int B, int N, int Nb, double* sse_parts_out,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    const int parts = qn_mlp_sse_parts(d, B, Nb, dtype);
+    if (parts <= 1)
+        return run("qn_mlp_sse_fwd_parts", d, dtype, W, X, Y, row_idx, B, N, Nb, sse_parts_out, nullptr, nullptr, workspace,
+                   workspace_bytes, stream);
+    if (int rc = check_common("qn_mlp_sse_fwd_parts", d, dtype, W, X, Y, row_idx, B, N, Nb, sse_parts_out, workspace)) return rc;
+    return qn_fused_run(d, dtype, W, X, Y, row_idx, B, N, Nb, sse_parts_out, nullptr, nullptr, workspace, workspace_bytes,
+                        static_cast<hipStream_t>(stream), true);
+}
+
 extern "C" int qn_mlp_sse_fwdbwd(const qn_desc* d, int dtype, const void* W, const void* X, const void* Y,
                                  const int32_t* row_idx, int B, int N, int Nb, double* sse_out, void* pred_out,
                                  void* gradW_out, void* workspace, size_t workspace_bytes, void* stream) {

@@ -65,6 +65,9 @@ int qn_rnet_fused_run(const qn_desc* d, const void* W, const void* X, const void
 // ---- fused MFMA path with LDS-resident weights: qn_fused.hip
 bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtype);
 size_t qn_fused_workspace(const qn_desc* d, int B, int Nb, int want_grad, int dtype);
+// parts_out (forward only): `sse` is [B][qn_fused_parts()] and receives the per-row-split partial sums (their plain
+// left-to-right sum is the SSE); the final summation kernel is skipped
 int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, const void* Y,
                  const int32_t* row_idx, int B, int N, int Nb, double* sse, void* pred,
-                 void* gradW, void* ws, size_t ws_bytes, hipStream_t st);
+                 void* gradW, void* ws, size_t ws_bytes, hipStream_t st, bool parts_out = false);
+int qn_fused_parts(const qn_desc* d, int B, int Nb);

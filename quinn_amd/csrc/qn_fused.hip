@@ -1162,9 +1162,15 @@ size_t qn_fused_workspace(const qn_desc* d, int B, int Nb, int want_grad, int dt
     return tot + 256;
 }
 
+int qn_fused_parts(const qn_desc* d, int B, int Nb) {
+    FusedArgs a;
+    plan(d, B, Nb, 0, &a);
+    return a.nsplit;
+}
+
 int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, const void* Y, const int32_t* row_idx,
                  int B, int N, int Nb, double* sse, void* pred, void* gradW, void* ws, size_t ws_bytes,
-                 hipStream_t st) {
+                 hipStream_t st, bool parts_out) {
     int H, nhid;
     const int want_grad = gradW != nullptr;
     if (!uniform_hidden(d, &H, &nhid) || dtype != QN_F64) {
@@ -1181,7 +1187,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
         qn_set_error("workspace too small: need %zu bytes, got %zu", need, ws_bytes);
         return QN_EWORKSPACE;
     }
-    double* partial = static_cast<double*>(ws);
+    double* partial = (parts_out && !want_grad) ? sse : static_cast<double*>(ws);
     double* slab = reinterpret_cast<double*>(static_cast<char*>(ws) + npart);
     a.dbg_off = (int64_t)(need / sizeof(double));          // the 256 spare bytes behind the slabs
     const size_t lds_bytes = lds_need(H, a.d, a.o, nhid, want_grad);
@@ -1209,7 +1215,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
         if (gx > 64) gx = 64;
         hipLaunchKernelGGL(k_grad_reduce, dim3(gx, B), dim3(256), 0, st, slab, a.nsplit, d->p, B, (double*)gradW);
     }
-    hipLaunchKernelGGL(k_sum_partials, dim3((B + 63) / 64), dim3(64), 0, st, partial, a.nsplit, B, sse);
+    if (partial != sse) hipLaunchKernelGGL(k_sum_partials, dim3((B + 63) / 64), dim3(64), 0, st, partial, a.nsplit, B, sse);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }

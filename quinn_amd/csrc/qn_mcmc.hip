@@ -324,6 +324,7 @@ __global__ __launch_bounds__(BLK) void k_apply_delta(const double* __restrict__ 
 struct AcceptArgs {
     double half_inv_sig2, lp_const;       // log-posterior = -(half_inv_sig2 * sse + lp_const)
     int chain0, nmcmc, kcap;
+    int nparts;                           // sse_prop is [C, nparts]: partial sums, added left to right
     int par, C;                           // parity of this step: scalar state is read from slot par, written to slot 1 - par
     int64_t p, pstride;
     uint64_t seed;
@@ -372,7 +373,9 @@ __global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __r
         double dummy;
         normal2(pz, z0n, dummy);
     }
-    const double plp = -(a.half_inv_sig2 * sse_prop[b] + a.lp_const);
+    double sse = 0.0;
+    for (int i = 0; i < a.nparts; ++i) sse += sse_prop[(int64_t)b * a.nparts + i];     // order of k_sum_partials
+    const double plp = -(a.half_inv_sig2 * sse + a.lp_const);
     const double clp = cur_lp[so];
     const double mh = exp(plp - clp);                               // exp(current_U - proposed_U), mcmc.py:69-72
     Philox ph;
@@ -533,9 +536,9 @@ extern "C" int qn_mcmc_accept(const double* prop, const double* sse_prop, double
                               int64_t p, int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
                               double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0,
                               float* hist, int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride,
-                              int64_t* step_ptr, int parity, void* stream) {
+                              int64_t* step_ptr, int parity, int nparts, void* stream) {
     if (!prop || !sse_prop || !cur || !cur_lp || !best || !best_lp || !lps || !alphas || !nacc || !step_ptr ||
-        C <= 0 || C > 65535 || chain0 < 0 || p <= 0 || sigma <= 0.0 || (parity != 0 && parity != 1) ||
+        C <= 0 || C > 65535 || chain0 < 0 || p <= 0 || sigma <= 0.0 || (parity != 0 && parity != 1) || nparts < 1 ||
         (hist && (!x0 || !mult || !kcur || !sumx || kcap <= 0 || pstride < p))) {
         qn_set_error("qn_mcmc_accept: bad argument");
         return QN_EINVAL;
@@ -544,7 +547,7 @@ extern "C" int qn_mcmc_accept(const double* prop, const double* sse_prop, double
     a.half_inv_sig2 = 0.5 / (sigma * sigma);
     a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
     a.chain0 = chain0; a.nmcmc = nmcmc; a.kcap = kcap; a.p = p; a.pstride = pstride; a.seed = seed;
-    a.par = parity; a.C = C;
+    a.par = parity; a.C = C; a.nparts = nparts;
     (void)hipGetLastError();
     NextArgs nx;
     nx.mode = 0; nx.t = 0; nx.c1 = 0.0; nx.s_iso = 0.0; nx.sd = nullptr; nx.delta = nullptr; nx.out = nullptr;
@@ -560,9 +563,9 @@ extern "C" int qn_mcmc_accept_propose(const double* prop, const double* sse_prop
                                       int64_t* nacc, const double* x0, float* hist, int32_t* mult, int32_t* kcur,
                                       double* sumx, int kcap, int64_t pstride, int64_t* step_ptr, int next_mode,
                                       const double* sd, double c1, const double* delta, int t_next, double s_iso,
-                                      double* prop_next, int parity, void* stream) {
+                                      double* prop_next, int parity, int nparts, void* stream) {
     if (!prop || !sse_prop || !cur || !cur_lp || !best || !best_lp || !lps || !alphas || !nacc || !step_ptr ||
-        C <= 0 || C > 65535 || chain0 < 0 || p <= 0 || sigma <= 0.0 || (parity != 0 && parity != 1) || (hist && (!x0 || !mult || !kcur || !sumx || kcap <= 0 || pstride < p)) ||
+        C <= 0 || C > 65535 || chain0 < 0 || p <= 0 || sigma <= 0.0 || (parity != 0 && parity != 1) || nparts < 1 || (hist && (!x0 || !mult || !kcur || !sumx || kcap <= 0 || pstride < p)) ||
         next_mode < 0 || next_mode > 2 || (next_mode && !prop_next) || (next_mode == 1 && !sd) ||
         (next_mode == 2 && (!delta || t_next < 0 || t_next >= TB))) {
         qn_set_error("qn_mcmc_accept_propose: bad argument");
@@ -572,7 +575,7 @@ extern "C" int qn_mcmc_accept_propose(const double* prop, const double* sse_prop
     a.half_inv_sig2 = 0.5 / (sigma * sigma);
     a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
     a.chain0 = chain0; a.nmcmc = nmcmc; a.kcap = kcap; a.p = p; a.pstride = pstride; a.seed = seed;
-    a.par = parity; a.C = C;
+    a.par = parity; a.C = C; a.nparts = nparts;
     NextArgs nx;
     nx.mode = next_mode; nx.t = t_next; nx.c1 = c1; nx.s_iso = s_iso; nx.sd = sd; nx.delta = delta; nx.out = prop_next;
     (void)hipGetLastError();

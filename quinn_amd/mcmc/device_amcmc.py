@@ -96,7 +96,9 @@ class DeviceAMCMC:
                    "qn_mcmc_apply_delta")
 
     def _accept(self, s, prop, sse, nmcmc, nxt=None):
+        """sse: [C] or [C, parts] (partial sums, added left to right by the kernel)."""
         C, p = prop.shape
+        nparts = sse.shape[1] if sse.dim() == 2 else 1
         if nxt is not None:
             mode, sd, c1, delta, t, s_iso = nxt
             _lib.check(self._L.qn_mcmc_accept_propose(
@@ -106,7 +108,7 @@ class DeviceAMCMC:
                 s['nacc'].data_ptr(), s['x0'].data_ptr(), s['hist'].data_ptr(), s['mult'].data_ptr(),
                 s['kcur'].data_ptr(), s['sumx'].data_ptr(), s['hist'].shape[1], s['hist'].shape[2], s['step'].data_ptr(),
                 mode, sd.data_ptr() if sd is not None else None, c1, delta.data_ptr() if delta is not None else None,
-                int(t), s_iso, prop.data_ptr(), s['par'], self._stream()), "qn_mcmc_accept_propose")
+                int(t), s_iso, prop.data_ptr(), s['par'], nparts, self._stream()), "qn_mcmc_accept_propose")
             s['par'] ^= 1
             return
         _lib.check(self._L.qn_mcmc_accept(
@@ -115,7 +117,7 @@ class DeviceAMCMC:
             s['chain'].data_ptr() if s['chain'] is not None else None, s['lps'].data_ptr(), s['alphas'].data_ptr(),
             s['nacc'].data_ptr(), s['x0'].data_ptr(), s['hist'].data_ptr(), s['mult'].data_ptr(),
             s['kcur'].data_ptr(), s['sumx'].data_ptr(), s['hist'].shape[1], s['hist'].shape[2],
-            s['step'].data_ptr(), s['par'], self._stream()), "qn_mcmc_accept")
+            s['step'].data_ptr(), s['par'], nparts, self._stream()), "qn_mcmc_accept")
         s['par'] ^= 1              # the kernel read slot `par` of the per-chain scalars / step counter and wrote the other
 
     def run(self, nmcmc, param_ini, store_chain=True, verbose=False):
@@ -214,14 +216,14 @@ class DeviceAMCMC:
                 for _ in range(n):
                     self._propose(None, None, 0.0, s, z)
                     prop.copy_(s['cur'] + z @ state['L'].T)
-                    self._accept(s, prop, self.op.sse(prop), nmcmc)
+                    self._accept(s, prop, self.op.sse_parts(prop), nmcmc)
                 return False
             have = state['have_prop']
             for k in range(n):
                 if not have:
                     self._propose(s['cur'], std0, 0.1, s, prop)
                 nxt = (1, std0, 0.1, None, 0, 0.0) if fuse and (k + 1 < n or last_fused) else None
-                self._accept(s, prop, self.op.sse(prop), nmcmc, nxt)
+                self._accept(s, prop, self.op.sse_parts(prop), nmcmc, nxt)
                 have = nxt is not None
             return have
 
@@ -236,7 +238,7 @@ class DeviceAMCMC:
                 if not have:
                     self._apply_delta(s, snap, delta, t, prop)
                 nxt = (2, None, 0.0, delta, t + 1, snap['s_iso']) if fuse and t + 1 < nsteps else None
-                self._accept(s, prop, self.op.sse(prop), nmcmc, nxt)
+                self._accept(s, prop, self.op.sse_parts(prop), nmcmc, nxt)
                 have = nxt is not None
 
         def capture(fn):

@@ -5,6 +5,7 @@ the predictions -- evaluated by the HIP kernels through the C ABI.
 torch is used for device memory and streams only.
 """
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Tuple
 
@@ -337,6 +338,25 @@ class BatchedMLP:
     def sse(self, W, row_idx=None):
         """sum_{n,o} (y - f_W(x))^2 for every weight vector: float64 device tensor [B]."""
         return self._call(W, row_idx, False, False)[0]
+
+    def sse_parts(self, W):
+        """[B, parts] float64 partial sums whose left-to-right sum is `sse(W)` bit for bit (qn_mlp_sse_fwd_parts): the
+        forward without its final summation launch, for `qn_mcmc_accept`, which adds the handful of numbers itself."""
+        Wt = self.weights(W)
+        B, N = Wt.shape[0], self.N
+        if B == 0 or self._chunk(B, N, False) < B or os.environ.get("QUINN_AMD_NO_PARTS"):     # (env: A/B measurements)
+            return self.sse(Wt).reshape(B, 1)
+        parts = int(self._L.qn_mlp_sse_parts(self._desc, B, N, self.qdt))
+        if parts < 1:
+            raise _lib.QuinnAmdError("qn_mlp_sse_parts failed")
+        out = torch.empty(B, parts, dtype=torch.float64, device=self.device)
+        ws = self._workspace(self.workspace_bytes(B, N, False))
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.qn_mlp_sse_fwd_parts(self._desc, self.qdt, Wt.data_ptr(), self.X.data_ptr(), self.Y.data_ptr(),
+                                                    None, B, N, N, out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                       "qn_mlp_sse_fwd_parts")
+        return out
 
     def sse_grad(self, W, row_idx=None):
         """(sse [B] float64, d sse / d W [B, p] compute dtype), device tensors."""

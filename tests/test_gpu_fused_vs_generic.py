@@ -196,3 +196,24 @@ def test_non_finite_inputs_follow_the_reference(where, grad):
         assert np.isnan(ref) == np.isnan(sf[b])
         if np.isfinite(ref):
             np.testing.assert_allclose(sf[b], ref, rtol=1e-11)
+
+
+@pytest.mark.parametrize("dims,N,B", [((1, 64, 64, 64, 1), 4096, 64), ((2, 32, 32, 1), 700, 5), ((1, 50, 50, 1), 300, 3),
+                                      ((1, 128, 128, 128, 1), 1000, 4), ((3, 256, 256, 2), 200, 2)])
+def test_partial_sums_add_up_to_the_sse_bit_for_bit(dims, N, B):
+    """qn_mlp_sse_fwd_parts: the forward without its final summation launch; summing a row left to right gives exactly
+    what qn_mlp_sse_fwd returns (the accept kernel of the device sampler does that sum itself)."""
+    rs = np.random.RandomState(N)
+    arch = MLPArch(dims, "tanh")
+    x, y = rs.randn(N, dims[0]), rs.randn(N, dims[-1])
+    op = BatchedMLP(arch, x, y)
+    W = op.weights(rs.randn(B, arch.nparams) / np.sqrt(max(dims)))
+    parts = op.sse_parts(W)
+    full = op.sse(W)
+    assert parts.shape[0] == B and parts.shape[1] >= 1
+    acc = torch.zeros(B, dtype=torch.float64, device=parts.device)
+    for i in range(parts.shape[1]):
+        acc = acc + parts[:, i]
+    assert torch.equal(acc, full)
+    if dims == (1, 64, 64, 64, 1):
+        assert parts.shape[1] == 8                       # cfg2: 8 row splits per chain
