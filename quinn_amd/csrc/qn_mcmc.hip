@@ -341,7 +341,7 @@ struct NextArgs {
     double* out;
 };
 
-// A chain's rows are spread over gridDim.x workgroups (2048 elements each).  The row updates are latency-bound (a
+// A chain's rows are spread over gridDim.x workgroups (1024 elements each, at most 16 per chain).  The row updates are latency-bound (a
 // handful of dependent 8-byte accesses per element), so what counts is loads in flight per chain: one 256-thread
 // workgroup per chain took 41 us at p = 8513, one 1024-thread workgroup 15 us.  Every workgroup of a chain takes
 // the accept decision itself, from the chain's scalar state (current / best log-posterior, number of stored
@@ -353,7 +353,10 @@ constexpr int ABLK = 1024;               // A/B builds: the earlier geometry, on
 #else
 constexpr int ABLK = 512;
 #endif
-constexpr int AUB = 4;                    // elements per thread in flight
+#ifndef QN_AUB
+#define QN_AUB 2
+#endif
+constexpr int AUB = QN_AUB;               // elements per thread in flight
 __global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __restrict__ prop,
                                                 const double* __restrict__ sse_prop, double* __restrict__ cur,
                                                 double* __restrict__ cur_lp, double* __restrict__ best,

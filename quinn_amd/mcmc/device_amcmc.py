@@ -45,7 +45,7 @@ from ..ops import BatchedMLP
 
 class DeviceAMCMC:
     def __init__(self, op: BatchedMLP, sigma, gamma=0.1, t0=100, tadapt=1000, cov_ini=None, seed=0,
-                 use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=False, groups=1):
+                 use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=True, groups=1):
         if op.dtype != "float64":
             raise NotImplementedError("the device AMCMC engine runs the float64 operator")
         self.op, self.sigma = op, float(sigma)
@@ -55,8 +55,9 @@ class DeviceAMCMC:
         self.seed = int(seed) & (2 ** 63 - 1)
         self.use_graph = use_graph
         self.max_history_bytes = int(max_history_bytes)
-        # next step's proposal written by the accept kernel (bit-identical; A/B on one box: 2-3 % SLOWER than the
-        # separate proposal kernel, which spreads over the whole chip while the accept kernel runs one block per chain)
+        # next step's proposal written by the accept kernel (bit-identical to the separate proposal kernel; A/B on one
+        # box: 2-3 % slower while the accept kernel ran one workgroup per chain, 1 % faster now that it spreads a
+        # chain over several)
         self.fuse_propose = bool(fuse_propose)
         self.chain0 = int(chain0)      # global id of this engine's first chain (random streams are keyed by it)
         # groups > 1: the chains are split into that many independent groups, each on its own HIP stream, enqueued

@@ -19,7 +19,7 @@ op = BatchedMLP(arch, x, y)
 ini = np.stack([np.random.RandomState(1000 + c).rand(arch.nparams) for c in range(C)])
 UG = os.environ.get("USE_GRAPH", "0") == "1"
 res = {"use_graph": UG, "nmcmc": NMCMC}
-FUSE = os.environ.get("QN_FUSE", "0") == "1"
+FUSE = os.environ.get("QN_FUSE", "1") == "1"
 res["fuse_propose"] = FUSE
 eng = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=1000, seed=1, use_graph=UG, fuse_propose=FUSE)
 eng.run(20, ini, store_chain=True)                      # warm-up (first launches)
