@@ -201,13 +201,15 @@ int qn_mcmc_propose_hist(const double* cur, const float* hist, const float* wsna
  * for t = 0..TB-1 reads the history once: HBM traffic per step / TB, a (TB x K).(K x p) product per chain
  * (float32 matrix cores).  step_ptr != NULL: step0 is read from the device step counter when the kernels
  * run (a static launch, capturable in a HIP graph).  coef: scratch of C * (ceil4(kcap) + 1) * TB float32; delta: [C, TB, p] float64.
+ * order (optional, [C] int32): a permutation of the chains giving the dispatch order of the history product -- pass the
+ * chains sorted by ksnap, longest first (the work per chain is proportional to ksnap[c]); results do not depend on it.
  * qn_mcmc_apply_delta: out[c,:] = cur[c,:] + delta[c, t, :] + s_iso * v (the proposal of step step0 + t; v on the
  * stream of the CURRENT step *step_ptr, as in qn_mcmc_propose_hist; s_iso is unused by the block call). */
 int qn_mcmc_hist_block_steps(void);
 int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap, const int32_t* ksnap, const double* msnap,
                                double s_lr, double s_iso, int C, int chain0, int64_t p, int64_t pstride, int kcap,
                                uint64_t seed, int64_t step0, const int64_t* step_ptr, float* coef, double* delta,
-                               void* stream);
+                               const int32_t* order, void* stream);
 int qn_mcmc_apply_delta(const double* cur, const double* delta, int t, double s_iso, int C, int chain0, int64_t p,
                         uint64_t seed, const int64_t* step_ptr, double* out, void* stream);
 

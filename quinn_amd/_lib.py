@@ -103,7 +103,7 @@ def lib():
     L.qn_mcmc_propose_hist.restype = i32
     L.qn_mcmc_hist_block_steps.argtypes = []
     L.qn_mcmc_hist_block_steps.restype = i32
-    L.qn_mcmc_propose_hist_block.argtypes = [vp, vp, vp, vp, f64, f64, i32, i32, i64, i64, i32, u64, i64, vp, vp, vp, vp]
+    L.qn_mcmc_propose_hist_block.argtypes = [vp, vp, vp, vp, f64, f64, i32, i32, i64, i64, i32, u64, i64, vp, vp, vp, vp, vp]
     L.qn_mcmc_propose_hist_block.restype = i32
     L.qn_mcmc_apply_delta.argtypes = [vp, vp, i32, f64, i32, i32, i64, u64, vp, vp, vp]
     L.qn_mcmc_apply_delta.restype = i32

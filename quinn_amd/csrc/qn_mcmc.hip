@@ -226,6 +226,7 @@ __global__ __launch_bounds__(BLK, 2) void k_hist_block_mfma(HistBlockArgs a, con
                                                             const float* __restrict__ csum,
                                                             const int32_t* __restrict__ ksnap,
                                                             const double* __restrict__ msnap,
+                                                            const int32_t* __restrict__ order,
                                                             double* __restrict__ delta) {
     constexpr int MT = TB / 32;          // tiles of 32 steps
     constexpr int NTL = 4;               // tiles of 32 columns per wave
@@ -234,7 +235,9 @@ __global__ __launch_bounds__(BLK, 2) void k_hist_block_mfma(HistBlockArgs a, con
 #endif
     constexpr int RG = QN_HIST_RG;       // row pairs in flight
     __shared__ __attribute__((aligned(16))) float cs[KB2 * TB];
-    const int b = blockIdx.y;
+    // chains are dispatched in the caller's order (longest history first): a workgroup's time is proportional to
+    // its chain's K, which differs up to 3x between chains, and the hardware hands out workgroups in grid order
+    const int b = order ? order[blockIdx.y] : blockIdx.y;
     const int K = ksnap[b] < a.kcap ? ksnap[b] : a.kcap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l32 = lane & 31, hi = lane >> 5;
@@ -493,7 +496,8 @@ extern "C" int qn_mcmc_hist_block_steps(void) { return TB; }
 extern "C" int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap, const int32_t* ksnap,
                                           const double* msnap, double s_lr, double s_iso, int C, int chain0,
                                           int64_t p, int64_t pstride, int kcap, uint64_t seed, int64_t step0,
-                                          const int64_t* step_ptr, float* coef, double* delta, void* stream) {
+                                          const int64_t* step_ptr, float* coef, double* delta, const int32_t* order,
+                                          void* stream) {
     if (!hist || !wsnap || !ksnap || !msnap || !coef || !delta || C <= 0 || C > 65535 || chain0 < 0 || p <= 0 || kcap <= 0 ||
         pstride < p || (pstride & 3) || step0 < 0) {
         qn_set_error("qn_mcmc_propose_hist_block: bad argument (pstride must be a multiple of 4 and >= p)");
@@ -510,7 +514,7 @@ extern "C" int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap,
     float* csum = coef + (int64_t)C * a.kstride * TB;                  // [C][TB] behind the coefficients
     hipLaunchKernelGGL(k_hist_coef_sum, dim3(C), dim3(BLK), 0, st, a, (const float*)coef, ksnap, csum);
     hipLaunchKernelGGL(k_hist_block_mfma, dim3((int)((p + 4 * BLK / 2 - 1) / (4 * BLK / 2)), C), dim3(BLK), 0, st, a, hist,
-                       (const float*)coef, (const float*)csum, ksnap, msnap, delta);
+                       (const float*)coef, (const float*)csum, ksnap, msnap, order, delta);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }

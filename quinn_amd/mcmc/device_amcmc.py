@@ -35,6 +35,7 @@ differ (Philox instead of numpy MT19937, sample-space draw instead of an SVD fac
 with the host sampler in distribution, not bit for bit.  Use `AMCMC` for bit-exact parity.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -88,7 +89,8 @@ class DeviceAMCMC:
             s['hist'].data_ptr(), snap['w'].data_ptr(), snap['k'].data_ptr(), snap['mean'].data_ptr(), snap['s_lr'],
             snap['s_iso'], C, self.chain0, p, s['hist'].shape[2], s['hist'].shape[1], self.seed, 0, self._step_ptr(s),
             coef.data_ptr(),
-            delta.data_ptr(), self._stream()), "qn_mcmc_propose_hist_block")
+            delta.data_ptr(), None if os.environ.get("QUINN_AMD_NO_ORDER") else snap['order'].data_ptr(),     # (env: A/B)
+            self._stream()), "qn_mcmc_propose_hist_block")
 
     def _apply_delta(self, s, snap, delta, t, out):
         C, p = out.shape
@@ -256,6 +258,8 @@ class DeviceAMCMC:
                 scale = self.gamma * 2.4 ** 2 / p
                 state['snap'] = {'k': (s['kcur'][s['par']] + 1).clone(), 'w': s['mult'].to(torch.float32).sqrt_(),
                                  'mean': s['sumx'] / (i + 1), 's_lr': float(np.sqrt(scale / i)),
+                                 # dispatch order of the history product: longest history first
+                                 'order': torch.argsort(s['kcur'][s['par']], descending=True).to(torch.int32),
                                  's_iso': float(np.sqrt(scale * 1e-8))}
                 graphs['adapted'] = None                                    # new snapshot tensors: recapture
                 if coef is None:

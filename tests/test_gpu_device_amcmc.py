@@ -115,7 +115,15 @@ def test_sample_space_proposal_kernel_covariance_and_history_tracking():
     delta = torch.empty(C, TB, p, dtype=torch.float64, device=dev)
     _lib.check(L.qn_mcmc_propose_hist_block(hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(), mean.data_ptr(),
                                             float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p, pstride, kcap,
-                                            1234, 10, None, coef.data_ptr(), delta.data_ptr(), None), "propose_hist_block")
+                                            1234, 10, None, coef.data_ptr(), delta.data_ptr(), None, None), "propose_hist_block")
+    # a dispatch order (any permutation of the chains) does not change the result
+    delta_p = torch.empty_like(delta)
+    order = torch.randperm(C, device=dev).to(torch.int32)
+    _lib.check(L.qn_mcmc_propose_hist_block(hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(), mean.data_ptr(),
+                                            float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p, pstride, kcap,
+                                            1234, 10, None, coef.data_ptr(), delta_p.data_ptr(), order.data_ptr(), None),
+               "propose_hist_block")
+    assert torch.equal(delta, delta_p)
     out3 = torch.empty_like(out)
     _lib.check(L.qn_mcmc_apply_delta(cur.data_ptr(), delta.data_ptr(), 7, float(np.sqrt(c * 1e-8)), C, 0, p, 1234,
                                      step.data_ptr(), out3.data_ptr(), None), "apply_delta")
