@@ -211,6 +211,29 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / (args.graph if args.graph else 1)
     lp_last = -neg_log_post_from_sse(out[0].cpu().numpy(), N, SIGMA)
     assert np.all(np.isfinite(lp_last))
+    step_dev_ms = kern_ms
+    if not want_grad and rank == 0 and op.sse_parts(batches[0]).shape[1] > 1:
+        # the dominant kernel ALONE (what rocprofv3 reports for it): the forward without the 64-thread kernel that
+        # adds the 8 row-split partial sums of a chain (qn_mlp_sse_fwd_parts), same graph / event scheme as above
+        g2n = args.graph if args.graph else 1
+        g2 = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            op.sse_parts(batches[0])
+        torch.cuda.current_stream(dev).wait_stream(side)
+        with torch.cuda.graph(g2):
+            for i in range(g2n):
+                parts = op.sse_parts(batches[i % NBATCH])
+        g2.replay()
+        torch.cuda.synchronize(dev)
+        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlaunch)]
+        for a_, b_ in ev2:
+            a_.record()
+            g2.replay()
+            b_.record()
+        torch.cuda.synchronize(dev)
+        kern_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev2])) / g2n
 
     t_max = el
     if dist is not None:
@@ -250,7 +273,7 @@ def main():
                        "parallelism": f"chains sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "flops_per_eval": flops, "evals_per_launch": CHAINS,
-                         "kernel_ms": kern_ms},
+                         "kernel_ms": kern_ms, "step_device_ms": step_dev_ms},
         }
         if world == 1 and not args.no_extras:
             res["extras"] = extras(op, arch, batches, args)
