@@ -51,7 +51,8 @@ __host__ __device__ inline int lds_doubles(int H, int dp, int o, int nhid) {
     return H * dp + H + (nhid - 1) * (H * stride_of(H) + H) + o * H + o + 8;   // + reduction scratch
 }
 constexpr int TANH_TAB = QN_TANH_LDS_DOUBLES;           // doubles reserved for the tanh table behind an image
-inline int padded_d(int d) { return d <= 2 ? 2 : 4; }
+inline int padded_d(int d) { return d <= 2 ? 2 : d <= 4 ? 4 : d <= 8 ? 8 : 16; }
+constexpr int DWIDE = 16, OWIDE = 16;    // forward kernel (tanh): up to 16 inputs / outputs; backward: DMAX / OMAX
 
 template <int ACT, bool NANSAFE = true> __device__ __forceinline__ double act_apply(double z, const double* tab) {
     if constexpr (ACT == QN_ACT_TANH) return qn_tanh_f64_tab<NANSAFE>(z, tab);
@@ -135,7 +136,8 @@ __device__ __forceinline__ int stage_weights(double* __restrict__ lds, const dou
     return bad;
 }
 
-template <int H, int G, int ACT, int DP, int NT>
+// OM = 4: targets prefetched with the inputs; OM = 16 (more than 4 outputs): targets read where they are used
+template <int H, int G, int ACT, int DP, int NT, int OM = OMAX>
 __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, const double* __restrict__ W,
                                                       const double* __restrict__ X, const double* __restrict__ Y,
                                                       const int32_t* __restrict__ row_idx,
@@ -163,7 +165,12 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
 
     // data of the NEXT iteration is fetched while the current one computes (x, y and row indices come
     // from HBM/L2; their latency would otherwise be exposed once per iteration)
-    double xn[G][DP], yn[G][OMAX];
+    constexpr bool YPRE = OM <= OMAX;             // prefetch the targets (few outputs) or read them late
+    constexpr int OY = YPRE ? OM : 1;
+    constexpr bool XPRE = DP <= DMAX;             // likewise the inputs: more than 4 are read at the start of the iteration
+    constexpr int DX = XPRE ? DP : 1;
+    double xn[G][DX], yn[G][OY];
+    int64_t rr_n[G];
     int nrow_n[G];
     bool valid_n[G];
     int xbad_n = 0;
@@ -178,18 +185,20 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
             const int nn = valid_n[g] ? n : 0;
             const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
 #pragma unroll
-            for (int k = 0; k < DP; ++k) {
-                xn[g][k] = k < d ? X[rr * d + k] : 0.0;
+            for (int k = 0; k < DX; ++k) {
+                xn[g][k] = (XPRE && k < d) ? X[rr * d + k] : 0.0;
                 xbad_n |= !qn_bounded(xn[g][k]);
             }
 #pragma unroll
-            for (int qo = 0; qo < OMAX; ++qo) yn[g][qo] = qo < o ? Y[rr * o + qo] : 0.0;
+            for (int qo = 0; qo < OY; ++qo) yn[g][qo] = (YPRE && qo < o) ? Y[rr * o + qo] : 0.0;
+            rr_n[g] = rr;
         }
     };
     fetch(0);
     for (int it = 0; it < a.iters; ++it) {
         double act[G][T][4];
-        double yk[G][OMAX];
+        double yk[G][OY];
+        int64_t rrk[G];
         int nrow[G];
         bool valid[G];
         double xk[G][DP];
@@ -197,10 +206,17 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
         for (int g = 0; g < G; ++g) {
             valid[g] = valid_n[g];
             nrow[g] = nrow_n[g];
+            rrk[g] = rr_n[g];
 #pragma unroll
-            for (int k = 0; k < DP; ++k) xk[g][k] = xn[g][k];
+            for (int k = 0; k < DP; ++k) {
+                if constexpr (XPRE) xk[g][k] = xn[g][k];
+                else {
+                    xk[g][k] = k < d ? X[rrk[g] * d + k] : 0.0;
+                    xbad_n |= !qn_bounded(xk[g][k]);
+                }
+            }
 #pragma unroll
-            for (int qo = 0; qo < OMAX; ++qo) yk[g][qo] = yn[g][qo];
+            for (int qo = 0; qo < OY; ++qo) yk[g][qo] = yn[g][qo];
         }
         const bool nan_possible = w_unbounded || __any(xbad_n);
         if (it + 1 < a.iters) fetch(it + 1);
@@ -218,6 +234,9 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
 #pragma unroll
                         for (int k = 0; k < DP; ++k) z = fma(lds[offW0 + j * DP + k], xk[g][k], z);
                         act[g][t][i] = act_apply<ACT, NS>(z, tanh_tab);
+                        // keep the scheduler from hoisting every element's DP weight reads at once (without it the
+                        // 4-input 3x64 kernel spilled 316 bytes per lane: 400 k -> 493 k evals/s at 64 chains x N=4096)
+                        if constexpr (DP > DMAX || (DP > 2 && H == 64)) __builtin_amdgcn_sched_barrier(0);
                     }
             }
         };
@@ -262,9 +281,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
         // ---- last layer (VALU + 2 cross-lane adds), residual, SSE
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-#pragma unroll
-            for (int qo = 0; qo < OMAX; ++qo) {
-                if (qo >= o) break;
+            auto output = [&](int qo, double yv) {
                 double part = 0.0;
 #pragma unroll
                 for (int t = 0; t < T; ++t)
@@ -274,11 +291,20 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
                 part += __shfl_xor(part, 16, 64);
                 part += __shfl_xor(part, 32, 64);
                 const double pr = part + lds[offbl + qo];
-                const double res = pr - yk[g][qo];
+                const double res = pr - yv;
                 if (valid[g] && q == 0) {
                     sse += res * res;
                     if (pred_out) pred_out[((int64_t)b * a.Nb + nrow[g]) * o + qo] = pr;
                 }
+            };
+            if constexpr (YPRE) {
+#pragma unroll
+                for (int qo = 0; qo < OM; ++qo) {
+                    if (qo >= o) break;
+                    output(qo, yk[g][qo]);
+                }
+            } else {
+                for (int qo = 0; qo < o; ++qo) output(qo, Y[rrk[g] * o + qo]);     // more than 4 outputs: a plain loop
             }
         }
     }
@@ -1099,7 +1125,19 @@ using bwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, 
 // Forward geometry: 4 waves x 2 row groups per workgroup (2 workgroups / CU, 2 waves / SIMD).  The
 // alternative 8 waves x 1 row group (4 waves / SIMD, same 128 rows per iteration) measured 3.5 % slower
 // at cfg2 (462 k vs 480 k evals/s): occupancy is not the lever on a serial DP pipe.
-fwd_fn pick_fwd(int H, int act, int dp) {
+fwd_fn pick_fwd(int H, int act, int dp, int o) {
+    if (dp > DMAX || o > OMAX) {             // wide first / last layer: tanh networks only
+#define QN_PICKW(HH, DD)                                                                          \
+    if (H == HH && dp == DD)                                                                      \
+        return o > OMAX ? k_fused_fwd_f64<HH, G_FWD, QN_ACT_TANH, DD, WG, OWIDE>                  \
+                        : k_fused_fwd_f64<HH, G_FWD, QN_ACT_TANH, DD, WG, OMAX>;
+        if (act != QN_ACT_TANH) return nullptr;
+        QN_PICKW(16, 2) QN_PICKW(16, 4) QN_PICKW(16, 8) QN_PICKW(16, 16)
+        QN_PICKW(32, 2) QN_PICKW(32, 4) QN_PICKW(32, 8) QN_PICKW(32, 16)
+        QN_PICKW(64, 2) QN_PICKW(64, 4) QN_PICKW(64, 8) QN_PICKW(64, 16)
+#undef QN_PICKW
+        return nullptr;
+    }
 #define QN_PICK(HH, AA, DD)                                                                    \
     if (H == HH && act == AA && dp == DD)                                                      \
         return k_fused_fwd_f64<HH, G_FWD, AA, DD, WG>;
@@ -1149,7 +1187,11 @@ bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtyp
 #endif
     if (H == HS && want_grad) return false;          // the streaming kernel is forward-only
     if (H != 16 && H != 32 && H != 64 && H != HS) return false;
-    if (d->dims[0] > DMAX || d->dims[d->nlayers] > OMAX) return false;
+    const int din = d->dims[0], dout = d->dims[d->nlayers];
+    if (din > DMAX || dout > OMAX) {
+        // wide first / last layer: forward kernel only, tanh, hidden width <= 64
+        if (want_grad || H == HS || d->act != QN_ACT_TANH || din > DWIDE || dout > OWIDE) return false;
+    }
     if (want_grad && !pick_bwd(H, nhid)) return false;
     return lds_need(H, d->dims[0], d->dims[d->nlayers], nhid, want_grad) <= 160 * 1024;
 }
@@ -1194,7 +1236,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
     dim3 grid(a.nsplit, B);
     (void)hipGetLastError();
     if (!want_grad) {
-        fwd_fn kern = pick_fwd(H, a.act, padded_d(a.d));
+        fwd_fn kern = pick_fwd(H, a.act, padded_d(a.d), a.o);
         if (!kern) {
             qn_set_error("qn_fused_run: no forward kernel instance for H=%d act=%d", H, a.act);
             return QN_EUNSUPPORTED;

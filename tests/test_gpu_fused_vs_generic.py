@@ -217,3 +217,41 @@ def test_partial_sums_add_up_to_the_sse_bit_for_bit(dims, N, B):
     assert torch.equal(acc, full)
     if dims == (1, 64, 64, 64, 1):
         assert parts.shape[1] == 8                       # cfg2: 8 row splits per chain
+
+
+@pytest.mark.parametrize("dims", [(6, 64, 64, 64, 1), (10, 32, 32, 10), (16, 16, 16), (3, 64, 64, 7), (5, 50, 40, 2),
+                                  (8, 11, 11, 11, 12)])
+def test_wide_first_and_last_layer_in_the_fused_forward(dims):
+    """Up to 16 inputs / outputs (tanh): the fused FORWARD kernel takes them (inputs / targets beyond 4 are read where
+    they are used instead of being prefetched); the gradient of such a network runs on the layer-wise kernels."""
+    rs = np.random.RandomState(sum(dims))
+    arch = MLPArch(dims, "tanh")
+    N, B = 777, 4
+    x, y = rs.randn(N, dims[0]), rs.randn(N, dims[-1])
+    W = rs.randn(B, arch.nparams) / np.sqrt(max(dims))
+    idx = rs.randint(0, N, size=(B, 300))
+    op = BatchedMLP(arch, x, y)
+    assert op.path(B, N, False) == _lib.PATH_FUSED and op.path(B, N, True) == _lib.PATH_GENERIC
+    L = _lib.lib()
+    res = {}
+    for path in (_lib.PATH_GENERIC, _lib.PATH_AUTO):
+        old = L.qn_set_path(path)
+        try:
+            s1 = op.sse(W)
+            s2, pr = op.sse_pred(W, row_idx=idx)
+        finally:
+            L.qn_set_path(old)
+        res[path] = (s1.cpu().numpy(), s2.cpu().numpy(), pr.cpu().numpy())
+    a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_AUTO]
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-12)
+    np.testing.assert_allclose(b[1], a[1], rtol=1e-12)
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-11, atol=1e-12)
+    # non-finite input in a late column of x: NaN-propagating tanh, same result as the layer-wise path
+    x2 = x.copy(); x2[5, dims[0] - 1] = np.nan
+    op2 = BatchedMLP(arch, x2, y)
+    old = L.qn_set_path(_lib.PATH_GENERIC)
+    try:
+        ref = op2.sse(W).cpu().numpy()
+    finally:
+        L.qn_set_path(old)
+    np.testing.assert_allclose(op2.sse(W).cpu().numpy(), ref, rtol=1e-12, equal_nan=True)
