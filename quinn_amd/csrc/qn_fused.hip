@@ -18,7 +18,7 @@
 // (64 banks x 4 B, conflicts per 32-lane half) both the forward fragment read (16 rows x 2 cols)
 // and the transposed read used by the backward pass (2 rows x 16 cols) are conflict-free.
 //
-// First layer (d <= 4 inputs) and last layer (o <= 4 outputs) are thin and run on the VALU; the
+// First layer (d <= 4 inputs; forward kernel: <= 16) and last layer (o <= 4 outputs; forward: <= 16) are thin and run on the VALU; the
 // last layer's dot product is finished with two cross-lane adds (lanes l, l^16, l^32 hold the same
 // data row).  SSE partials are reduced in a fixed order (bitwise reproducible).
 #include "qn_common.h"
