@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
                         act[g][t][i] = act_apply<ACT, NS>(z, tanh_tab);
                         // keep the scheduler from hoisting every element's DP weight reads at once (without it the
                         // 4-input 3x64 kernel spilled 316 bytes per lane: 400 k -> 493 k evals/s at 64 chains x N=4096)
-                        if constexpr (DP > DMAX || (DP > 2 && H == 64)) __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (DP > DMAX || ((DP > 2 || ACT != QN_ACT_TANH) && H == 64)) __builtin_amdgcn_sched_barrier(0);
                     }
             }
         };
