@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int RMAX = 8, DOMAX = 4;
+constexpr int RMAX = 8, DOMAX = 4, DOWIDE = 16;     // inputs / outputs: 4 (forward + backward), 16 (forward kernel only)
 
 struct RnFusedArgs {
     int64_t p;                      // flat parameters per chain
@@ -37,20 +37,20 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // LDS image (doubles): Wpre [R][DOMAX] | bpre [R] | Weff [S][R*R + R] | Wpost [DOMAX][R] | bpost [DOMAX] | tanh table
-template <int R> __host__ __device__ constexpr int img_doubles(int S) {
-    return R * DOMAX + R + S * (R * R + R) + DOMAX * R + DOMAX;
+template <int R, int DO = DOMAX> __host__ __device__ constexpr int img_doubles(int S) {
+    return R * DO + R + S * (R * R + R) + DO * R + DO;
 }
 
-template <int R>
+template <int R, int DO = DOMAX>
 __device__ __forceinline__ void stage(const RnFusedArgs& a, const double* __restrict__ Wb, double* lds, int tid, int nt) {
     const int r = a.r;
     double* Wpre = lds;
-    double* bpre = Wpre + R * DOMAX;
+    double* bpre = Wpre + R * DO;
     double* Weff = bpre + R;
     double* Wpost = Weff + a.S * (R * R + R);
-    double* bpost = Wpost + DOMAX * R;
-    for (int e = tid; e < R * DOMAX; e += nt) {
-        const int j = e / DOMAX, k = e % DOMAX;
+    double* bpost = Wpost + DO * R;
+    for (int e = tid; e < R * DO; e += nt) {
+        const int j = e / DO, k = e % DO;
         Wpre[e] = (a.pre && j < r && k < a.d) ? Wb[a.offWpre + j * a.d + k] : 0.0;
     }
     for (int e = tid; e < R; e += nt) bpre[e] = (a.pre && e < r) ? Wb[a.offBpre + e] : 0.0;
@@ -69,11 +69,11 @@ __device__ __forceinline__ void stage(const RnFusedArgs& a, const double* __rest
         }
         Weff[e] = s;
     }
-    for (int e = tid; e < DOMAX * R; e += nt) {
+    for (int e = tid; e < DO * R; e += nt) {
         const int q = e / R, k = e % R;
         Wpost[e] = (a.post && q < a.o && k < r) ? Wb[a.offWpost + q * r + k] : 0.0;
     }
-    for (int e = tid; e < DOMAX; e += nt) bpost[e] = (a.post && e < a.o) ? Wb[a.offBpost + e] : 0.0;
+    for (int e = tid; e < DO; e += nt) bpost[e] = (a.post && e < a.o) ? Wb[a.offBpost + e] : 0.0;
 }
 
 __device__ __forceinline__ double act_f(double z, int act, const double* tab) {
@@ -82,11 +82,11 @@ __device__ __forceinline__ double act_f(double z, int act, const double* tab) {
 __device__ __forceinline__ double act_d(double a, int act) { return act == QN_ACT_TANH ? 1.0 - a * a : 1.0; }
 
 // one data row through the network; states written to the stash when GRAD
-template <int R, bool GRAD>
-__device__ __forceinline__ void forward_row(const RnFusedArgs& a, const double* lds, const double* tab, const double (&x)[DOMAX],
+template <int R, bool GRAD, int DO = DOMAX>
+__device__ __forceinline__ void forward_row(const RnFusedArgs& a, const double* lds, const double* tab, const double (&x)[DO],
                                             double (&out)[R], double* stash, int T) {
     const double* Wpre = lds;
-    const double* bpre = Wpre + R * DOMAX;
+    const double* bpre = Wpre + R * DO;
     const double* Weff = bpre + R;
     const double h = 1.0 / a.S;
     if (a.pre) {
@@ -94,12 +94,12 @@ __device__ __forceinline__ void forward_row(const RnFusedArgs& a, const double* 
         for (int j = 0; j < R; ++j) {
             double z = bpre[j];
 #pragma unroll
-            for (int k = 0; k < DOMAX; ++k) z = fma(Wpre[j * DOMAX + k], x[k], z);
+            for (int k = 0; k < DO; ++k) z = fma(Wpre[j * DO + k], x[k], z);
             out[j] = j < a.r ? act_f(z, a.act, tab) : 0.0;
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < R; ++j) out[j] = (j < DOMAX && j < a.r) ? x[j < DOMAX ? j : 0] : 0.0;
+        for (int j = 0; j < R; ++j) out[j] = (j < DO && j < a.r) ? x[j < DO ? j : 0] : 0.0;
     }
     for (int i = 0; i < a.S; ++i) {
         const double* Wi = Weff + i * (R * R + R);
@@ -124,30 +124,31 @@ __device__ __forceinline__ void forward_row(const RnFusedArgs& a, const double* 
     }
 }
 
-template <int R>
+// DO = 4, or 16 for networks with more than 4 inputs / outputs (forward only)
+template <int R, int DO = DOMAX>
 __global__ __launch_bounds__(256) void k_rnet_fwd(RnFusedArgs a, const double* __restrict__ W, const double* __restrict__ X,
                                                   const double* __restrict__ Y, const int32_t* __restrict__ row_idx,
                                                   double* __restrict__ pred, double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
-    double* tab = lds + ((img_doubles<R>(a.S) + 1) & ~1);
+    double* tab = lds + ((img_doubles<R, DO>(a.S) + 1) & ~1);
     double* red = tab + QN_TANH_LDS_DOUBLES + 1;
     const int b = blockIdx.y, tid = threadIdx.x;
-    stage<R>(a, W + (int64_t)b * a.p, lds, tid, blockDim.x);
+    stage<R, DO>(a, W + (int64_t)b * a.p, lds, tid, blockDim.x);
     qn_tanh_table_stage(tab, tid, blockDim.x);
     __syncthreads();
-    const double* Wpost = lds + R * DOMAX + R + a.S * (R * R + R);
-    const double* bpost = Wpost + DOMAX * R;
+    const double* Wpost = lds + R * DO + R + a.S * (R * R + R);
+    const double* bpost = Wpost + DO * R;
     double sse = 0.0;
     for (int n = blockIdx.x * blockDim.x + tid; n < a.Nb; n += gridDim.x * blockDim.x) {
         const int64_t row = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + n] : (int64_t)n;
-        double x[DOMAX];
+        double x[DO];
 #pragma unroll
-        for (int k = 0; k < DOMAX; ++k) x[k] = k < a.d ? X[row * a.d + k] : 0.0;
+        for (int k = 0; k < DO; ++k) x[k] = k < a.d ? X[row * a.d + k] : 0.0;
         double out[R];
-        forward_row<R, false>(a, lds, tab, x, out, nullptr, 0);
+        forward_row<R, false, DO>(a, lds, tab, x, out, nullptr, 0);
 #pragma unroll
-        for (int q = 0; q < DOMAX; ++q) {
+        for (int q = 0; q < DO; ++q) {
             if (q >= a.o) break;
             double pr;
             if (a.post) {
@@ -404,8 +405,8 @@ __global__ void k_rnet_sse_final(const double* __restrict__ partial, int nblk, i
 
 int pad_r(int r) { return r <= 4 ? 4 : 8; }
 
-template <int R> size_t fwd_lds(int S) {
-    return sizeof(double) * (size_t)(((img_doubles<R>(S) + 1) & ~1) + QN_TANH_LDS_DOUBLES + 1 + 8);
+template <int R, int DO = DOMAX> size_t fwd_lds(int S) {
+    return sizeof(double) * (size_t)(((img_doubles<R, DO>(S) + 1) & ~1) + QN_TANH_LDS_DOUBLES + 1 + 8);
 }
 template <int R> size_t bwd_lds(int S, int T, int r) {
     return fwd_lds<R>(S) + sizeof(double) * (size_t)(2 * S * r + S * (r * r + r)) * T;
@@ -451,7 +452,17 @@ int run(const qn_desc* d, RnFusedArgs& a, const double* W, const double* X, cons
     double* partial = static_cast<double*>(ws);
     double* slab = reinterpret_cast<double*>(static_cast<char*>(ws) + npart);
     (void)hipGetLastError();
-    if (!grad) {
+    if (!grad && (a.d > DOMAX || a.o > DOMAX)) {
+        static bool armed = false;
+        if (!armed) {
+            QN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rnet_fwd<R, DOWIDE>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            armed = true;
+        }
+        const size_t lds_w = fwd_lds<R, DOWIDE>(a.S);
+        hipLaunchKernelGGL((k_rnet_fwd<R, DOWIDE>), dim3(a.nblk, a.B), dim3(256), lds_w, st, a, W, X, Y, row_idx, pred,
+                           partial);
+    } else if (!grad) {
         static bool armed = false;
         if (!armed) {
             QN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rnet_fwd<R>),
@@ -482,7 +493,8 @@ int run(const qn_desc* d, RnFusedArgs& a, const double* W, const double* X, cons
 
 bool qn_rnet_fused_supported(const qn_desc* d, int want_grad, int dtype) {
     if (d->kind != QN_KIND_RNET || dtype != QN_F64) return false;
-    if (d->rn_r > RMAX || d->dims[0] > DOMAX || d->dims[2] > DOMAX) return false;
+    const int dmax = want_grad ? DOMAX : DOWIDE;
+    if (d->rn_r > RMAX || d->dims[0] > dmax || d->dims[2] > dmax) return false;
     if (d->act != QN_ACT_TANH && d->act != QN_ACT_IDENTITY) return false;
     if (!want_grad) return true;
     return (pad_r(d->rn_r) == 4 ? pick_T<4>(d->rn_steps, d->rn_r) : pick_T<8>(d->rn_steps, d->rn_r)) > 0;

@@ -143,6 +143,44 @@ def test_single_launch_kernels_equal_layerwise_and_oracle(case, use_idx):
     assert np.array_equal(g3.cpu().numpy(), b[1]) and np.array_equal(s3.cpu().numpy(), b[0])
 
 
+@pytest.mark.parametrize("spec", [RNetSpec(3, 3, "poly", 0, 1, 10, layer_pre=True, layer_post=True),      # ex_ufit.py with Sine10
+                                  RNetSpec(5, 2, "nonpar", 0, 12, 7, layer_pre=True, layer_post=True),
+                                  RNetSpec(8, 1, "lin", 0, 16, 16, layer_pre=True, layer_post=True)],
+                         ids=["sine10", "d12o7", "d16o16"])
+def test_single_launch_forward_with_up_to_16_inputs_and_outputs(spec):
+    """More than 4 inputs / outputs (`Sine10`, examples/ex_ufit.py:54): the single-launch FORWARD kernel takes up to 16; the
+    gradient of such a network runs on the layer-wise kernels."""
+    from quinn_amd import _lib
+    rs = np.random.RandomState(spec.d * 31 + spec.o)
+    N, B = 210, 3
+    x = rs.uniform(-2, 2, (N, spec.d))
+    y = rs.randn(N, spec.o)
+    W = 0.4 * rs.randn(B, spec.nparams)
+    idx = rs.randint(0, N, size=(B, 64)).astype(np.int32)
+    op = BatchedMLP(MLPArch.from_module(_net_from_spec(spec)), x, y)
+    assert op.path(B, N, False) == _lib.PATH_FUSED and op.path(B, N, True) == _lib.PATH_GENERIC
+    L = _lib.lib()
+    res = {}
+    for path in (_lib.PATH_GENERIC, _lib.PATH_AUTO):
+        old = L.qn_set_path(path)
+        try:
+            s1 = op.sse(W)
+            s2, pr = op.sse_pred(W, row_idx=idx)
+        finally:
+            L.qn_set_path(old)
+        res[path] = (s1.cpu().numpy(), s2.cpu().numpy(), pr.cpu().numpy())
+    a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_AUTO]
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-12)
+    np.testing.assert_allclose(b[1], a[1], rtol=1e-12)
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-11, atol=1e-12)
+    mod = mlp_ref.build_module(spec)
+    for k in range(2):
+        np.testing.assert_allclose(b[0][k], mlp_ref.sse(mod, W[k], x, y), rtol=1e-11)
+    s, g = op.sse_grad(W)                                   # layer-wise kernels
+    ref_g = -mlp_ref.logpostgrad(mod, W[0], x, [v for v in y], 1.0) * 2.0
+    assert np.max(np.abs(g[0].cpu().numpy() - ref_g)) / np.abs(ref_g).max() < 1e-10
+
+
 def test_minibatch_rows_per_member():
     """row_idx gathers (the ensemble trainer's minibatches) on an RNet."""
     spec = RNetSpec(6, 2, "quad", 0, 2, 1, layer_pre=True, layer_post=True)
