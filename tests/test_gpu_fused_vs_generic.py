@@ -255,3 +255,47 @@ def test_wide_first_and_last_layer_in_the_fused_forward(dims):
     finally:
         L.qn_set_path(old)
     np.testing.assert_allclose(op2.sse(W).cpu().numpy(), ref, rtol=1e-12, equal_nan=True)
+
+
+def _dispatch_cases(n=120, seed=2024):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        nh = int(rs.randint(0, 5))
+        wmax = int(rs.choice([8, 20, 64, 70, 128, 200, 300]))
+        hid = tuple(int(rs.randint(1, wmax + 1)) for _ in range(nh))
+        if nh and rs.rand() < 0.4:
+            hid = (hid[0],) * nh                                     # uniform widths
+        d, o = int(rs.choice([1, 2, 3, 4, 5, 8, 12, 16, 20])), int(rs.choice([1, 2, 4, 5, 9, 16, 17]))
+        out.append(((d,) + hid + (o,), str(rs.choice(["tanh", "tanh", "relu", "identity"])), bool(rs.rand() < 0.8),
+                    int(rs.choice([1, 2, 63, 64, 65, 130, 333])), int(rs.randint(1, 5)), bool(rs.rand() < 0.3)))
+    return out
+
+
+@pytest.mark.parametrize("case", _dispatch_cases(), ids=lambda c: f"{c[0]}-{c[1]}-b{int(c[2])}-N{c[3]}-B{c[4]}-idx{int(c[5])}")
+def test_default_dispatch_equals_exact_layerwise_kernels(case):
+    """Random shapes through every dispatch rule (fused / streaming / padded twins / wide first and last layer / layer-wise):
+    the default path gives what the exact-width layer-wise kernels give."""
+    dims, act, bias, N, B, use_idx = case
+    rs = np.random.RandomState(sum(dims) * 7 + N + B)
+    arch = MLPArch(dims, act, bias)
+    x, y = rs.randn(N, dims[0]), rs.randn(N, dims[-1])
+    W = rs.randn(B, arch.nparams) / np.sqrt(max(dims))
+    idx = rs.randint(0, N, size=(B, max(1, N // 2 + 1))) if use_idx else None
+    op = BatchedMLP(arch, x, y)
+    L = _lib.lib()
+    res = {}
+    for path in (_lib.PATH_GENERIC, _lib.PATH_AUTO):
+        old = L.qn_set_path(path)
+        try:
+            s, g = op.sse_grad(W, row_idx=idx)
+            s2, pr = op.sse_pred(W, row_idx=idx)
+            s3 = op.sse(W, row_idx=idx)
+        finally:
+            L.qn_set_path(old)
+        res[path] = (s.cpu().numpy(), g.cpu().numpy(), s2.cpu().numpy(), pr.cpu().numpy(), s3.cpu().numpy())
+    a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_AUTO]
+    for k in (0, 2, 4):
+        np.testing.assert_allclose(b[k], a[k], rtol=1e-11)
+    assert np.abs(b[1] - a[1]).max() <= 1e-10 * max(np.abs(a[1]).max(), 1e-300)
+    np.testing.assert_allclose(b[3], a[3], rtol=1e-10, atol=1e-11)
