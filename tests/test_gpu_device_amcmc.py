@@ -271,28 +271,3 @@ def test_device_hmc_matches_host_hmc_in_distribution():
     se = np.sqrt(mh.var(ddof=1) / C + md.var(ddof=1) / C)
     assert abs(mh.mean() - md.mean()) < 5 * se + 0.5, (mh.mean(), md.mean(), se)
 
-
-def test_two_ranks_share_the_chains_of_the_device_engine():
-    """NN_MCMC.fit(engine='device') under two ranks (gloo collectives; both ranks on this one GPU): chains are block-
-    partitioned, keyed by their global index, gathered once at the end -- every rank holds all chains, equal to the
-    single-process run (tools/check_device_2rank.py)."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = os.path.join(root, "tools", "check_device_2rank.py")
-    env = dict(os.environ, OMP_NUM_THREADS="1")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    one = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300, env=env, check=True)
-    ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
-    port = 29600 + os.getpid() % 300
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), script],
-                         capture_output=True, text=True, timeout=300, env=env, check=True)
-    outs = [json.loads(l[l.index("{"):]) for l in two.stdout.replace("}{", "}\n{").splitlines() if "{" in l]
-    assert sorted(o["rank"] for o in outs) == [0, 1]
-    for o in outs:
-        assert o["world"] == 2 and o["chains"] == ref["chains"] == [6, 601, 321]
-        assert o["accrate"] == ref["accrate"] and o["maxpost"] == ref["maxpost"]
