@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
 """Headline benchmark: log-posterior evals/sec, 64 chains x (3x64 tanh MLP) x N=4096 per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f64|f32] [--kind logpost|grad]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--dtype f64|f32] [--kind logpost|grad]
 
 One *step* = one lock-step evaluation of the log-posterior of all 64 chains' proposals on this
 GPU (64 evals; `--kind grad`: log-posterior + parameter gradient, the HMC inner step), through
 the C ABI, with weights / dataset resident in HBM.  Successive steps use different weight
 batches (8 resident batches in rotation), nothing is cached between steps.  Chains shard over
-ranks with no data-path collective (weak scaling: 64 chains per GPU); one RCCL all_gather of
-the final log-posteriors happens after the timed region.  Rank 0 prints ONE JSON line.
+ranks with no data-path collective (`--scaling weak`, the default: 64 chains per GPU; `--scaling
+strong`: 64 chains in total, block-partitioned); one RCCL all_gather of the final log-posteriors
+happens after the timed region.  Rank 0 prints ONE JSON line.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts the N ranks itself
+(`quinn_amd.parallel.launch_ranks` = `python -m torch.distributed.run`, rendezvous on 127.0.0.1) BEFORE
+it touches the GPU and forwards their output and exit code.  Launched by an outer torchrun
+(WORLD_SIZE set) it is one of the ranks.  On a box with fewer than N GPUs the ranks share cuda:0 and
+use gloo for the collectives (a rehearsal of the launch / shard / gather logic, marked in `config`).
 """
 import argparse
 import json
@@ -118,11 +125,13 @@ def extras(op, arch, batches, args):
     return out
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: 64 chains per GPU; strong: 64 chains in total, block-partitioned over the GPUs")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--kind", default="logpost", choices=["logpost", "grad"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,11 +139,26 @@ def main():
     ap.add_argument("--path", default="auto", choices=["auto", "generic", "fused"])
     ap.add_argument("--graph", type=int, default=-1, help="capture this many consecutive steps in one HIP graph and "
                     "replay it (0 = direct launches, -1 = the largest divisor of --steps up to 50)")
-    args = ap.parse_args()
+    ap.add_argument("--spread", type=int, default=20, help="extra replays of the dominant kernel alone, after the timed "
+                    "region, for roofline.kernel_ms_min / _median / _max")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # parent of the N ranks: starts them before anything here touches the GPU, forwards output and exit code
+        from quinn_amd.parallel import launch_ranks
+        env = dict(os.environ)
+        if torch.cuda.device_count() < args.gpus:        # (counting devices does not initialise the GPU)
+            env["QN_BENCH_BACKEND"] = "gloo"            # rehearsal: the ranks share cuda:0, CPU-side collectives
+        sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, env=env))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; measuring {world} rank(s)", file=sys.stderr)
     dist = None
     # rehearsal on a 1-GPU box: QN_BENCH_BACKEND=gloo runs all ranks on cuda:0 with CPU-side collectives
     backend = os.environ.get("QN_BENCH_BACKEND", "nccl")
@@ -151,16 +175,23 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    from quinn_amd.parallel import shard_bounds
+    # this rank's chains [lo, hi) of the job's `total`; global chain id c: W[c] = 0.1*RandomState(1000+c).randn(p)
+    total = CHAINS * world if args.scaling == "weak" else CHAINS
+    lo, hi = shard_bounds(total, rank, world)
+    nloc = hi - lo
+    if nloc < 1:
+        raise SystemExit(f"rank {rank} owns no chain ({total} chains over {world} ranks)")
+
     tdt = "float64" if args.dtype == "f64" else "float32"
     arch = MLPArch(DIMS, "tanh")
     x, y = synthetic(N, DIMS[0])
     op = BatchedMLP(arch, x, y, device=dev, dtype=tdt)
-    _lib.lib().qn_set_path({"auto": 0, "generic": 1, "fused": 2}[args.path])
-    # this rank's chains: global chain id = rank*CHAINS + c; W[c] = 0.1*RandomState(1000+id).randn(p)
+    path_force = {"auto": _lib.PATH_AUTO, "generic": _lib.PATH_GENERIC, "fused": _lib.PATH_FUSED}[args.path]
+    op.set_path(path_force)
     batches = []
     for k in range(NBATCH):
-        Wk = np.stack([0.1 * np.random.RandomState(1000 + (rank * CHAINS + c) + 100003 * k).randn(arch.nparams)
-                       for c in range(CHAINS)])
+        Wk = np.stack([0.1 * np.random.RandomState(1000 + c + 100003 * k).randn(arch.nparams) for c in range(lo, hi)])
         batches.append(op.weights(Wk))
     want_grad = args.kind == "grad"
     run = (lambda W: op.sse_grad(W)) if want_grad else (lambda W: (op.sse(W), None))
@@ -177,20 +208,25 @@ def main():
         args.graph = max(g for g in range(1, 51) if args.steps % g == 0)
         if args.graph == 1:
             args.graph = 0
-    if args.graph:
-        # G consecutive steps (rotating over the resident weight batches) captured once and replayed
-        assert args.steps % args.graph == 0
+
+    def capture(fn, nsteps):
+        """nsteps consecutive steps (rotating over the resident weight batches) captured once in a HIP graph."""
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for i in range(NBATCH):
-                out = run(batches[i])
+                res_ = fn(batches[i])
         torch.cuda.current_stream(dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for i in range(args.graph):
-                out = run(batches[i % NBATCH])
-        graph.replay()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(nsteps):
+                res_ = fn(batches[i % NBATCH])
+        g.replay()
+        return g, res_
+
+    if args.graph:
+        assert args.steps % args.graph == 0
+        graph, out = capture(run, args.graph)
     barrier()
     nlaunch = args.steps // args.graph if args.graph else args.steps
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlaunch)]
@@ -207,73 +243,79 @@ def main():
             ev[i][1].record()
     barrier()
     el = time.perf_counter() - t0
-    # device time per step (one launch group = forward kernel + partial-sum kernel)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / (args.graph if args.graph else 1)
+    # device time per step (one launch group = forward kernel + partial-sum kernel), HIP events on the launch stream
+    per = args.graph if args.graph else 1
+    step_dev_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / per
     lp_last = -neg_log_post_from_sse(out[0].cpu().numpy(), N, SIGMA)
     assert np.all(np.isfinite(lp_last))
-    step_dev_ms = kern_ms
-    if not want_grad and rank == 0 and op.sse_parts(batches[0]).shape[1] > 1:
-        # the dominant kernel ALONE (what rocprofv3 reports for it): the forward without the 64-thread kernel that
-        # adds the 8 row-split partial sums of a chain (qn_mlp_sse_fwd_parts), same graph / event scheme as above
+
+    # the dominant kernel ALONE (what rocprofv3 reports for it): for the log-posterior the forward without the
+    # 64-thread kernel that adds the row-split partial sums of a chain (qn_mlp_sse_fwd_parts); replayed
+    # max(nlaunch, --spread) times AFTER the timed region, one event pair per replay -> mean and spread
+    kern = {"kernel_ms": step_dev_ms}
+    if rank == 0:
+        alone = (lambda W: op.sse_parts(W)) if (not want_grad and op.sse_parts(batches[0]).shape[1] > 1) else run
         g2n = args.graph if args.graph else 1
-        g2 = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            op.sse_parts(batches[0])
-        torch.cuda.current_stream(dev).wait_stream(side)
-        with torch.cuda.graph(g2):
-            for i in range(g2n):
-                parts = op.sse_parts(batches[i % NBATCH])
-        g2.replay()
+        g2, _ = capture(alone, g2n)
         torch.cuda.synchronize(dev)
-        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlaunch)]
+        nrep = max(nlaunch, args.spread)
+        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nrep)]
         for a_, b_ in ev2:
             a_.record()
             g2.replay()
             b_.record()
         torch.cuda.synchronize(dev)
-        kern_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev2])) / g2n
+        ms = np.array([a_.elapsed_time(b_) for a_, b_ in ev2]) / g2n
+        kern = {"kernel_ms": float(ms.mean()), "kernel_ms_min": float(ms.min()), "kernel_ms_median": float(np.median(ms)),
+                "kernel_ms_max": float(ms.max()), "kernel_ms_samples": int(nrep), "kernel_steps_per_sample": int(g2n)}
 
     t_max = el
     if dist is not None:
         t = torch.tensor([el], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_max = float(t.item())
-        gathered = [torch.empty(CHAINS, device=cdev, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(gathered, out[0].to(cdev))        # the single end-of-run collective (RCCL)
+        # the single end-of-run collective (RCCL): every rank's final log-posteriors, padded to the largest shard
+        nmax = -(-total // world)
+        send = torch.zeros(nmax, device=cdev, dtype=torch.float64)
+        send[:nloc] = out[0].to(cdev)
+        gathered = torch.empty(world * nmax, device=cdev, dtype=torch.float64)
+        dist.all_gather_into_tensor(gathered, send)
         torch.cuda.synchronize(dev)
-        assert all(torch.isfinite(gth).all() for gth in gathered)
+        assert torch.isfinite(gathered).all()
 
     if rank == 0:
-        evals = CHAINS * args.steps * world
+        evals = total * args.steps
         value = evals / t_max
         flops = arch.flops_fwdbwd(N) if want_grad else arch.flops_fwd(N)
-        ach = CHAINS * flops / (kern_ms * 1e-3) / 1e12
+        ach = nloc * flops / (kern["kernel_ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
-        path = op.path(CHAINS, N, want_grad)
+        path = op.path(nloc, N, want_grad)
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and nloc == CHAINS:
             # HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
             # correction, + WRITE_SIZE), recorded by tools/prof_traffic.sh for this kernel / config
             key = f"{args.kind}_{args.dtype}_{ {1: 'generic', 2: 'fused'}.get(path) }"
             traffic = json.load(open(tfile)).get(key, {}).get("hbm_bytes_per_launch")
+        per_gpu = f"{CHAINS} AMCMC chains/GPU" if args.scaling == "weak" else f"{CHAINS} AMCMC chains in total ({nloc} on rank 0)"
+        cfg = {"workload": f"configs[1]: {per_gpu}, 3x64 tanh MLP (p=8513), N=4096 1-D regression; step = batched "
+                           + ("log-posterior+gradient" if want_grad else "log-posterior") + " of all chains",
+               "chains_total": total, "chains_rank0": nloc, "N": N, "dims": list(DIMS),
+               "kind": args.kind, "kernel_path": {1: "generic", 2: "fused"}.get(path, str(path)),
+               "launch": (f"HIP graph of {args.graph} steps, replayed {args.steps // args.graph}x" if args.graph
+                          else "direct launches"),
+               "parallelism": f"chains sharded x{world}, no data-path collective, one all_gather at the end"}
+        if backend != "nccl" and world > 1:
+            cfg["rehearsal"] = f"{world} ranks share cuda:0 of a {torch.cuda.device_count()}-GPU box, {backend} collectives"
         res = {
             "metric": "log-posterior evals/sec (64 chains, 3x64 MLP, N=4096) at 1/2/4/8 GPU",
             "value": value, "unit": "log-posterior evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: 64 AMCMC chains/GPU, 3x64 tanh MLP (p=8513), N=4096 1-D "
-                                   "regression; step = batched " + ("log-posterior+gradient" if want_grad else "log-posterior")
-                                   + " of all 64 chains", "chains_per_gpu": CHAINS, "N": N, "dims": list(DIMS),
-                       "kind": args.kind, "kernel_path": {1: "generic", 2: "fused"}.get(path, str(path)),
-                       "launch": (f"HIP graph of {args.graph} steps, replayed {args.steps // args.graph}x" if args.graph
-                                  else "direct launches"),
-                       "parallelism": f"chains sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": traffic, "flops_per_eval": flops, "evals_per_launch": CHAINS,
-                         "kernel_ms": kern_ms, "step_device_ms": step_dev_ms},
+            "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": cfg,
+            "roofline": dict({"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                              "traffic": traffic, "flops_per_eval": flops, "evals_per_launch": nloc,
+                              "step_device_ms": step_dev_ms}, **kern),
         }
         if world == 1 and not args.no_extras:
             res["extras"] = extras(op, arch, batches, args)

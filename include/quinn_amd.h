@@ -31,7 +31,7 @@ extern "C" {
 enum { QN_F64 = 0, QN_F32 = 1 };
 enum { QN_ACT_IDENTITY = 0, QN_ACT_TANH = 1, QN_ACT_RELU = 2 };
 enum { QN_OK = 0, QN_EINVAL = -1, QN_EWORKSPACE = -2, QN_EHIP = -3, QN_EUNSUPPORTED = -4 };
-/* kernel families, for qn_set_path (tests / profiling) */
+/* kernel families, for qn_mlp_desc_set_path (tests / profiling) */
 enum { QN_PATH_AUTO = 0, QN_PATH_GENERIC = 1, QN_PATH_FUSED = 2 };
 
 typedef struct qn_desc qn_desc;
@@ -61,10 +61,12 @@ size_t qn_workspace_bytes(const qn_desc* desc, int B, int Nb, int want_grad, int
 
 /* Which kernel family the next call with these sizes would run (QN_PATH_GENERIC/FUSED). */
 int qn_mlp_path(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
-/* Force a kernel family (QN_PATH_AUTO restores dispatch). Returns the previous setting.  QN_PATH_GENERIC is the
- * layer-wise family at the EXACT layer widths; under QN_PATH_AUTO hidden widths that are no multiples of 64 run on a
- * zero-padded twin of the network (padded units stay exactly 0, results equal the unpadded network's). */
-int qn_set_path(int path);
+/* Force a kernel family for the calls made with THIS descriptor (QN_PATH_AUTO restores dispatch by shape).  Returns
+ * the previous setting.  There is no process-wide state: two operators in one process do not see each other's
+ * choice.  QN_PATH_GENERIC is the layer-wise family at the EXACT layer widths; under QN_PATH_AUTO hidden widths that
+ * are no multiples of 64 run on a zero-padded twin of the network (padded units stay exactly 0, results equal the
+ * unpadded network's). */
+int qn_mlp_desc_set_path(qn_desc* desc, int path);
 
 /* sse_out[b] = sum_{n,o} (Y[r(b,n),o] - f_{W[b]}(X[r(b,n),:])[o])^2 for b < B.
  * Replaces the per-weight-vector loop over NN_MCMC.logpost -> NNWrap.calc_loss ->

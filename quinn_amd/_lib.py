@@ -19,7 +19,7 @@ PATH_AUTO, PATH_GENERIC, PATH_FUSED = 0, 1, 2
 
 # every symbol include/quinn_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = ["qn_mlp_desc_create", "qn_rnet_desc_create", "qn_mlp_desc_destroy", "qn_mlp_num_params", "qn_workspace_bytes",
-           "qn_mlp_path", "qn_set_path", "qn_mlp_sse_fwd", "qn_mlp_sse_parts", "qn_mlp_sse_fwd_parts", "qn_mlp_sse_fwdbwd", "qn_vi_sample_kl",
+           "qn_mlp_path", "qn_mlp_desc_set_path", "qn_mlp_sse_fwd", "qn_mlp_sse_parts", "qn_mlp_sse_fwd_parts", "qn_mlp_sse_fwdbwd", "qn_vi_sample_kl",
            "qn_vi_grad", "qn_adam_batched", "qn_mcmc_propose", "qn_mcmc_propose_hist", "qn_mcmc_hist_block_steps", "qn_mcmc_propose_hist_block",
            "qn_mcmc_apply_delta", "qn_mcmc_accept", "qn_mcmc_accept_propose", "qn_debug_tanh", "qn_debug_tanh_finite", "qn_debug_tanh_table", "qn_last_error",
            "qn_version"]
@@ -80,8 +80,8 @@ def lib():
     L.qn_workspace_bytes.restype = sz
     L.qn_mlp_path.argtypes = [vp, i32, i32, i32, i32]
     L.qn_mlp_path.restype = i32
-    L.qn_set_path.argtypes = [i32]
-    L.qn_set_path.restype = i32
+    L.qn_mlp_desc_set_path.argtypes = [vp, i32]
+    L.qn_mlp_desc_set_path.restype = i32
     L.qn_mlp_sse_fwd.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, sz, vp]
     L.qn_mlp_sse_fwd.restype = i32
     L.qn_mlp_sse_parts.argtypes = [vp, i32, i32, i32]

@@ -2,12 +2,10 @@
 // families, and the small elementwise kernels of the VI / ensemble trainers.
 #include "qn_common.h"
 #include "qn_math.h"
-#include <atomic>
 #include <cmath>
 #include <cstring>
 
 static thread_local char g_err[512] = "";
-static std::atomic<int> g_forced_path{QN_PATH_AUTO};
 
 void qn_set_error(const char* fmt, ...) {
     va_list ap;
@@ -15,13 +13,13 @@ void qn_set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-int qn_forced_path() { return g_forced_path.load(); }
 
 extern "C" const char* qn_last_error(void) { return g_err; }
 extern "C" const char* qn_version(void) { return "quinn_amd 0.1 gfx950"; }
-extern "C" int qn_set_path(int path) {
-    const int old = g_forced_path.load();
-    if (path == QN_PATH_AUTO || path == QN_PATH_GENERIC || path == QN_PATH_FUSED) g_forced_path.store(path);
+extern "C" int qn_mlp_desc_set_path(qn_desc* d, int path) {
+    if (!d) return QN_EINVAL;
+    const int old = d->path;
+    if (path == QN_PATH_AUTO || path == QN_PATH_GENERIC || path == QN_PATH_FUSED) d->path = path;
     return old;
 }
 
@@ -147,7 +145,7 @@ static bool fused_ok(const qn_desc* d, int B, int Nb, int want_grad, int dtype) 
     return d->kind == QN_KIND_MLP && qn_fused_supported(fused_desc(d), B, Nb, want_grad, dtype);
 }
 static bool use_fused(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
-    if (g_forced_path.load() == QN_PATH_GENERIC) return false;
+    if (d->path == QN_PATH_GENERIC) return false;
     return fused_ok(d, B, Nb, want_grad, dtype);
 }
 static size_t fused_ws(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
@@ -160,7 +158,7 @@ static size_t fused_ws(const qn_desc* d, int B, int Nb, int want_grad, int dtype
 // gradients): MFMA GEMMs instead of VALU kernels.  Not under a forced path: QN_PATH_GENERIC stays the exact-width
 // reference the tests compare against.
 static bool use_padded_generic(const qn_desc* d) {
-    if (d->kind != QN_KIND_MLP || !d->padded || d->padded->dims[1] < 64 || g_forced_path.load() != QN_PATH_AUTO) return false;
+    if (d->kind != QN_KIND_MLP || !d->padded || d->padded->dims[1] < 64 || d->path != QN_PATH_AUTO) return false;
     int hmax = 0;
     for (int l = 1; l < d->nlayers; ++l) hmax = d->dims[l] > hmax ? d->dims[l] : hmax;
     return hmax >= 48;      // measured: 50 -> 64 wins 1.4-2.6x, 40 -> 64 ties, 33 -> 64 loses 30 % against the exact VALU kernels
@@ -260,7 +258,7 @@ int run_padded(const qn_desc* d, bool generic, int dtype, const void* W, const v
 }  // namespace
 
 static bool use_rnet_fused(const qn_desc* d, int want_grad, int dtype) {
-    return d->kind == QN_KIND_RNET && g_forced_path.load() != QN_PATH_GENERIC && qn_rnet_fused_supported(d, want_grad, dtype);
+    return d->kind == QN_KIND_RNET && d->path != QN_PATH_GENERIC && qn_rnet_fused_supported(d, want_grad, dtype);
 }
 
 extern "C" int qn_mlp_path(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
@@ -271,15 +269,15 @@ extern "C" int qn_mlp_path(const qn_desc* d, int B, int Nb, int want_grad, int d
 
 extern "C" size_t qn_workspace_bytes(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
     if (!d || B <= 0 || Nb <= 0) return 0;
-    if (d->kind == QN_KIND_RNET) {      // sized for either family so that qn_set_path never invalidates a caller's buffer
+    if (d->kind == QN_KIND_RNET) {      // sized for either family so that qn_mlp_desc_set_path never invalidates a caller's buffer
         const size_t g = qn_rnet_workspace(d, B, Nb, want_grad, dtype);
         const size_t f = qn_rnet_fused_supported(d, want_grad, dtype) ? qn_rnet_fused_workspace(d, B, Nb, want_grad) : 0;
         return g > f ? g : f;
     }
-    // sized for either family so that qn_set_path never invalidates a caller's buffer
+    // sized for either family so that qn_mlp_desc_set_path never invalidates a caller's buffer
     size_t g = qn_generic_workspace(d, B, Nb, want_grad, dtype);
     size_t f = fused_ok(d, B, Nb, want_grad, dtype) ? fused_ws(d, B, Nb, want_grad, dtype) : 0;
-    if (g_forced_path.load() == QN_PATH_AUTO && f) return f;
+    if (d->path == QN_PATH_AUTO && f) return f;
     if (use_padded_generic(d)) {
         const size_t pg = padded_generic_ws(d, B, Nb, want_grad, dtype);
         g = pg > g ? pg : g;
@@ -316,7 +314,7 @@ static int run(const char* fn, const qn_desc* d, int dtype, const void* W, const
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int want_grad = gradW != nullptr;
     if (d->kind == QN_KIND_RNET) {
-        if (g_forced_path.load() == QN_PATH_FUSED && !qn_rnet_fused_supported(d, want_grad, dtype)) {
+        if (d->path == QN_PATH_FUSED && !qn_rnet_fused_supported(d, want_grad, dtype)) {
             qn_set_error("%s: fused path forced but not supported for this residual network", fn);
             return QN_EUNSUPPORTED;
         }
@@ -324,7 +322,7 @@ static int run(const char* fn, const qn_desc* d, int dtype, const void* W, const
             return qn_rnet_fused_run(d, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
         return qn_rnet_run(d, dtype, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
     }
-    if (g_forced_path.load() == QN_PATH_FUSED && !fused_ok(d, B, Nb, want_grad, dtype)) {
+    if (d->path == QN_PATH_FUSED && !fused_ok(d, B, Nb, want_grad, dtype)) {
         qn_set_error("%s: fused path forced but not supported for this shape", fn);
         return QN_EUNSUPPORTED;
     }

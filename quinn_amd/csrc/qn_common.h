@@ -26,11 +26,12 @@ struct qn_desc {
     // ---- MLP whose hidden widths are <= 64 but not all equal to 16 / 32 / 64: the same network with every hidden
     // layer zero-padded to one of those widths, which the fused kernels take (qn_api.hip: pad -> fused -> unpad)
     qn_desc* padded;
+    // ---- kernel family forced on this descriptor (qn_mlp_desc_set_path; QN_PATH_AUTO = dispatch by shape)
+    int path;
 };
 enum { QN_KIND_MLP = 0, QN_KIND_RNET = 1 };
 
 void qn_set_error(const char* fmt, ...);
-int qn_forced_path();
 
 #define QN_HIP_CHECK(expr)                                                          \
     do {                                                                            \

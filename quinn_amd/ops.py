@@ -278,6 +278,11 @@ class BatchedMLP:
     def path(self, B, Nb=None, want_grad=False):
         return int(self._L.qn_mlp_path(self._desc, B, Nb or self.N, int(want_grad), self.qdt))
 
+    def set_path(self, path):
+        """Force a kernel family for THIS operator (`_lib.PATH_AUTO` / `PATH_GENERIC` / `PATH_FUSED`; tests and
+        profiling); returns the previous setting.  Per descriptor: other operators are unaffected."""
+        return int(self._L.qn_mlp_desc_set_path(self._desc, int(path)))
+
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None

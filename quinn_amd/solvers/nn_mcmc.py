@@ -19,7 +19,7 @@ from ..mcmc.admcmc import AMCMC
 from ..mcmc.hmc import HMC
 from ..mcmc.mala import MALA
 from ..ops import BatchedMLP, neg_log_post_from_sse
-from ..parallel import all_gather_rows, dist_info, run_chains_sharded, shard_bounds
+from ..parallel import dist_info, empty_results, gather_results, run_chains_sharded, shard_bounds
 from .quinn import QUiNNBase
 
 
@@ -84,7 +84,7 @@ class NN_MCMC(QUiNNBase):
 
     # -- fit -------------------------------------------------------------------------------
     def fit(self, xtrn, ytrn, zflag=True, datanoise=0.05, nmcmc=6000, param_ini=None, sampler='amcmc',
-            sampler_params=None, *, nchains=1, seeds=None, engine='host'):
+            sampler_params=None, *, nchains=1, seeds=None, engine='host', gather='all'):
         """Run MCMC over the flat weight vector.
 
         Args (reference): xtrn `(N,d)`, ytrn `(N,o)`, zflag (BFGS pre-fit of a random start),
@@ -96,6 +96,10 @@ class NN_MCMC(QUiNNBase):
             engine='device' (samplers 'amcmc' and 'hmc'): states, proposal factors and history stay on the
             GPU, no host synchronisation per step (`quinn_amd.mcmc.device_amcmc`); same target and
             adaptation schedule, chains equal the host engine in distribution, not bit for bit.
+            gather (multi-rank runs; chains are block-partitioned over the ranks): 'all' -- every rank ends with all
+            chains (one all_gather of the result arrays, from the device buffers in bounded pieces); 'root' -- rank 0
+            does, the other ranks keep their own shard; 'none' -- no communication at all.  A gather whose result
+            exceeds `quinn_amd.parallel.DEFAULT_MAX_GATHER_BYTES` raises MemoryError before any traffic.
         """
         ntrn_, outdim = ytrn.shape
         assert xtrn.shape[0] == ntrn_
@@ -143,13 +147,10 @@ class NN_MCMC(QUiNNBase):
                 raise ValueError("engine='device' is implemented for sampler='amcmc' and 'hmc'")
             if hi > lo:
                 res = eng.run(nmcmc, ini2[lo:hi], verbose=self.verbose and rank == 0)
-                res = {k: v.cpu().numpy() for k, v in res.items()}
             else:
-                p_ = ini2.shape[1]
-                res = {'chain': np.zeros((0, nmcmc + 1, p_)), 'mapparams': np.zeros((0, p_)), 'maxpost': np.zeros(0),
-                       'accrate': np.zeros(0), 'logpost': np.zeros((0, nmcmc + 1)), 'alphas': np.zeros((0, nmcmc + 1))}
-            if world > 1:                                                  # the single collective, at the end
-                res = {k: all_gather_rows(v, ctot) for k, v in res.items()}
+                res = empty_results(nmcmc, ini2.shape[1])
+            # the single collective, at the end, straight from the device tensors (world == 1: a device->host copy)
+            res = gather_results(res, ctot, gather)
             self.mcmc_results = res
             if np.ndim(param_ini) == 1:
                 self.mcmc_results = {k: v[0] for k, v in self.mcmc_results.items()}
@@ -169,7 +170,7 @@ class NN_MCMC(QUiNNBase):
 
         if rngs is not None and dist_info()[1] > 1:
             # chains shard over ranks; one all_gather of the result arrays at the end
-            self.mcmc_results = run_chains_sharded(lambda: mymcmc, nmcmc, param_ini, seeds, verbose=False)
+            self.mcmc_results = run_chains_sharded(lambda: mymcmc, nmcmc, param_ini, seeds, verbose=False, gather=gather)
         else:
             self.mcmc_results = mymcmc.run(nmcmc=nmcmc, param_ini=param_ini, rngs=rngs, verbose=self.verbose)
         self.samples, self.cmode = self.mcmc_results['chain'], self.mcmc_results['mapparams']

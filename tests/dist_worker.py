@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_golden, spec_of, assert_chain_matches_fixture  # noqa: E402
 from oracle import mlp_ref  # noqa: E402
 from quinn_amd.mcmc.admcmc import AMCMC  # noqa: E402
-from quinn_amd.parallel import all_gather_rows, run_chains_sharded, shard_bounds  # noqa: E402
+from quinn_amd.parallel import all_gather_rows, gather_bytes, gather_rows, run_chains_sharded, shard_bounds  # noqa: E402
 
 
 def main():
@@ -29,6 +29,21 @@ def main():
     full = all_gather_rows(local, n)
     assert full.shape == (5, 3) and np.array_equal(full[:, 0], np.arange(5.0)), full
     assert [shard_bounds(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+    # 1b. the same from a torch tensor, in pieces much smaller than a shard (7 elements per piece), every gather mode
+    big = torch.arange(lo * 11, hi * 11, dtype=torch.float64).reshape(hi - lo, 11)
+    want = np.arange(5 * 11, dtype=np.float64).reshape(5, 11)
+    assert np.array_equal(gather_rows(big, n, dst="all", chunk_bytes=56), want)
+    at_root = gather_rows(big, n, dst="root", chunk_bytes=56)
+    assert np.array_equal(at_root, want if rank == 0 else want[lo:hi])
+    assert np.array_equal(gather_rows(big, n, dst="none"), want[lo:hi])
+    ints = gather_rows(torch.arange(lo, hi, dtype=torch.int64), n, dst="all", chunk_bytes=8)
+    assert ints.dtype == np.int64 and np.array_equal(ints, np.arange(5))
+    try:                                                    # the size guard trips on every rank before any traffic
+        gather_rows(big, n, dst="all", max_bytes=100)
+        raise AssertionError("no MemoryError")
+    except MemoryError as err:
+        assert "gather='root'" in str(err)
+    assert gather_bytes((11,), 8, 5, world=2, dst="all") == (3 * 88, 2 * 3 * 88, 5 * 88)
     # 2. sharded chains == fixture == single-process lock-step
     g = load_golden("g8_multichain.npz")
     spec = spec_of(g)
@@ -59,6 +74,14 @@ def main():
     assert one.shape == (1, 2) and (one == 7.0).all()
     res1 = run_chains_sharded(make, 25, None, seeds[:1])
     assert res1["chain"].shape == (1, 26, spec.nparams)
+    # 4. gather='root': rank 0 holds every chain, rank 1 its own shard; 'none': shards only
+    resr = run_chains_sharded(make, 25, None, seeds[:3], gather="root")
+    assert resr["chain"].shape[0] == (3 if rank == 0 else 1)
+    resn = run_chains_sharded(make, 25, None, seeds[:3], gather="none")
+    lo3, hi3 = shard_bounds(3)
+    assert resn["chain"].shape[0] == hi3 - lo3
+    if rank == 0:
+        assert np.array_equal(resr["chain"][lo3:hi3], resn["chain"])
     np.testing.assert_allclose(res1["chain"][0], g["chain"][0][:26], rtol=1e-9, atol=1e-11)
     dist.barrier()
     with open(os.path.join(os.environ["QN_DIST_OUT"], f"ok_{rank}"), "w") as f:

@@ -52,12 +52,12 @@ def test_fused_equals_generic(case):
     L = _lib.lib()
     res = {}
     for path in (_lib.PATH_GENERIC, _lib.PATH_FUSED):
-        old = L.qn_set_path(path)
+        old = op.set_path(path)
         try:
             s, g = op.sse_grad(W, row_idx=idx)
             s2, pr = op.sse_pred(W, row_idx=idx)
         finally:
-            L.qn_set_path(old)
+            op.set_path(old)
         res[path] = (s.cpu().numpy(), g.cpu().numpy(), s2.cpu().numpy(), pr.cpu().numpy())
     a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_FUSED]
     np.testing.assert_allclose(b[0], a[0], rtol=1e-12)
@@ -94,12 +94,12 @@ def test_streaming_forward_equals_generic(case):
     assert op.path(B, Nb, True) == _lib.PATH_GENERIC
     res = {}
     for path in (_lib.PATH_GENERIC, _lib.PATH_FUSED):
-        old = L.qn_set_path(path)
+        old = op.set_path(path)
         try:
             s = op.sse(W, row_idx=idx)
             s2, pr = op.sse_pred(W, row_idx=idx)
         finally:
-            L.qn_set_path(old)
+            op.set_path(old)
         res[path] = (s.cpu().numpy(), s2.cpu().numpy(), pr.cpu().numpy())
     a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_FUSED]
     np.testing.assert_allclose(b[0], a[0], rtol=1e-12)
@@ -109,11 +109,11 @@ def test_streaming_forward_equals_generic(case):
     if act == "tanh" and len(dims) > 3:
         W2 = W.copy()
         W2[0, arch.nparams // 2] = np.inf
-        old = L.qn_set_path(_lib.PATH_GENERIC)
+        old = op.set_path(_lib.PATH_GENERIC)
         try:
             ref = op.sse(W2, row_idx=idx).cpu().numpy()
         finally:
-            L.qn_set_path(old)
+            op.set_path(old)
         got = op.sse(W2, row_idx=idx).cpu().numpy()
         np.testing.assert_allclose(got, ref, rtol=1e-12, equal_nan=True)
 
@@ -134,12 +134,12 @@ def test_wide_ragged_widths_run_on_the_padded_twin(dims, dtype):
     L = _lib.lib()
     res = {}
     for path in (_lib.PATH_GENERIC, _lib.PATH_AUTO):
-        old = L.qn_set_path(path)
+        old = op.set_path(path)
         try:
             s, g = op.sse_grad(W)
             s2, pr = op.sse_pred(W, row_idx=idx)
         finally:
-            L.qn_set_path(old)
+            op.set_path(old)
         res[path] = (s.cpu().numpy(), g.double().cpu().numpy(), s2.cpu().numpy(), pr.double().cpu().numpy())
     a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_AUTO]
     rt, gt = (1e-11, 1e-10) if dtype == "float64" else (2e-4, 2e-3)
@@ -172,7 +172,7 @@ def test_non_finite_inputs_follow_the_reference(where, grad):
     op = BatchedMLP(arch, x, y)
     out = {}
     for path in (_lib.PATH_GENERIC, _lib.PATH_FUSED):
-        old = _lib.lib().qn_set_path(path)
+        old = op.set_path(path)
         try:
             if grad:
                 s, g = op.sse_grad(W)
@@ -181,7 +181,7 @@ def test_non_finite_inputs_follow_the_reference(where, grad):
                 s, pr = op.sse_pred(W)
                 out[path] = (s.cpu().numpy(), pr.cpu().numpy())
         finally:
-            _lib.lib().qn_set_path(old)
+            op.set_path(old)
     sg, ag = out[_lib.PATH_GENERIC]
     sf, af = out[_lib.PATH_FUSED]
     assert np.array_equal(np.isnan(sg), np.isnan(sf))
@@ -235,12 +235,12 @@ def test_wide_first_and_last_layer_in_the_fused_forward(dims):
     L = _lib.lib()
     res = {}
     for path in (_lib.PATH_GENERIC, _lib.PATH_AUTO):
-        old = L.qn_set_path(path)
+        old = op.set_path(path)
         try:
             s1 = op.sse(W)
             s2, pr = op.sse_pred(W, row_idx=idx)
         finally:
-            L.qn_set_path(old)
+            op.set_path(old)
         res[path] = (s1.cpu().numpy(), s2.cpu().numpy(), pr.cpu().numpy())
     a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_AUTO]
     np.testing.assert_allclose(b[0], a[0], rtol=1e-12)
@@ -249,11 +249,11 @@ def test_wide_first_and_last_layer_in_the_fused_forward(dims):
     # non-finite input in a late column of x: NaN-propagating tanh, same result as the layer-wise path
     x2 = x.copy(); x2[5, dims[0] - 1] = np.nan
     op2 = BatchedMLP(arch, x2, y)
-    old = L.qn_set_path(_lib.PATH_GENERIC)
+    old = op2.set_path(_lib.PATH_GENERIC)
     try:
         ref = op2.sse(W).cpu().numpy()
     finally:
-        L.qn_set_path(old)
+        op2.set_path(old)
     np.testing.assert_allclose(op2.sse(W).cpu().numpy(), ref, rtol=1e-12, equal_nan=True)
 
 
@@ -286,13 +286,13 @@ def test_default_dispatch_equals_exact_layerwise_kernels(case):
     L = _lib.lib()
     res = {}
     for path in (_lib.PATH_GENERIC, _lib.PATH_AUTO):
-        old = L.qn_set_path(path)
+        old = op.set_path(path)
         try:
             s, g = op.sse_grad(W, row_idx=idx)
             s2, pr = op.sse_pred(W, row_idx=idx)
             s3 = op.sse(W, row_idx=idx)
         finally:
-            L.qn_set_path(old)
+            op.set_path(old)
         res[path] = (s.cpu().numpy(), g.cpu().numpy(), s2.cpu().numpy(), pr.cpu().numpy(), s3.cpu().numpy())
     a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_AUTO]
     for k in (0, 2, 4):

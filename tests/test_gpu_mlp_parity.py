@@ -19,22 +19,22 @@ def paths_for(op, B, Nb, grad):
     """Kernel families to test for this shape: generic always, fused when supported."""
     L = _lib.lib()
     out = [_lib.PATH_GENERIC]
-    old = L.qn_set_path(_lib.PATH_AUTO)
+    old = op.set_path(_lib.PATH_AUTO)
     if op.path(B, Nb, grad) == _lib.PATH_FUSED:
         out.append(_lib.PATH_FUSED)
-    L.qn_set_path(old)
+    op.set_path(old)
     return out
 
 
 class forced:
-    def __init__(self, path):
-        self.path = path
+    def __init__(self, op, path):
+        self.op, self.path = op, path
 
     def __enter__(self):
-        self.old = _lib.lib().qn_set_path(self.path)
+        self.old = self.op.set_path(self.path)
 
     def __exit__(self, *a):
-        _lib.lib().qn_set_path(self.old)
+        self.op.set_path(self.old)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -47,7 +47,7 @@ def test_g1_golden_logpost_grad_pred(ci, dtype):
     rt, gt = TOL[dtype]
     n, sigma = g["x"].shape[0], float(g["sigma"])
     for path in paths_for(op, 8, n, True):
-        with forced(path):
+        with forced(op, path):
             sse, grad = op.sse_grad(g["W"])
             sse2, pred = op.sse_pred(g["W"])
         lp = -neg_log_post_from_sse(sse.cpu().numpy(), n, sigma)
@@ -90,7 +90,7 @@ def test_random_shapes_vs_oracle(case, dtype):
     ref_lp = np.array([mlp_ref.logpost(mod, w, x, yd, 0.5) for w in W])
     ref_g = np.array([mlp_ref.logpostgrad(mod, w, x, yd, 0.5) for w in W])
     for path in paths_for(op, B, N, True):
-        with forced(path):
+        with forced(op, path):
             sse, grad = op.sse_grad(W)
             sse_f = op.sse(W)
         np.testing.assert_allclose(sse_f.cpu().numpy(), sse.cpu().numpy(), rtol=rt)
@@ -115,7 +115,7 @@ def test_row_idx_minibatches(dtype):
     op = BatchedMLP(arch, x, y, dtype=dtype)
     rt, gt = TOL[dtype]
     for path in paths_for(op, B, Nb, True):
-        with forced(path):
+        with forced(op, path):
             sse, grad = op.sse_grad(W, row_idx=idx)
         for b in range(B):
             xb, yb = x[idx[b]], y[idx[b]]

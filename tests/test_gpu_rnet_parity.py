@@ -120,12 +120,12 @@ def test_single_launch_kernels_equal_layerwise_and_oracle(case, use_idx):
     assert op.path(B, N, True) == _lib.PATH_FUSED
     res = {}
     for path in (_lib.PATH_GENERIC, _lib.PATH_FUSED):
-        old = L.qn_set_path(path)
+        old = op.set_path(path)
         try:
             s, g = op.sse_grad(W, row_idx=idx)
             s2, pr = op.sse_pred(W, row_idx=idx)
         finally:
-            L.qn_set_path(old)
+            op.set_path(old)
         res[path] = (s.cpu().numpy(), g.cpu().numpy(), s2.cpu().numpy(), pr.cpu().numpy())
     a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_FUSED]
     np.testing.assert_allclose(b[0], a[0], rtol=1e-12)
@@ -162,12 +162,12 @@ def test_single_launch_forward_with_up_to_16_inputs_and_outputs(spec):
     L = _lib.lib()
     res = {}
     for path in (_lib.PATH_GENERIC, _lib.PATH_AUTO):
-        old = L.qn_set_path(path)
+        old = op.set_path(path)
         try:
             s1 = op.sse(W)
             s2, pr = op.sse_pred(W, row_idx=idx)
         finally:
-            L.qn_set_path(old)
+            op.set_path(old)
         res[path] = (s1.cpu().numpy(), s2.cpu().numpy(), pr.cpu().numpy())
     a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_AUTO]
     np.testing.assert_allclose(b[0], a[0], rtol=1e-12)

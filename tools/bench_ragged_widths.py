@@ -19,12 +19,12 @@ for dims in [(1, 11, 11, 11, 1), (1, 50, 50, 50, 1), (1, 20, 40, 10, 1), (1, 64,
     W = op.weights(0.1 * rs.randn(B, arch.nparams))
     r = {}
     for name, path in (("generic", _lib.PATH_GENERIC), ("auto", _lib.PATH_AUTO)):
-        old = _lib.lib().qn_set_path(path)
+        old = op.set_path(path)
         try:
             r[name + "_fwd_evals_per_s"] = B / timeit(lambda: op.sse(W), 30)
             r[name + "_grad_evals_per_s"] = B / timeit(lambda: op.sse_grad(W), 20)
             r[name + "_path"] = op.path(B, N, False)
         finally:
-            _lib.lib().qn_set_path(old)
+            op.set_path(old)
     out[str(dims)] = r
 print(json.dumps(out, indent=1))
