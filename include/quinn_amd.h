@@ -215,6 +215,33 @@ int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap, const int3
 int qn_mcmc_apply_delta(const double* cur, const double* delta, int t, double s_iso, int C, int chain0, int64_t p,
                         uint64_t seed, const int64_t* step_ptr, double* out, void* stream);
 
+/* Device-resident Hamiltonian Monte Carlo step (throughput engine of quinn/mcmc/hmc.py:43-66 + the accept block of
+ * quinn/mcmc/mcmc.py:65-85): three elementwise kernels around qn_mlp_sse_fwdbwd, no host synchronisation, every launch
+ * static given the step parity (a pair of steps is capturable as one HIP graph).  All state is float64 [C, p]; the
+ * gradient arrays hold d SSE / d W as qn_mlp_sse_fwdbwd writes it (d logpost = -0.5/sigma^2 * d SSE is applied here).
+ *
+ * qn_hmc_begin (hmc.py:43-51): momentum z ~ N(0, I) -- Philox4x32-10 keyed by (seed, step, GLOBAL chain id = chain0 + c,
+ *   index), so a chain's draws do not depend on how chains are split over launches or ranks --,
+ *   mom = z + (eps/2) d logpost(cur), q = cur + eps * mom, and the current kinetic energy as partial sums of z^2:
+ *   kin_cur_parts [C, qn_hmc_parts(p)] (the accept call adds them left to right and halves the sum; the number of
+ *   partials depends on p alone).  grad_cur is the gradient at the current state, kept from the accepted proposal.
+ * qn_hmc_leap (hmc.py:53-60): given grad_q = d SSE / d W at q (dtype QN_F64 / QN_F32): inner step (last = 0)
+ *   mom += eps * d logpost(q), q += eps * mom; last step (last = 1) mom += (eps/2) * d logpost(q) and kin_prop_parts
+ *   [C, qn_hmc_parts(p)] = partial sums of mom^2 (the sign flip of hmc.py:64 does not change it).
+ * qn_hmc_accept (mcmc.py:68-85): log-posterior of the proposal from sse_q [C] (the SSE the last gradient call returned:
+ *   the reference spends an extra forward pass on it), mh = exp((U + K) - (U' + K')), accept iff u_c < mh; on accept
+ *   cur <- q, grad_cur <- grad_q; MAP, chain / lps / alphas rows, nacc and the double-buffered scalars / step counter
+ *   exactly as qn_mcmc_accept (cur_lp, best_lp: [2, C]; step_ptr: [2]; slot `parity` read, slot 1 - parity written). */
+int qn_hmc_parts(int64_t p);
+int qn_hmc_begin(const double* cur, const double* grad_cur, double sigma, double epsilon, int C, int chain0, int64_t p,
+                 uint64_t seed, const int64_t* step_ptr, double* mom, double* q, double* kin_cur_parts, void* stream);
+int qn_hmc_leap(const void* grad_q, int dtype, double sigma, double epsilon, int last, int C, int64_t p, double* mom,
+                double* q, double* kin_prop_parts, void* stream);
+int qn_hmc_accept(const double* q, const double* grad_q, const double* sse_q, const double* kin_cur_parts,
+                  const double* kin_prop_parts, double sigma, int n_rows, int C, int chain0, int64_t p, int nmcmc,
+                  uint64_t seed, double* cur, double* grad_cur, double* cur_lp, double* best, double* best_lp,
+                  double* chain, double* lps, double* alphas, int64_t* nacc, int64_t* step_ptr, int parity, void* stream);
+
 /* Diagnostic: y[i] = device tanh(x[i]) in float64 (the activation used by every kernel). */
 int qn_debug_tanh(const double* x, double* y, int64_t n, void* stream);
 /* Diagnostic: the variant the fused kernels use when all weights and inputs are finite and bounded

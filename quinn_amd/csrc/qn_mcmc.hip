@@ -331,6 +331,13 @@ struct AcceptArgs {
     int par, C;                           // parity of this step: scalar state is read from slot par, written to slot 1 - par
     int64_t p, pstride;
     uint64_t seed;
+    // HMC (qn_hmc_accept): kinetic energies K = (sum of nkin partial sums, left to right) / 2 enter the MH ratio,
+    // and an accepted proposal also carries its gradient row (gprop -> gcur).  nkin == 0: plain Metropolis.
+    int nkin;
+    const double* kin_cur;                // [C, nkin]
+    const double* kin_prop;               // [C, nkin]
+    const double* gprop;                  // [C, p]
+    double* gcur;                         // [C, p]
 };
 
 // Optional fusion of the NEXT step's proposal into the accept kernel (it already has the new state in registers):
@@ -383,7 +390,10 @@ __global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __r
     for (int i = 0; i < a.nparts; ++i) sse += sse_prop[(int64_t)b * a.nparts + i];     // order of k_sum_partials
     const double plp = -(a.half_inv_sig2 * sse + a.lp_const);
     const double clp = cur_lp[so];
-    const double mh = exp(plp - clp);                               // exp(current_U - proposed_U), mcmc.py:69-72
+    double kin_c = 0.0, kin_p = 0.0;
+    for (int i = 0; i < a.nkin; ++i) { kin_c += a.kin_cur[(int64_t)b * a.nkin + i]; kin_p += a.kin_prop[(int64_t)b * a.nkin + i]; }
+    // exp(current_H - proposed_H), H = U + K, U = -log-posterior (mcmc.py:69-72); with K = 0 this is exp(plp - clp) exactly
+    const double mh = exp((-clp + 0.5 * kin_c) - (-plp + 0.5 * kin_p));
     Philox ph;
     ph.gen(a.seed, 2 * (uint64_t)step + 1, ctr_of(a.chain0 + b, 2, 0));
     const double u = u01(ph.c[0], ph.c[1]);
@@ -418,6 +428,7 @@ __global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __r
             const int64_t e = e0 + (int64_t)u * ABLK;
             if (e >= hi) break;
             if (take) cur[base + e] = v[u];
+            if (take && a.gcur) a.gcur[base + e] = a.gprop[base + e];
             if (better) best[base + e] = v[u];
             if (crow) crow[e] = v[u];
             if (hist) {
@@ -455,6 +466,93 @@ __global__ __launch_bounds__(ABLK) void k_accept(AcceptArgs a, const double* __r
     }
 }
 
+
+// ---- Hamiltonian Monte Carlo on the device (quinn/mcmc/hmc.py:43-66 around the batched gradient kernel).
+// Elementwise over [C, p], HBM-bound: begin 2 reads + 2 writes, leap 3 reads + 2 writes of 8 B per element.  A
+// chain's elements are spread over HPARTS(p) workgroups of HBLK threads x HUB elements; each writes ONE partial sum
+// of squares (fixed-order tree inside the block), the accept kernel adds the partials left to right: kinetic energies
+// are bitwise reproducible and depend only on p, never on how many chains a launch or a rank holds.
+constexpr int HBLK = 256;
+constexpr int HUB = 4;
+__device__ __forceinline__ double block_sum_256(double v, double* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+// momentum z ~ N(0, I) (Philox stream 2*step, keyed by the global chain id), K_cur partials = sum z^2,
+// half kick with the cached gradient of the current state, first drift:
+//   mom = z + (eps/2) * gs * g_cur;   q = cur + eps * mom           (gs = -0.5 / sigma^2: d logpost = gs * d SSE)
+__global__ __launch_bounds__(HBLK) void k_hmc_begin(const double* __restrict__ cur, const double* __restrict__ gcur,
+                                                    double half_kick, double eps, int chain0, int64_t p, uint64_t seed,
+                                                    const int64_t* __restrict__ step_ptr, double* __restrict__ mom,
+                                                    double* __restrict__ q, double* __restrict__ kin_parts) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    const uint64_t step = (uint64_t)*step_ptr;
+    const int64_t base = (int64_t)b * p;
+    const int64_t npair = (p + 1) / 2;
+    const int64_t pchunk = (npair + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = blockIdx.x * pchunk, hi = lo + pchunk < npair ? lo + pchunk : npair;
+    double ss = 0.0;
+    for (int64_t j = lo + threadIdx.x; j < hi; j += HBLK) {
+        Philox ph;
+        ph.gen(seed, 2 * step, ctr_of(chain0 + b, 0, (uint64_t)j));
+        double za, zb;
+        normal2(ph, za, zb);
+        const int64_t e = 2 * j;
+        const double m0 = fma(half_kick, gcur[base + e], za);
+        mom[base + e] = m0;
+        q[base + e] = fma(eps, m0, cur[base + e]);
+        ss = fma(za, za, ss);
+        if (e + 1 < p) {
+            const double m1 = fma(half_kick, gcur[base + e + 1], zb);
+            mom[base + e + 1] = m1;
+            q[base + e + 1] = fma(eps, m1, cur[base + e + 1]);
+            ss = fma(zb, zb, ss);
+        }
+    }
+    const double tot = block_sum_256(ss, red);
+    if (threadIdx.x == 0) kin_parts[(int64_t)b * gridDim.x + blockIdx.x] = tot;
+}
+// kick with the gradient at q, then (inner step) drift, or (last step) the proposal's kinetic energy partials:
+//   mom += kick * g;   last ? K_prop partial = sum mom^2 : q += eps * mom
+template <typename TG>
+__global__ __launch_bounds__(HBLK) void k_hmc_leap(const TG* __restrict__ g, double kick, double eps, int last, int64_t p,
+                                                   double* __restrict__ mom, double* __restrict__ q,
+                                                   double* __restrict__ kin_parts) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    const int64_t base = (int64_t)b * p;
+    const int64_t chunk = (p + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = blockIdx.x * chunk, hi = lo + chunk < p ? lo + chunk : p;
+    double ss = 0.0;
+    for (int64_t e0 = lo + threadIdx.x; e0 < hi; e0 += (int64_t)HUB * HBLK) {
+        double gv[HUB], mv[HUB], qv[HUB];
+#pragma unroll
+        for (int u = 0; u < HUB; ++u) {
+            const int64_t e = e0 + (int64_t)u * HBLK;
+            const bool in = e < hi;
+            gv[u] = in ? (double)g[base + e] : 0.0;
+            mv[u] = in ? mom[base + e] : 0.0;
+            qv[u] = (in && !last) ? q[base + e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < HUB; ++u) {
+            const int64_t e = e0 + (int64_t)u * HBLK;
+            if (e >= hi) break;
+            const double m = fma(kick, gv[u], mv[u]);
+            mom[base + e] = m;
+            if (last) ss = fma(m, m, ss);
+            else q[base + e] = fma(eps, m, qv[u]);
+        }
+    }
+    if (last) {
+        const double tot = block_sum_256(ss, red);
+        if (threadIdx.x == 0) kin_parts[(int64_t)b * gridDim.x + blockIdx.x] = tot;
+    }
+}
 }  // namespace
 
 extern "C" int qn_mcmc_propose(const double* cur, const double* sd, double c1, int C, int chain0, int64_t p,
@@ -555,6 +653,7 @@ extern "C" int qn_mcmc_accept(const double* prop, const double* sse_prop, double
     a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
     a.chain0 = chain0; a.nmcmc = nmcmc; a.kcap = kcap; a.p = p; a.pstride = pstride; a.seed = seed;
     a.par = parity; a.C = C; a.nparts = nparts;
+    a.nkin = 0; a.kin_cur = a.kin_prop = a.gprop = nullptr; a.gcur = nullptr;
     (void)hipGetLastError();
     NextArgs nx;
     nx.mode = 0; nx.t = 0; nx.c1 = 0.0; nx.s_iso = 0.0; nx.sd = nullptr; nx.delta = nullptr; nx.out = nullptr;
@@ -583,11 +682,83 @@ extern "C" int qn_mcmc_accept_propose(const double* prop, const double* sse_prop
     a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
     a.chain0 = chain0; a.nmcmc = nmcmc; a.kcap = kcap; a.p = p; a.pstride = pstride; a.seed = seed;
     a.par = parity; a.C = C; a.nparts = nparts;
+    a.nkin = 0; a.kin_cur = a.kin_prop = a.gprop = nullptr; a.gcur = nullptr;
     NextArgs nx;
     nx.mode = next_mode; nx.t = t_next; nx.c1 = c1; nx.s_iso = s_iso; nx.sd = sd; nx.delta = delta; nx.out = prop_next;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_accept, dim3(accept_parts(p), C), dim3(ABLK), 0, static_cast<hipStream_t>(stream), a, prop, sse_prop, cur, cur_lp,
                        best, best_lp, chain, lps, alphas, nacc, x0, hist, mult, kcur, sumx, step_ptr, nx);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- HMC entry points
+static int hmc_parts(int64_t p) {                      // workgroups per chain: a function of p alone (see k_hmc_begin)
+    const int64_t n = (p + HBLK * HUB - 1) / (HBLK * HUB);
+    return n > 64 ? 64 : (n < 1 ? 1 : (int)n);
+}
+extern "C" int qn_hmc_parts(int64_t p) { return p > 0 ? hmc_parts(p) : QN_EINVAL; }
+
+extern "C" int qn_hmc_begin(const double* cur, const double* grad_cur, double sigma, double epsilon, int C, int chain0,
+                            int64_t p, uint64_t seed, const int64_t* step_ptr, double* mom, double* q, double* kin_cur_parts,
+                            void* stream) {
+    if (!cur || !grad_cur || !step_ptr || !mom || !q || !kin_cur_parts || C <= 0 || C > 65535 || chain0 < 0 || p <= 0 ||
+        !(sigma > 0.0)) {
+        qn_set_error("qn_hmc_begin: bad argument");
+        return QN_EINVAL;
+    }
+    const double gs = -0.5 / (sigma * sigma);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_hmc_begin, dim3(hmc_parts(p), C), dim3(HBLK), 0, static_cast<hipStream_t>(stream), cur, grad_cur,
+                       0.5 * epsilon * gs, epsilon, chain0, p, seed, step_ptr, mom, q, kin_cur_parts);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
+
+extern "C" int qn_hmc_leap(const void* grad_q, int dtype, double sigma, double epsilon, int last, int C, int64_t p, double* mom,
+                           double* q, double* kin_prop_parts, void* stream) {
+    if (!grad_q || !mom || !q || (last && !kin_prop_parts) || C <= 0 || C > 65535 || p <= 0 || !(sigma > 0.0) ||
+        (dtype != QN_F64 && dtype != QN_F32)) {
+        qn_set_error("qn_hmc_leap: bad argument");
+        return QN_EINVAL;
+    }
+    const double gs = -0.5 / (sigma * sigma);
+    const double kick = (last ? 0.5 : 1.0) * epsilon * gs;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    if (dtype == QN_F32)
+        hipLaunchKernelGGL(k_hmc_leap<float>, dim3(hmc_parts(p), C), dim3(HBLK), 0, st, (const float*)grad_q, kick, epsilon,
+                           last ? 1 : 0, p, mom, q, kin_prop_parts);
+    else
+        hipLaunchKernelGGL(k_hmc_leap<double>, dim3(hmc_parts(p), C), dim3(HBLK), 0, st, (const double*)grad_q, kick, epsilon,
+                           last ? 1 : 0, p, mom, q, kin_prop_parts);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
+
+extern "C" int qn_hmc_accept(const double* q, const double* grad_q, const double* sse_q, const double* kin_cur_parts,
+                             const double* kin_prop_parts, double sigma, int n_rows, int C, int chain0, int64_t p, int nmcmc,
+                             uint64_t seed, double* cur, double* grad_cur, double* cur_lp, double* best, double* best_lp,
+                             double* chain, double* lps, double* alphas, int64_t* nacc, int64_t* step_ptr, int parity,
+                             void* stream) {
+    if (!q || !grad_q || !sse_q || !kin_cur_parts || !kin_prop_parts || !cur || !grad_cur || !cur_lp || !best || !best_lp ||
+        !lps || !alphas || !nacc || !step_ptr || C <= 0 || C > 65535 || chain0 < 0 || p <= 0 || !(sigma > 0.0) ||
+        (parity != 0 && parity != 1)) {
+        qn_set_error("qn_hmc_accept: bad argument");
+        return QN_EINVAL;
+    }
+    AcceptArgs a;
+    a.half_inv_sig2 = 0.5 / (sigma * sigma);
+    a.lp_const = 0.5 * n_rows * std::log(2.0 * M_PI) + n_rows * std::log(sigma);
+    a.chain0 = chain0; a.nmcmc = nmcmc; a.kcap = 0; a.p = p; a.pstride = p; a.seed = seed;
+    a.par = parity; a.C = C; a.nparts = 1;
+    a.nkin = hmc_parts(p); a.kin_cur = kin_cur_parts; a.kin_prop = kin_prop_parts; a.gprop = grad_q; a.gcur = grad_cur;
+    NextArgs nx;
+    nx.mode = 0; nx.t = 0; nx.c1 = 0.0; nx.s_iso = 0.0; nx.sd = nullptr; nx.delta = nullptr; nx.out = nullptr;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_accept, dim3(accept_parts(p), C), dim3(ABLK), 0, static_cast<hipStream_t>(stream), a, q, sse_q, cur,
+                       cur_lp, best, best_lp, chain, lps, alphas, nacc, (const double*)nullptr, (float*)nullptr,
+                       (int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, step_ptr, nx);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }

@@ -305,7 +305,7 @@ class BatchedMLP:
         return Wt
 
     # ------------------------------------------------------------------ the operator
-    def _call(self, W, row_idx, want_pred, want_grad, X=None, Y=None):
+    def _call(self, W, row_idx, want_pred, want_grad, X=None, Y=None, out=None):
         X = self.X if X is None else X
         Y = self.Y if Y is None else Y
         N = X.shape[0]
@@ -317,9 +317,15 @@ class BatchedMLP:
         else:
             ridx, Nb = None, N
         o = self.arch.dims[-1]
-        sse = torch.empty(B, dtype=torch.float64, device=self.device)
+        if out is not None:                          # caller-owned result buffers (engines that run inside a HIP graph)
+            sse, grad = out
+            if sse.shape != (B,) or sse.dtype != torch.float64 or not sse.is_contiguous() or \
+                    (want_grad and (grad.shape != (B, self.p) or grad.dtype != self.tdt or not grad.is_contiguous())):
+                raise ValueError("out=(sse [B] float64, grad [B, p] compute dtype) does not match the call")
+        else:
+            sse = torch.empty(B, dtype=torch.float64, device=self.device)
+            grad = torch.empty(B, self.p, dtype=self.tdt, device=self.device) if want_grad else None
         pred = torch.empty(B, Nb, o, dtype=self.tdt, device=self.device) if want_pred else None
-        grad = torch.empty(B, self.p, dtype=self.tdt, device=self.device) if want_grad else None
         if B == 0:                                   # nothing to evaluate (e.g. an empty shard of chains)
             return sse, pred, grad
         bc = self._chunk(B, Nb, want_grad)
@@ -363,9 +369,10 @@ class BatchedMLP:
                        "qn_mlp_sse_fwd_parts")
         return out
 
-    def sse_grad(self, W, row_idx=None):
-        """(sse [B] float64, d sse / d W [B, p] compute dtype), device tensors."""
-        s, _, g = self._call(W, row_idx, False, True)
+    def sse_grad(self, W, row_idx=None, out=None):
+        """(sse [B] float64, d sse / d W [B, p] compute dtype), device tensors; `out=(sse, grad)` writes into the
+        caller's buffers instead of allocating."""
+        s, _, g = self._call(W, row_idx, False, True, out=out)
         return s, g
 
     def sse_pred(self, W, row_idx=None):

@@ -142,7 +142,7 @@ class NN_MCMC(QUiNNBase):
                 eng = DeviceAMCMC(op, datanoise, seed=seed0, chain0=lo, **sampler_params)
             elif sampler == 'hmc':
                 from ..mcmc.device_hmc import DeviceHMC
-                eng = DeviceHMC(op, datanoise, seed=seed0 + 7919 * rank, **sampler_params)
+                eng = DeviceHMC(op, datanoise, seed=seed0, chain0=lo, **sampler_params)
             else:
                 raise ValueError("engine='device' is implemented for sampler='amcmc' and 'hmc'")
             if hi > lo:

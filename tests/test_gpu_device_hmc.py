@@ -1,0 +1,168 @@
+"""GPU: the device-resident HMC engine (qn_hmc_begin / qn_hmc_leap / qn_hmc_accept around the batched gradient kernel).
+The leapfrog arithmetic and the MH ratio are checked against the reference's formulas (quinn/mcmc/hmc.py:43-66,
+mcmc.py:68-75) evaluated with the ORACLE's gradient on the kernel's own momenta; chains are checked for independence
+from the way they are split over engines (what sharding over ranks does), for graph replay == direct launches, and in
+distribution on a Gaussian posterior."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mlp_ref
+from quinn_amd import _lib
+from quinn_amd.mcmc.device_hmc import DeviceHMC
+from quinn_amd.ops import BatchedMLP, MLPArch
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(seed=0, N=48, d=1):
+    rs = np.random.RandomState(seed)
+    x = rs.rand(N, d) * 6 - 3
+    y = np.sin(x).sum(axis=1, keepdims=True) + 0.1 * rs.randn(N, 1)
+    return x, y
+
+
+def _begin(op, cur, gcur, sigma, eps, chain0, seed, step):
+    """qn_hmc_begin through the C ABI -> (mom, q, K_cur) on the host."""
+    L = _lib.lib()
+    C, p = cur.shape
+    nk = L.qn_hmc_parts(p)
+    mom, q = torch.empty_like(cur), torch.empty_like(cur)
+    kparts = torch.empty(C, nk, dtype=torch.float64, device=cur.device)
+    st = torch.zeros(2, dtype=torch.int64, device=cur.device)
+    st[0] = step
+    _lib.check(L.qn_hmc_begin(cur.data_ptr(), gcur.data_ptr(), sigma, eps, C, chain0, p, seed, st.data_ptr(), mom.data_ptr(),
+                              q.data_ptr(), kparts.data_ptr(), None), "qn_hmc_begin")
+    torch.cuda.synchronize()
+    return mom.cpu().numpy(), q.cpu().numpy(), 0.5 * kparts.cpu().numpy().sum(axis=1)
+
+
+@pytest.mark.parametrize("dims,L_", [((1, 8, 8, 1), 3), ((2, 16, 1), 1), ((1, 64, 64, 64, 1), 4)])
+def test_one_step_equals_the_reference_leapfrog_on_the_kernel_momenta(dims, L_):
+    x, y = _problem(N=40, d=dims[0])
+    sigma, eps, seed, C = 0.2, 0.003, 1234, 5
+    arch = MLPArch(dims, "tanh")
+    op = BatchedMLP(arch, x, y)
+    rs = np.random.RandomState(3)
+    ini = 0.3 * rs.randn(C, arch.nparams)
+    eng = DeviceHMC(op, sigma, epsilon=eps, L=L_, seed=seed, chain0=7)
+    r = eng.run(1, ini)
+    torch.cuda.synchronize()
+    # the momenta the engine drew at step 0: rerun the begin kernel on the same (state, gradient, seed, step, chain0)
+    cur = torch.as_tensor(ini, device="cuda")
+    _, g0 = op.sse_grad(cur)
+    mom, q1, kcur = _begin(op, cur, g0, sigma, eps, 7, eng.seed, 0)
+    mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, "tanh"))
+    yd = [v for v in y]
+    lp = lambda w: mlp_ref.logpost(mod, w, x, yd, sigma)
+    lpg = lambda w: mlp_ref.logpostgrad(mod, w, x, yd, sigma)
+    for c in range(C):
+        z = mom[c] - eps * lpg(ini[c]) / 2                          # undo the half kick: the N(0, I) draw itself
+        assert abs(np.sum(np.square(z)) / 2 - kcur[c]) <= 1e-12 * kcur[c]
+        # reference sampler (hmc.py:43-66) on this momentum
+        qq, pp = ini[c].copy(), z.copy()
+        k0 = np.sum(np.square(pp)) / 2
+        pp += eps * lpg(qq) / 2
+        for jj in range(L_):
+            qq += eps * pp
+            if jj != L_ - 1:
+                pp += eps * lpg(qq)
+        pp += eps * lpg(qq) / 2
+        k1 = np.sum(np.square(-pp)) / 2
+        mh = np.exp((-lp(ini[c]) + k0) - (-lp(qq) + k1))           # mcmc.py:68-72
+        np.testing.assert_allclose(r['alphas'][c, 1].item(), mh, rtol=1e-8)
+        got = r['chain'][c, 1].cpu().numpy()
+        moved = not np.array_equal(got, ini[c])
+        if moved:
+            np.testing.assert_allclose(got, qq, rtol=1e-10, atol=1e-12)
+            assert abs(r['logpost'][c, 1].item() - lp(qq)) <= 1e-10 * abs(lp(qq))
+        assert abs(r['logpost'][c, 0].item() - lp(ini[c])) <= 1e-10 * abs(lp(ini[c]))
+    assert np.all(r['alphas'][:, 0].cpu().numpy() == 0.0)
+
+
+def test_momenta_are_standard_normal_and_keyed_by_global_chain_and_step():
+    x, y = _problem()
+    arch = MLPArch((1, 64, 64, 1), "tanh")
+    op = BatchedMLP(arch, x, y)
+    C, p = 64, arch.nparams
+    cur = torch.zeros(C, p, dtype=torch.float64, device="cuda")
+    g = torch.zeros_like(cur)                                        # zero gradient: mom is the draw itself
+    z, q, k = _begin(op, cur, g, 0.2, 0.5, 0, 42, 5)
+    v = z.ravel()
+    n = v.size
+    assert abs(v.mean()) < 5 / np.sqrt(n) and abs(v.var() - 1) < 5 * np.sqrt(2 / n) and abs((v ** 4).mean() - 3) < 5 * np.sqrt(96 / n)
+    np.testing.assert_allclose(q, 0.5 * z, rtol=0, atol=0)            # first drift: q = cur + eps * mom
+    np.testing.assert_allclose(k, 0.5 * (z ** 2).sum(axis=1), rtol=1e-13)
+    # chains 10..19 of a launch that starts at chain 10 == chains 10..19 of the launch that starts at 0
+    z10, _, _ = _begin(op, cur[:10], g[:10], 0.2, 0.5, 10, 42, 5)
+    assert np.array_equal(z10, z[10:20])
+    z_other_step, _, _ = _begin(op, cur, g, 0.2, 0.5, 0, 42, 6)
+    assert not np.array_equal(z_other_step, z)
+
+
+def test_chains_do_not_depend_on_how_they_are_split():
+    x, y = _problem(N=64)
+    arch = MLPArch((1, 16, 16, 1), "tanh")
+    op = BatchedMLP(arch, x, y)
+    C, nmcmc = 6, 40
+    ini = np.stack([np.random.RandomState(50 + c).rand(arch.nparams) for c in range(C)])
+    kw = dict(epsilon=0.002, L=3, seed=9)
+    whole = DeviceHMC(op, 0.2, chain0=0, **kw).run(nmcmc, ini)
+    a = DeviceHMC(op, 0.2, chain0=0, **kw).run(nmcmc, ini[:2])
+    b = DeviceHMC(op, 0.2, chain0=2, **kw).run(nmcmc, ini[2:])
+    for k in ('chain', 'logpost', 'alphas', 'accrate', 'mapparams', 'maxpost'):
+        joined = torch.cat([a[k], b[k]]).cpu().numpy()
+        # identical random numbers; only the summation order of a chain's SSE / gradient depends on the batch size
+        np.testing.assert_allclose(joined, whole[k].cpu().numpy(), rtol=1e-7, atol=1e-9, err_msg=k)
+    moved = lambda r: (r['chain'][:, 1:] != r['chain'][:, :-1]).any(dim=2).cpu().numpy()
+    assert np.array_equal(np.concatenate([moved(a), moved(b)]), moved(whole))
+    assert 0.3 < whole['accrate'].mean().item() <= 1.0
+
+
+def test_graph_replay_equals_direct_launches_bit_for_bit():
+    x, y = _problem(N=64)
+    arch = MLPArch((1, 16, 16, 1), "tanh")
+    op = BatchedMLP(arch, x, y)
+    ini = np.stack([np.random.RandomState(70 + c).rand(arch.nparams) for c in range(4)])
+    for nmcmc in (11, 12):                                              # odd: the last step is launched directly
+        d = DeviceHMC(op, 0.2, epsilon=0.002, L=2, seed=5).run(nmcmc, ini)
+        g = DeviceHMC(op, 0.2, epsilon=0.002, L=2, seed=5, use_graph=True).run(nmcmc, ini)
+        for k in d:
+            assert torch.equal(d[k], g[k]), (nmcmc, k)
+
+
+def test_float32_operator_runs_the_same_chain_to_float32_accuracy():
+    x, y = _problem(N=64)
+    arch = MLPArch((1, 16, 16, 1), "tanh")
+    ini = np.stack([np.random.RandomState(80 + c).rand(arch.nparams) for c in range(3)])
+    r64 = DeviceHMC(BatchedMLP(arch, x, y), 0.3, epsilon=0.002, L=3, seed=2).run(5, ini)
+    r32 = DeviceHMC(BatchedMLP(arch, x, y, dtype="float32"), 0.3, epsilon=0.002, L=3, seed=2).run(5, ini)
+    np.testing.assert_allclose(r32['logpost'].cpu().numpy(), r64['logpost'].cpu().numpy(), rtol=2e-4)
+
+
+def test_gaussian_posterior_moments():
+    """Linear model y = w x + b: the posterior over (w, b) is Gaussian with the least-squares mean and covariance
+    sigma^2 (A^T A)^-1 -- the device chains must reproduce it (the reference's own sampler test is of this kind,
+    tests/test_mcmc.py:93-109)."""
+    rs = np.random.RandomState(1)
+    N, sigma = 50, 0.5
+    x = rs.randn(N, 1)
+    y = 1.5 * x - 0.7 + sigma * rs.randn(N, 1)
+    arch = MLPArch((1, 1), "identity")
+    op = BatchedMLP(arch, x, y)
+    A = np.hstack([x, np.ones((N, 1))])
+    cov = sigma ** 2 * np.linalg.inv(A.T @ A)
+    mean = np.linalg.solve(A.T @ A, A.T @ y).ravel()
+    C, nmcmc = 256, 400
+    ini = mean + 0.1 * rs.randn(C, 2)
+    r = DeviceHMC(op, sigma, epsilon=0.03, L=8, seed=11).run(nmcmc, ini)
+    ch = r['chain'][:, 100:].cpu().numpy().reshape(-1, 2)
+    acc = r['accrate'].mean().item()
+    assert 0.7 < acc <= 1.0
+    se = np.sqrt(np.diag(cov) / (C * 10))                              # generous: ~10 effective samples per chain
+    assert np.all(np.abs(ch.mean(axis=0) - mean) < 5 * se)
+    np.testing.assert_allclose(np.cov(ch.T), cov, rtol=0.15, atol=0.1 * np.abs(cov).max())
+    lp_map = r['maxpost'].cpu().numpy()
+    assert np.all(lp_map >= r['logpost'].cpu().numpy().max(axis=1) - 1e-9)
