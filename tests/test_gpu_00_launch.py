@@ -1,0 +1,66 @@
+"""GPU, runs FIRST (file name): the multi-rank paths as child programs, started before this pytest process has touched
+the GPU (a GPU-initialised process must not start child programs on these boxes).  On a 1-GPU box the ranks share
+cuda:0 and use gloo for the collectives; what is checked is the launch / shard / gather logic:
+  * `bench.py --gpus 2` starts its own two ranks and prints ONE JSON line with n_gpus = 2, weak and strong scaling;
+  * `NN_MCMC.fit(engine='device')` under two ranks equals the single-process run for AMCMC and for HMC (random streams
+    keyed by the global chain id), with gather = 'all' and gather = 'root'."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from quinn_amd.parallel import launch_ranks
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _no_gpu_yet():
+    if torch.cuda.is_initialized():
+        pytest.skip("this process has already initialised the GPU: child programs are not started from it")
+
+
+def _json_lines(text):
+    return [json.loads(ln) for ln in text.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_gpus_2_starts_two_ranks(scaling):
+    _no_gpu_yet()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", scaling, "--steps", "20",
+                        "--warmup", "2", "--spread", "4"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["steps"] == 20
+    assert d["config"]["chains_total"] == (128 if scaling == "weak" else 64)
+    assert d["config"]["chains_rank0"] == (64 if scaling == "weak" else 32)
+    assert d["value"] > 0 and d["roofline"]["kernel_ms_min"] <= d["roofline"]["kernel_ms_median"] <= d["roofline"]["kernel_ms_max"]
+    assert abs(d["value"] - d["config"]["chains_total"] * 20 / (d["ms_per_step"] * 20e-3)) <= 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("sampler,gather", [("amcmc", "all"), ("hmc", "all"), ("hmc", "root")])
+def test_device_engine_two_ranks_equal_one_process(sampler, gather):
+    _no_gpu_yet()
+    tool = os.path.join(ROOT, "tools", "check_device_2rank.py")
+    one = subprocess.run([sys.executable, tool, sampler, gather], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    ref = _json_lines(one.stdout)[-1]
+    rc, so, se = launch_ranks(tool, [sampler, gather], 2, timeout=900, capture=True)
+    assert rc == 0, se[-3000:]
+    outs = {d["rank"]: d for d in _json_lines(so)}
+    assert set(outs) == {0, 1}
+    keys = ("accrate", "maxpost", "last_logpost", "chain_checksum")
+    assert outs[0]["chains"] == ref["chains"]                         # rank 0 holds every chain under 'all' and 'root'
+    for k in keys:
+        assert outs[0][k] == pytest.approx(ref[k], rel=1e-6, abs=1e-4), k
+    if gather == "all":
+        assert all(outs[1][k] == outs[0][k] for k in keys)
+    else:                                                             # rank 1 keeps its own shard (chains 3..5)
+        assert outs[1]["chains"][0] == 3
+        for k in keys:
+            assert outs[1][k] == pytest.approx(ref[k][3:], rel=1e-6, abs=1e-4), k
