@@ -250,7 +250,7 @@ class DeviceAMCMC:
                 fn()
             return g
 
-        graphs = {'initial': None, 'adapted': None}
+        graphs = {}
         i = 0
         while i < nmcmc:
             if i > self.t0 and i % self.tadapt == 0:
@@ -261,7 +261,7 @@ class DeviceAMCMC:
                                  # dispatch order of the history product: longest history first
                                  'order': torch.argsort(s['kcur'][s['par']], descending=True).to(torch.int32),
                                  's_iso': float(np.sqrt(scale * 1e-8))}
-                graphs['adapted'] = None                                    # new snapshot tensors: recapture
+                graphs = {k: g for k, g in graphs.items() if k[0] != 'adapted'}   # new snapshot tensors: recapture
                 if coef is None:
                     coef = torch.empty(C * ((kcap + 3) // 4 * 4 + 1) * TB, dtype=torch.float32, device=dev)
                     delta = torch.empty(C, TB, p, dtype=f64, device=dev)
@@ -270,8 +270,11 @@ class DeviceAMCMC:
             nfull, rest = divmod(nrun, G)
             if self.use_graph and nfull > 0 and (adapted or state['L'] is None):   # (torch matmul path: not captured)
                 # G steps captured once and replayed (no faster than direct launches at cfg2; kept as an option)
-                key = 'adapted' if adapted else 'initial'
-                if graphs[key] is None:
+                # a captured block bakes in the parity slots of the double-buffered scalars it starts from (G is even,
+                # so a replay leaves the parity where it was): one graph per (regime, starting parity) -- a stretch
+                # of an odd number of directly launched steps in between flips the parity
+                key = ('adapted' if adapted else 'initial', s['par'])
+                if graphs.get(key) is None:
                     graphs[key] = capture((lambda: block_adapted(G)) if adapted
                                           else (lambda: run_initial(G, False)))
                 state['have_prop'] = False

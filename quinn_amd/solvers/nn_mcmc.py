@@ -42,8 +42,10 @@ class NN_MCMC(QUiNNBase):
 
     # -- device operator bound to lpinfo's dataset -----------------------------------------
     def _operator(self, lpinfo):
-        key = (id(lpinfo['xd']), id(lpinfo['yd']))
-        if self._op is None or self._op_key != key:
+        # the cached operator belongs to these very objects (kept referenced here, compared with `is`: an id() alone
+        # can be recycled by a new array after the old one is freed)
+        key = (lpinfo['xd'], lpinfo['yd'])
+        if self._op is None or self._op_key[0] is not key[0] or self._op_key[1] is not key[1]:
             xd = np.asarray(lpinfo['xd'], dtype=np.float64)
             yd = np.asarray(lpinfo['yd'], dtype=np.float64)      # list of (o,) rows -> (N,o)
             self._op = BatchedMLP(self.arch, xd, yd.reshape(xd.shape[0], -1), device=self._device,
@@ -84,7 +86,7 @@ class NN_MCMC(QUiNNBase):
 
     # -- fit -------------------------------------------------------------------------------
     def fit(self, xtrn, ytrn, zflag=True, datanoise=0.05, nmcmc=6000, param_ini=None, sampler='amcmc',
-            sampler_params=None, *, nchains=1, seeds=None, engine='host', gather='all'):
+            sampler_params=None, *, nchains=1, seeds=None, engine='host', gather='all', bfgs_jac=None):
         """Run MCMC over the flat weight vector.
 
         Args (reference): xtrn `(N,d)`, ytrn `(N,o)`, zflag (BFGS pre-fit of a random start),
@@ -100,6 +102,9 @@ class NN_MCMC(QUiNNBase):
             chains (one all_gather of the result arrays, from the device buffers in bounded pieces); 'root' -- rank 0
             does, the other ranks keep their own shard; 'none' -- no communication at all.  A gather whose result
             exceeds `quinn_amd.parallel.DEFAULT_MAX_GATHER_BYTES` raises MemoryError before any traffic.
+            bfgs_jac: None -- the `zflag` BFGS pre-fit lets scipy difference the log-posterior, exactly as the reference
+            does (nn_mcmc.py:125-127; p + 1 log-posterior evaluations per gradient); 'device' -- the gradient kernel is
+            passed as the analytic jacobian (one evaluation per gradient; a different start point than the reference's).
         """
         ntrn_, outdim = ytrn.shape
         assert xtrn.shape[0] == ntrn_
@@ -118,10 +123,11 @@ class NN_MCMC(QUiNNBase):
             draw = (lambda r: r.rand(self.pdim)) if rngs else (lambda r: np.random.rand(self.pdim))
             inis = [draw(r) for r in (rngs or [None])]
             if zflag:
-                # BFGS pre-fit of the random start (nn_mcmc.py:125-127).  The reference lets scipy difference the
-                # log-posterior (p + 1 evaluations per gradient); here the gradient kernel is the jacobian
-                inis = [minimize((lambda x, fcn, lpinfo: -fcn(x, lpinfo)), ini, args=(self.logpost, self.lpinfo),
-                                 jac=(lambda x, fcn, lpinfo: -self.logpostgrad(x, lpinfo)),
+                # BFGS pre-fit of the random start (nn_mcmc.py:125-127); finite differences by default, like the reference
+                if bfgs_jac not in (None, 'device'):
+                    raise ValueError("bfgs_jac is None (scipy differences the log-posterior) or 'device'")
+                jac = (lambda x, fcn, lpinfo: -self.logpostgrad(x, lpinfo)) if bfgs_jac == 'device' else None
+                inis = [minimize((lambda x, fcn, lpinfo: -fcn(x, lpinfo)), ini, args=(self.logpost, self.lpinfo), jac=jac,
                                  method='BFGS', options={'gtol': 1e-13}).x for ini in inis]
             param_ini = np.stack(inis) if rngs else inis[0]
         param_ini = np.asarray(param_ini, dtype=np.float64)

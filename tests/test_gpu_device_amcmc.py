@@ -226,6 +226,23 @@ def test_fused_next_proposal_is_bit_identical(graph):
     assert (a['accrate'] > 0).all()
 
 
+def test_graph_replay_with_odd_stretches_equals_direct_launches():
+    """A captured block bakes in the step-parity slots it starts from; an odd number of directly launched steps between
+    two replays (odd `tadapt`, t0 > tadapt) flips the parity, so the engine keeps one graph per starting parity."""
+    from quinn_amd.mcmc.device_amcmc import DeviceAMCMC
+    from quinn_amd.ops import MLPArch, BatchedMLP
+    x, y = _problem(8)
+    arch = MLPArch((1, 8, 1), "tanh")
+    op = BatchedMLP(arch, x, y)
+    C, nmcmc = 3, 520
+    ini = np.stack([np.random.RandomState(950 + c).rand(arch.nparams) for c in range(C)])
+    for kw in (dict(gamma=0.1, t0=300, tadapt=129, seed=4), dict(gamma=0.1, t0=70, tadapt=65, seed=4)):
+        a = DeviceAMCMC(op, 0.2, use_graph=False, **kw).run(nmcmc, ini)
+        b = DeviceAMCMC(op, 0.2, use_graph=True, **kw).run(nmcmc, ini)
+        for k in ('chain', 'logpost', 'alphas', 'accrate', 'mapparams', 'maxpost'):
+            assert torch.equal(a[k], b[k]), (kw, k)
+
+
 def test_device_engine_matches_host_sampler_in_distribution():
     x, y = _problem(1)
     torch.manual_seed(1)

@@ -110,12 +110,19 @@ def test_zflag_bfgs_and_single_vector_api():
     from quinn_amd.nns.mlp import MLP
     small = NN_MCMC(MLP(1, 1, (5,), activ='tanh'), verbose=False)     # test_solvers.py:25-100 shape
     x = np.linspace(-1, 1, 20)[:, None]
-    np.random.seed(42)
-    small.fit(x, np.sin(3 * x), zflag=True, datanoise=0.1, nmcmc=200, sampler='amcmc', sampler_params={})
-    assert small.samples.shape == (201, small.pdim) and small.cmode.shape == (small.pdim,)
-    # the BFGS pre-fit (device gradient as jacobian) starts the chain near a mode: far above a random start
-    lp0 = small.mcmc_results['logpost'][0]
-    rnd = np.mean([small.logpost(np.random.RandomState(s).rand(small.pdim), small.lpinfo) for s in range(5)])
-    assert lp0 > rnd + 10.0, (lp0, rnd)
+    # the BFGS pre-fit starts the chain near a mode, far above a random start: with scipy's finite differences of the
+    # device log-posterior (default, as the reference does) and with the device gradient as the jacobian (opt-in)
+    for jac in (None, 'device'):
+        np.random.seed(42)
+        small.fit(x, np.sin(3 * x), zflag=True, datanoise=0.1, nmcmc=200, sampler='amcmc', sampler_params={}, bfgs_jac=jac)
+        assert small.samples.shape == (201, small.pdim) and small.cmode.shape == (small.pdim,)
+        lp0 = small.mcmc_results['logpost'][0]
+        rnd = np.mean([small.logpost(np.random.RandomState(s).rand(small.pdim), small.lpinfo) for s in range(5)])
+        assert lp0 > rnd + 10.0, (jac, lp0, rnd)
+    # the operator cache follows the dataset OBJECTS: a new lpinfo with other data is evaluated on that data
+    lp_a = small.logpost(small.cmode, small.lpinfo)
+    other = {'xd': x.copy(), 'yd': [v for v in np.cos(3 * x)], 'ltype': 'classical', 'lparams': {'sigma': 0.1}}
+    lp_b = small.logpost(small.cmode, other)
+    assert lp_a != lp_b and small.logpost(small.cmode, small.lpinfo) == lp_a
     assert small.predict_ens(x, nens=5, nburn=100).shape == (5, 20, 1)
     assert small.predict_MAP(x).shape == (20, 1)
