@@ -136,7 +136,8 @@ def parse_args():
     ap.add_argument("--kind", default="logpost", choices=["logpost", "grad"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (N=1 only)")
-    ap.add_argument("--path", default="auto", choices=["auto", "generic", "fused"])
+    ap.add_argument("--path", default="auto", choices=["auto", "generic", "fused", "fused_dp"],
+                    help="kernel family (fused_dp: the float64-MFMA fused kernels, without the sliced int8-product forward)")
     ap.add_argument("--graph", type=int, default=-1, help="capture this many consecutive steps in one HIP graph and "
                     "replay it (0 = direct launches, -1 = the largest divisor of --steps up to 50)")
     ap.add_argument("--spread", type=int, default=20, help="extra replays of the dominant kernel alone, after the timed "
@@ -187,7 +188,8 @@ def main():
     arch = MLPArch(DIMS, "tanh")
     x, y = synthetic(N, DIMS[0])
     op = BatchedMLP(arch, x, y, device=dev, dtype=tdt)
-    path_force = {"auto": _lib.PATH_AUTO, "generic": _lib.PATH_GENERIC, "fused": _lib.PATH_FUSED}[args.path]
+    path_force = {"auto": _lib.PATH_AUTO, "generic": _lib.PATH_GENERIC, "fused": _lib.PATH_FUSED,
+                  "fused_dp": _lib.PATH_FUSED_DP}[args.path]
     op.set_path(path_force)
     batches = []
     for k in range(NBATCH):
@@ -295,13 +297,17 @@ def main():
         if os.path.exists(tfile) and nloc == CHAINS:
             # HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
             # correction, + WRITE_SIZE), recorded by tools/prof_traffic.sh for this kernel / config
-            key = f"{args.kind}_{args.dtype}_{ {1: 'generic', 2: 'fused'}.get(path) }"
+            fam = {1: 'generic', 2: 'fused'}.get(path)
+            if fam == 'fused' and args.kind == 'logpost' and args.dtype == 'f64' and args.path != 'fused_dp':
+                fam = 'fused_i8'                       # the sliced int8-product forward (csrc/qn_fused_i8.hip)
+            key = f"{args.kind}_{args.dtype}_{fam}"
             traffic = json.load(open(tfile)).get(key, {}).get("hbm_bytes_per_launch")
         per_gpu = f"{CHAINS} AMCMC chains/GPU" if args.scaling == "weak" else f"{CHAINS} AMCMC chains in total ({nloc} on rank 0)"
         cfg = {"workload": f"configs[1]: {per_gpu}, 3x64 tanh MLP (p=8513), N=4096 1-D regression; step = batched "
                            + ("log-posterior+gradient" if want_grad else "log-posterior") + " of all chains",
                "chains_total": total, "chains_rank0": nloc, "N": N, "dims": list(DIMS),
-               "kind": args.kind, "kernel_path": {1: "generic", 2: "fused"}.get(path, str(path)),
+               "kind": args.kind, "kernel_path": {1: "generic", 2: "fused"}.get(path, str(path)) + (
+                   " (float64 MFMA kernels)" if args.path == "fused_dp" else ""),
                "launch": (f"HIP graph of {args.graph} steps, replayed {args.steps // args.graph}x" if args.graph
                           else "direct launches"),
                "parallelism": f"chains sharded x{world}, no data-path collective, one all_gather at the end"}

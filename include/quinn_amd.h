@@ -32,7 +32,7 @@ enum { QN_F64 = 0, QN_F32 = 1 };
 enum { QN_ACT_IDENTITY = 0, QN_ACT_TANH = 1, QN_ACT_RELU = 2 };
 enum { QN_OK = 0, QN_EINVAL = -1, QN_EWORKSPACE = -2, QN_EHIP = -3, QN_EUNSUPPORTED = -4 };
 /* kernel families, for qn_mlp_desc_set_path (tests / profiling) */
-enum { QN_PATH_AUTO = 0, QN_PATH_GENERIC = 1, QN_PATH_FUSED = 2 };
+enum { QN_PATH_AUTO = 0, QN_PATH_GENERIC = 1, QN_PATH_FUSED = 2, QN_PATH_FUSED_DP = 3 };
 
 typedef struct qn_desc qn_desc;
 
@@ -65,7 +65,9 @@ int qn_mlp_path(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
  * the previous setting.  There is no process-wide state: two operators in one process do not see each other's
  * choice.  QN_PATH_GENERIC is the layer-wise family at the EXACT layer widths; under QN_PATH_AUTO hidden widths that
  * are no multiples of 64 run on a zero-padded twin of the network (padded units stay exactly 0, results equal the
- * unpadded network's). */
+ * unpadded network's).  QN_PATH_FUSED_DP is QN_PATH_FUSED restricted to the kernels that use the float64 matrix
+ * instructions: it excludes the forward kernel that forms the 64-wide hidden layers as sliced exact int8 products
+ * (same results to ~1e-14 relative; kept selectable as the second implementation the tests compare it with). */
 int qn_mlp_desc_set_path(qn_desc* desc, int path);
 
 /* sse_out[b] = sum_{n,o} (Y[r(b,n),o] - f_{W[b]}(X[r(b,n),:])[o])^2 for b < B.

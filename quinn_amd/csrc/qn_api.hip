@@ -19,7 +19,10 @@ extern "C" const char* qn_version(void) { return "quinn_amd 0.1 gfx950"; }
 extern "C" int qn_mlp_desc_set_path(qn_desc* d, int path) {
     if (!d) return QN_EINVAL;
     const int old = d->path;
-    if (path == QN_PATH_AUTO || path == QN_PATH_GENERIC || path == QN_PATH_FUSED) d->path = path;
+    if (path == QN_PATH_AUTO || path == QN_PATH_GENERIC || path == QN_PATH_FUSED || path == QN_PATH_FUSED_DP) {
+        d->path = path;
+        if (d->padded) d->padded->path = path;         // the fused kernels run on the zero-padded twin
+    }
     return old;
 }
 
@@ -314,7 +317,7 @@ static int run(const char* fn, const qn_desc* d, int dtype, const void* W, const
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int want_grad = gradW != nullptr;
     if (d->kind == QN_KIND_RNET) {
-        if (d->path == QN_PATH_FUSED && !qn_rnet_fused_supported(d, want_grad, dtype)) {
+        if ((d->path == QN_PATH_FUSED || d->path == QN_PATH_FUSED_DP) && !qn_rnet_fused_supported(d, want_grad, dtype)) {
             qn_set_error("%s: fused path forced but not supported for this residual network", fn);
             return QN_EUNSUPPORTED;
         }
@@ -322,7 +325,7 @@ static int run(const char* fn, const qn_desc* d, int dtype, const void* W, const
             return qn_rnet_fused_run(d, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
         return qn_rnet_run(d, dtype, W, X, Y, row_idx, B, N, Nb, sse, pred, gradW, ws, ws_bytes, st);
     }
-    if (d->path == QN_PATH_FUSED && !fused_ok(d, B, Nb, want_grad, dtype)) {
+    if ((d->path == QN_PATH_FUSED || d->path == QN_PATH_FUSED_DP) && !fused_ok(d, B, Nb, want_grad, dtype)) {
         qn_set_error("%s: fused path forced but not supported for this shape", fn);
         return QN_EUNSUPPORTED;
     }

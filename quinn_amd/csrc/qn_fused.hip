@@ -22,6 +22,7 @@
 // last layer's dot product is finished with two cross-lane adds (lanes l, l^16, l^32 hold the same
 // data row).  SSE partials are reduced in a fixed order (bitwise reproducible).
 #include "qn_common.h"
+#include "qn_fused_args.h"
 #include "qn_math.h"
 #include <cstdlib>
 #include <type_traits>
@@ -35,13 +36,6 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int WG = 256;      // 4 waves
 constexpr int DMAX = 4;
 constexpr int OMAX = 4;
-
-struct FusedArgs {
-    int64_t p;
-    int B, N, Nb, d, o, nhid, act, has_bias;
-    int nsplit, rows_per_split, iters;
-    int64_t dbg_off;     // diagnostic builds: offset (doubles, from the partials) of a 12-word scratch
-};
 
 __host__ __device__ constexpr int swz(int j) { return ((j & 1) << 4) | (((j >> 1) & 7) << 1); }
 __host__ __device__ constexpr int stride_of(int H) { return (H + 31) / 32 * 32; }
@@ -1118,7 +1112,7 @@ size_t lds_need(int H, int d, int o, int nhid, int want_grad) {
                                      2 + TANH_TAB);
 }
 
-using fwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*);
+using fwd_fn = qn_fwd_fn;
 using bwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*,
                         double*);
 
@@ -1232,11 +1226,17 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
     double* partial = (parts_out && !want_grad) ? sse : static_cast<double*>(ws);
     double* slab = reinterpret_cast<double*>(static_cast<char*>(ws) + npart);
     a.dbg_off = (int64_t)(need / sizeof(double));          // the 256 spare bytes behind the slabs
-    const size_t lds_bytes = lds_need(H, a.d, a.o, nhid, want_grad);
+    size_t lds_bytes = lds_need(H, a.d, a.o, nhid, want_grad);
     dim3 grid(a.nsplit, B);
     (void)hipGetLastError();
     if (!want_grad) {
         fwd_fn kern = pick_fwd(H, a.act, padded_d(a.d), a.o);
+        // 64-wide tanh networks: the hidden GEMMs as sliced exact products on the int8 matrix pipe (qn_fused_i8.hip),
+        // unless the descriptor asks for the float64-MFMA kernels (QN_PATH_FUSED_DP)
+        if (d->path != QN_PATH_FUSED_DP && qn_fused_i8_applies(H, nhid, a.act, a.d, a.o)) {
+            kern = qn_fused_i8_kernel(a.d, a.o);
+            lds_bytes = qn_fused_i8_lds_bytes(a.d, nhid);
+        }
         if (!kern) {
             qn_set_error("qn_fused_run: no forward kernel instance for H=%d act=%d", H, a.act);
             return QN_EUNSUPPORTED;

@@ -1,0 +1,19 @@
+// Launch arguments shared by the fused forward kernels (qn_fused.hip, qn_fused_i8.hip); not part of the C ABI.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+struct FusedArgs {
+    int64_t p;
+    int B, N, Nb, d, o, nhid, act, has_bias;
+    int nsplit, rows_per_split, iters;
+    int64_t dbg_off;     // diagnostic builds: offset (doubles, from the partials) of a 12-word scratch
+};
+
+using qn_fwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*);
+
+// sliced int8-product forward for 64-wide tanh networks (qn_fused_i8.hip): same grid, block and partial-sum
+// conventions as k_fused_fwd_f64<64, 2, tanh, DP, 256>
+bool qn_fused_i8_applies(int H, int nhid, int act, int d, int o);
+size_t qn_fused_i8_lds_bytes(int d, int nhid);
+qn_fwd_fn qn_fused_i8_kernel(int d, int o);

@@ -1,0 +1,141 @@
+"""GPU: the sliced int8-product forward for 64-wide tanh networks (csrc/qn_fused_i8.hip) against the oracle, against the
+float64-MFMA fused kernel (QN_PATH_FUSED_DP) and against the layer-wise kernels: float64 tolerance 1e-11 (measured
+~1e-14), exceptional weights / inputs through its plain-float64 tile path, and an AMCMC chain whose acceptance
+indices do not depend on which of the kernels evaluated the log-posterior."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mlp_ref
+from quinn_amd import _lib
+from quinn_amd.mcmc.admcmc import AMCMC
+from quinn_amd.ops import BatchedMLP, MLPArch, neg_log_post_from_sse
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(N, d, o, seed=0):
+    rs = np.random.RandomState(seed)
+    x = rs.rand(N, d) * 2 * np.pi - np.pi
+    y = np.sin(x).sum(axis=1, keepdims=True) * np.ones((1, o)) + 0.02 * rs.randn(N, o)
+    return x, y
+
+
+def _both(op, fn):
+    out = {}
+    for path in (_lib.PATH_FUSED, _lib.PATH_FUSED_DP, _lib.PATH_GENERIC):
+        old = op.set_path(path)
+        try:
+            out[path] = fn()
+        finally:
+            op.set_path(old)
+    return out[_lib.PATH_FUSED], out[_lib.PATH_FUSED_DP], out[_lib.PATH_GENERIC]
+
+
+@pytest.mark.parametrize("dims,N,B,wscale", [((1, 64, 64, 64, 1), 4096, 64, 0.1), ((1, 64, 64, 1), 300, 5, 1.0),
+                                             ((3, 64, 64, 64, 64, 2), 257, 3, 0.3), ((4, 64, 64, 4), 64, 2, 3.0),
+                                             ((2, 64, 64, 64, 1), 1000, 9, 1e-3), ((1, 50, 50, 50, 1), 333, 4, 0.2)],
+                         ids=["cfg2", "2hid", "4hid_d3_o2", "d4_o4_bigw", "tinyw", "padded50"])
+def test_matches_oracle_and_float64_kernels(dims, N, B, wscale):
+    x, y = _data(N, dims[0], dims[-1])
+    arch = MLPArch(dims, "tanh")
+    rs = np.random.RandomState(sum(dims) + N)
+    W = wscale * rs.randn(B, arch.nparams)
+    W[0, : arch.nparams // 3] *= 1e-6                                   # rows with very different scales in one chain
+    op = BatchedMLP(arch, x, y)
+    assert op.path(B, N, False) == _lib.PATH_FUSED
+    (s8, p8), (sd, pd), (sg, pg) = _both(op, lambda: tuple(t.cpu().numpy() for t in op.sse_pred(W)))
+    np.testing.assert_allclose(s8, sd, rtol=1e-11)
+    np.testing.assert_allclose(s8, sg, rtol=1e-11)
+    scale = np.abs(pg).max()
+    assert np.abs(p8 - pg).max() <= 1e-11 * scale and np.abs(p8 - pd).max() <= 1e-11 * scale
+    # parts (what the device samplers consume) sum to the same SSE
+    np.testing.assert_allclose(op.sse_parts(W).cpu().numpy().sum(axis=1), s8, rtol=1e-13)
+    mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, "tanh"))
+    yd = [v for v in y]
+    for b in range(min(B, 3)):
+        ref = mlp_ref.logpost(mod, W[b], x, yd, 0.02)
+        got = -neg_log_post_from_sse(s8[b], N, 0.02)
+        assert abs(got - ref) <= 1e-11 * abs(ref), (b, got, ref)
+    err8, errd = np.abs(p8 - pg).max() / scale, np.abs(pd - pg).max() / scale
+    print(f"max |pred - layerwise| / max|pred|: int8 slices {err8:.2e}, f64 MFMA {errd:.2e}")
+
+
+def test_row_subsets_and_ragged_tail():
+    dims = (2, 64, 64, 64, 1)
+    x, y = _data(777, 2, 1, seed=3)
+    arch = MLPArch(dims, "tanh")
+    rs = np.random.RandomState(5)
+    W = 0.2 * rs.randn(6, arch.nparams)
+    idx = rs.randint(0, 777, size=(6, 403))
+    op = BatchedMLP(arch, x, y)
+    (s8, p8), (sd, pd), (sg, pg) = _both(op, lambda: tuple(t.cpu().numpy() for t in op.sse_pred(W, row_idx=idx)))
+    np.testing.assert_allclose(s8, sg, rtol=1e-11)
+    np.testing.assert_allclose(p8, pg, rtol=0, atol=1e-11 * np.abs(pg).max())
+    # determinism: two launches, same bits
+    s8b = op.sse(W, row_idx=idx).cpu().numpy()
+    assert np.array_equal(s8b, s8)
+
+
+@pytest.mark.parametrize("where", ["weight_nan", "weight_inf", "weight_huge", "bias_nan", "x_nan", "x_inf", "y_nan", "w0_inf"])
+def test_exceptional_values_follow_the_layerwise_kernels(where):
+    dims = (1, 64, 64, 64, 1)
+    arch = MLPArch(dims, "tanh")
+    x, y = _data(200, 1, 1, seed=1)
+    rs = np.random.RandomState(2)
+    W = 0.2 * rs.randn(3, arch.nparams)
+    off_w1 = 64 + 64 + 5 * 64 + 7                                        # an entry of the first hidden matrix
+    if where == "weight_nan": W[1, off_w1] = np.nan
+    if where == "weight_inf": W[1, off_w1] = np.inf
+    if where == "weight_huge": W[1, off_w1] = 1e200
+    if where == "bias_nan": W[1, 64 + 3] = np.nan
+    if where == "w0_inf": W[1, 3] = -np.inf
+    if where == "x_nan": x[17, 0] = np.nan
+    if where == "x_inf": x[150, 0] = -np.inf
+    if where == "y_nan": y[17, 0] = np.nan
+    op = BatchedMLP(arch, x, y)
+    (s8, p8), (sd, pd), (sg, pg) = _both(op, lambda: tuple(t.cpu().numpy() for t in op.sse_pred(W)))
+    assert np.array_equal(np.isnan(s8), np.isnan(sg)) and np.array_equal(np.isnan(p8), np.isnan(pg))
+    fin = np.isfinite(pg)
+    np.testing.assert_allclose(p8[fin], pg[fin], rtol=1e-10, atol=1e-11)
+    ok = np.isfinite(sg)
+    np.testing.assert_allclose(s8[ok], sg[ok], rtol=1e-11)
+    assert np.array_equal(np.isinf(s8), np.isinf(sg))
+
+
+def test_amcmc_acceptance_does_not_depend_on_the_kernel():
+    """A host AMCMC chain (reference-exact sampler) on the cfg2 network with the log-posterior from the int8-slice kernel
+    and from the float64-MFMA kernel: same acceptance indices, states equal to 1e-9."""
+    dims = (1, 64, 64, 64, 1)
+    arch = MLPArch(dims, "tanh")
+    x, y = _data(512, 1, 1, seed=4)
+    op = BatchedMLP(arch, x, y)
+    sigma, C, nmcmc = 0.05, 4, 250
+    res = {}
+    for path in (_lib.PATH_FUSED, _lib.PATH_FUSED_DP):
+        op.set_path(path)
+        mc = AMCMC(gamma=0.01, t0=100, tadapt=1000)
+        mc.setLogPostBatch(lambda Wc: -neg_log_post_from_sse(op.sse(Wc).cpu().numpy(), 512, sigma), None)
+        rngs = [np.random.RandomState(40 + c) for c in range(C)]
+        ini = np.stack([0.1 * np.random.RandomState(90 + c).randn(arch.nparams) for c in range(C)])
+        res[path] = mc.run(nmcmc, ini, rngs=rngs, verbose=False)
+    op.set_path(_lib.PATH_AUTO)
+    a, b = res[_lib.PATH_FUSED], res[_lib.PATH_FUSED_DP]
+    moved = lambda r: (np.asarray(r['chain'])[:, 1:] != np.asarray(r['chain'])[:, :-1]).any(axis=2)
+    assert np.array_equal(moved(a), moved(b))
+    assert 0.0 < moved(a).mean() < 1.0
+    np.testing.assert_allclose(a['chain'], b['chain'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(a['logpost'], b['logpost'], rtol=1e-11)
+
+
+def test_path_override_is_per_operator():
+    """qn_mlp_desc_set_path acts on one descriptor: two operators in one process keep their own choice."""
+    dims = (1, 64, 64, 64, 1)
+    arch = MLPArch(dims, "tanh")
+    x, y = _data(128, 1, 1)
+    a, b = BatchedMLP(arch, x, y), BatchedMLP(arch, x, y)
+    assert a.set_path(_lib.PATH_GENERIC) == _lib.PATH_AUTO
+    assert a.path(8, 128, False) == _lib.PATH_GENERIC and b.path(8, 128, False) == _lib.PATH_FUSED
+    assert b.set_path(_lib.PATH_FUSED_DP) == _lib.PATH_AUTO and a.set_path(_lib.PATH_AUTO) == _lib.PATH_GENERIC
+    W = 0.1 * np.random.RandomState(0).randn(8, arch.nparams)
+    np.testing.assert_allclose(a.sse(W).cpu().numpy(), b.sse(W).cpu().numpy(), rtol=1e-11)

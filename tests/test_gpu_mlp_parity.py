@@ -21,7 +21,7 @@ def paths_for(op, B, Nb, grad):
     out = [_lib.PATH_GENERIC]
     old = op.set_path(_lib.PATH_AUTO)
     if op.path(B, Nb, grad) == _lib.PATH_FUSED:
-        out.append(_lib.PATH_FUSED)
+        out += [_lib.PATH_FUSED, _lib.PATH_FUSED_DP]      # (64-wide tanh forwards: sliced int8 products / float64 MFMA)
     op.set_path(old)
     return out
 
