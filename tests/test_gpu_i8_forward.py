@@ -8,7 +8,6 @@ import torch
 
 from oracle import mlp_ref
 from quinn_amd import _lib
-from quinn_amd.mcmc.admcmc import AMCMC
 from quinn_amd.ops import BatchedMLP, MLPArch, neg_log_post_from_sse
 
 pytestmark = pytest.mark.gpu
@@ -103,19 +102,22 @@ def test_exceptional_values_follow_the_layerwise_kernels(where):
     assert np.array_equal(np.isinf(s8), np.isinf(sg))
 
 
-def test_amcmc_acceptance_does_not_depend_on_the_kernel():
-    """A host AMCMC chain (reference-exact sampler) on the cfg2 network with the log-posterior from the int8-slice kernel
-    and from the float64-MFMA kernel: same acceptance indices, states equal to 1e-9."""
+def test_mh_acceptance_does_not_depend_on_the_kernel():
+    """Host HMC chains (the reference-exact stepper, quinn/mcmc/mcmc.py:65-85) on the cfg2 network with the proposal's
+    log-posterior from the int8-slice kernel and from the float64-MFMA kernel: same acceptance indices, states equal to
+    1e-9.  (The host AMCMC cannot run at p = 8513: numpy's multivariate_normal factors a p x p matrix per draw.)"""
+    from quinn_amd.mcmc.hmc import HMC
     dims = (1, 64, 64, 64, 1)
     arch = MLPArch(dims, "tanh")
     x, y = _data(512, 1, 1, seed=4)
     op = BatchedMLP(arch, x, y)
-    sigma, C, nmcmc = 0.05, 4, 250
+    sigma, C, nmcmc = 0.05, 4, 120
     res = {}
     for path in (_lib.PATH_FUSED, _lib.PATH_FUSED_DP):
         op.set_path(path)
-        mc = AMCMC(gamma=0.01, t0=100, tadapt=1000)
-        mc.setLogPostBatch(lambda Wc: -neg_log_post_from_sse(op.sse(Wc).cpu().numpy(), 512, sigma), None)
+        mc = HMC(epsilon=2e-4, L=3)
+        mc.setLogPostBatch(lambda Wc: -neg_log_post_from_sse(op.sse(Wc).cpu().numpy(), 512, sigma),
+                           lambda Wc: -(0.5 * op.sse_grad(Wc)[1].cpu().numpy() / sigma ** 2))
         rngs = [np.random.RandomState(40 + c) for c in range(C)]
         ini = np.stack([0.1 * np.random.RandomState(90 + c).randn(arch.nparams) for c in range(C)])
         res[path] = mc.run(nmcmc, ini, rngs=rngs, verbose=False)
@@ -123,9 +125,11 @@ def test_amcmc_acceptance_does_not_depend_on_the_kernel():
     a, b = res[_lib.PATH_FUSED], res[_lib.PATH_FUSED_DP]
     moved = lambda r: (np.asarray(r['chain'])[:, 1:] != np.asarray(r['chain'])[:, :-1]).any(axis=2)
     assert np.array_equal(moved(a), moved(b))
-    assert 0.0 < moved(a).mean() < 1.0
+    assert 0.05 < moved(a).mean() < 1.0, moved(a).mean()
     np.testing.assert_allclose(a['chain'], b['chain'], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(a['logpost'], b['logpost'], rtol=1e-11)
+    fin = np.isfinite(b['alphas']) & (b['alphas'] < 1e300)
+    np.testing.assert_allclose(a['alphas'][fin], b['alphas'][fin], rtol=1e-6)
 
 
 def test_path_override_is_per_operator():
