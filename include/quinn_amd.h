@@ -250,7 +250,8 @@ int qn_debug_tanh(const double* x, double* y, int64_t n, void* stream);
  * (no NaN handling; same values for every non-NaN input). */
 int qn_debug_tanh_finite(const double* x, double* y, int64_t n, void* stream);
 /* Diagnostic: the table-assisted tanh of the fused kernels (tanh(n/16) from LDS + a short polynomial;
- * nansafe != 0: NaN-propagating variant). */
+ * nansafe = 1: NaN-propagating variant, 0: the variant for arguments that cannot be NaN; 2: the absolute-accuracy variant
+ * of the int8-slice forward kernel (tanh(n/64) table, arguments that cannot be NaN). */
 int qn_debug_tanh_table(const double* x, double* y, int64_t n, int nansafe, void* stream);
 
 const char* qn_last_error(void);

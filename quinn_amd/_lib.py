@@ -33,7 +33,7 @@ def build(force=False, verbose=False):
     """Compile the HIP sources for gfx950 into quinn_amd/lib/libquinn_amd.so (hipcc
     cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "qn_common.h"), os.path.join(CSRC, "qn_math.h"), os.path.join(CSRC, "qn_tanh_table.h"), os.path.join(CSRC, "qn_fused_args.h"), os.path.join(_HERE, "..", "include", "quinn_amd.h")]
+    deps = srcs + [os.path.join(CSRC, "qn_common.h"), os.path.join(CSRC, "qn_math.h"), os.path.join(CSRC, "qn_tanh_table.h"), os.path.join(CSRC, "qn_tanh_table64.h"), os.path.join(CSRC, "qn_fused_args.h"), os.path.join(_HERE, "..", "include", "quinn_amd.h")]
     if not force and os.path.exists(LIBPATH):
         if os.path.getmtime(LIBPATH) >= max(os.path.getmtime(d) for d in deps):
             return LIBPATH

@@ -560,6 +560,13 @@ __global__ void k_tanh_f64_tab(const double* __restrict__ x, double* __restrict_
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = qn_tanh_f64_tab<NANSAFE>(x[i], tab);
 }
+__global__ void k_tanh_f64_tab64(const double* __restrict__ x, double* __restrict__ y, int64_t n) {
+    __shared__ double tab[QN_TANH64_LDS_DOUBLES];
+    qn_tanh_table64_stage(tab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = qn_tanh_f64_tab64(x[i], tab);
+}
 int debug_tanh(const char* fn, int variant, const double* x, double* y, int64_t n, void* stream) {
     if (!x || !y || n <= 0) {
         qn_set_error("%s: bad argument", fn);
@@ -571,7 +578,8 @@ int debug_tanh(const char* fn, int variant, const double* x, double* y, int64_t 
     if (variant == 0) hipLaunchKernelGGL(k_tanh_f64<true>, grid, dim3(256), 0, st, x, y, n);
     else if (variant == 1) hipLaunchKernelGGL(k_tanh_f64<false>, grid, dim3(256), 0, st, x, y, n);
     else if (variant == 2) hipLaunchKernelGGL(k_tanh_f64_tab<true>, grid, dim3(256), 0, st, x, y, n);
-    else hipLaunchKernelGGL(k_tanh_f64_tab<false>, grid, dim3(256), 0, st, x, y, n);
+    else if (variant == 3) hipLaunchKernelGGL(k_tanh_f64_tab<false>, grid, dim3(256), 0, st, x, y, n);
+    else hipLaunchKernelGGL(k_tanh_f64_tab64, grid, dim3(256), 0, st, x, y, n);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }
@@ -584,5 +592,5 @@ extern "C" int qn_debug_tanh_finite(const double* x, double* y, int64_t n, void*
     return debug_tanh("qn_debug_tanh_finite", 1, x, y, n, stream);
 }
 extern "C" int qn_debug_tanh_table(const double* x, double* y, int64_t n, int nansafe, void* stream) {
-    return debug_tanh("qn_debug_tanh_table", nansafe ? 2 : 3, x, y, n, stream);
+    return debug_tanh("qn_debug_tanh_table", nansafe == 2 ? 4 : (nansafe ? 2 : 3), x, y, n, stream);
 }

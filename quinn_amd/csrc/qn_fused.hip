@@ -1082,11 +1082,20 @@ constexpr int G_FWD = 2;
 
 bool streams(const qn_desc* d, int want_grad) { return !want_grad && d->nlayers >= 2 && d->dims[1] == HS; }
 
+// the forward of 64-wide tanh networks runs as sliced int8 products (qn_fused_i8.hip) unless the descriptor asks for
+// the float64-MFMA kernels (QN_PATH_FUSED_DP)
+bool uses_i8(const qn_desc* d, int want_grad) {
+    int H, nhid;
+    return !want_grad && d->path != QN_PATH_FUSED_DP && uniform_hidden(d, &H, &nhid) &&
+           qn_fused_i8_applies(H, nhid, d->act, d->dims[0], d->dims[d->nlayers]);
+}
+
 void plan(const qn_desc* d, int B, int Nb, int want_grad, FusedArgs* a) {
     // rows one workgroup covers per iteration; target workgroups per chip: 2/CU forward, 1/CU backward
     // (and streaming forward: its 128 KB matrix buffer leaves room for one workgroup per CU)
     const bool stream = streams(d, want_grad);
-    const int rows_it = want_grad ? ROWS_IT : (stream ? (NTS / 64) * 16 : (WG / 64) * 16 * G_FWD);
+    int rows_it = want_grad ? ROWS_IT : (stream ? (NTS / 64) * 16 : (WG / 64) * 16 * G_FWD);
+    if (uses_i8(d, want_grad)) rows_it = qn_fused_i8_rows_per_iteration();
 #ifndef QN_FWD_TARGET
 #define QN_FWD_TARGET 512
 #endif
@@ -1231,9 +1240,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
     (void)hipGetLastError();
     if (!want_grad) {
         fwd_fn kern = pick_fwd(H, a.act, padded_d(a.d), a.o);
-        // 64-wide tanh networks: the hidden GEMMs as sliced exact products on the int8 matrix pipe (qn_fused_i8.hip),
-        // unless the descriptor asks for the float64-MFMA kernels (QN_PATH_FUSED_DP)
-        if (d->path != QN_PATH_FUSED_DP && qn_fused_i8_applies(H, nhid, a.act, a.d, a.o)) {
+        if (uses_i8(d, want_grad)) {
             kern = qn_fused_i8_kernel(a.d, a.o);
             lds_bytes = qn_fused_i8_lds_bytes(a.d, nhid);
         }

@@ -14,6 +14,7 @@ using qn_fwd_fn = void (*)(FusedArgs, const double*, const double*, const double
 
 // sliced int8-product forward for 64-wide tanh networks (qn_fused_i8.hip): same grid, block and partial-sum
 // conventions as k_fused_fwd_f64<64, 2, tanh, DP, 256>
+int qn_fused_i8_rows_per_iteration();       // data rows one workgroup covers per loop iteration
 bool qn_fused_i8_applies(int H, int nhid, int act, int d, int o);
 size_t qn_fused_i8_lds_bytes(int d, int nhid);
 qn_fwd_fn qn_fused_i8_kernel(int d, int o);

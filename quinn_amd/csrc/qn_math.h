@@ -119,6 +119,37 @@ __device__ __forceinline__ double qn_tanh_f64_tab(double x, const double* __rest
     return __hiloint2double(rh, __double2loint(r));
 }
 
+// ---------------------------------------------------------------------------------------------
+// tanh to ABSOLUTE accuracy ~2^-51 for arguments that cannot be NaN: the activation of the int8-slice forward kernel
+// (qn_fused_i8.hip), whose next step rounds the result to a multiple of 2^-46 anyway.  14 DP instructions + v_rcp_f64
+// (qn_tanh_f64_tab: 18 + v_rcp): a table of tanh(n / 64) (1281 values, 10 KB of LDS) leaves |b| <= 1/128, so
+//   tanh(b) = b + b^3 (-1/3 + 2/15 b^2)                 (next term 17/315 b^7 < 2^-53),
+//   tanh(a + b) = (T + t) / (1 + T t),  |T t| <= 2^-7:  v_rcp_f64 (2^-24) + one cubic Newton step (2^-72), one product.
+// Relative error of the quotient ~1.5 ulp; no residual correction (it bought the last half ulp of qn_tanh_f64_tab).
+#include "qn_tanh_table64.h"
+static __device__ const double qn_tanh_table64_g[QN_TANH_TAB64_N] = {QN_TANH_TAB64_VALUES};
+#define QN_TANH64_LDS_DOUBLES (QN_TANH_TAB64_N + 1)
+__device__ __forceinline__ void qn_tanh_table64_stage(double* lds_tab, int tid, int nthreads) {
+    for (int e = tid; e < QN_TANH_TAB64_N; e += nthreads) lds_tab[e] = qn_tanh_table64_g[e];
+}
+__device__ __forceinline__ double qn_tanh_f64_tab64(double x, const double* __restrict__ lds_tab) {
+    const double kClamp = 20.0;
+    double ax;
+    asm("v_min_f64 %0, |%1|, %2" : "=v"(ax) : "v"(x), "s"(kClamp));
+    const double kMagic = 6755399441055744.0;                          // 1.5 * 2^52
+    const double zm = fma(ax, 64.0, kMagic);                           // 64|x| rounded to an integer n in 0..1280
+    const double T = lds_tab[__double2loint(zm)];                      // tanh(n / 64)
+    const double b = fma(zm - kMagic, -0.015625, ax);                  // exact, |b| <= 1/128
+    const double b2 = b * b;
+    const double tb = fma(b * b2, fma(b2, 1.33333333333333333e-01, -3.33333333333333333e-01), b);
+    const double num = T + tb;
+    const double den = fma(T, tb, 1.0);                                // in [0.992, 1.008]
+    const double y0 = __builtin_amdgcn_rcp(den);                       // 2^-24
+    const double e0 = fma(-den, y0, 1.0);
+    const double y1 = fma(y0, fma(e0, e0, e0), y0);                    // cubic step: 2^-72
+    return __builtin_copysign(num * y1, x);
+}
+
 // tanh for float32: 1 - 2 / (exp(2|x|) + 1) on the hardware exp2 / rcp (7 instructions, absolute error
 // ~2e-7, i.e. float32-level; NaN propagates through v_exp_f32).
 __device__ __forceinline__ float qn_tanh_f32(float x) {

@@ -86,3 +86,26 @@ def test_table_assisted_tanh_ulp_error(nansafe):
     _lib.check(L.qn_debug_tanh_table(t.data_ptr(), u.data_ptr(), t.numel(), nansafe, None), "qn_debug_tanh_table")
     d = (u[1:] - u[:-1]).cpu().numpy()
     assert (d >= -2.3e-16).all()                                         # never decreases by more than ~1 ulp
+
+
+def test_absolute_accuracy_tanh_of_the_int8_slice_kernel():
+    """qn_tanh_f64_tab64 (table of tanh(n/64), no residual correction): absolute error far below the 2^-47 half step to
+    which the int8-slice forward rounds its activations; exact at 0 and +-inf, odd, bounded by 1."""
+    rs = np.random.RandomState(3)
+    grid = np.arange(0, 1281) / 64.0
+    xs = np.concatenate([rs.uniform(-20, 20, 300000), rs.uniform(-1, 1, 200000), rs.uniform(-1e-3, 1e-3, 50000),
+                         10.0 ** rs.uniform(-300, -3, 20000), grid, -grid, grid + 1 / 128, np.nextafter(grid + 1 / 128, 40),
+                         np.array([0.0, -0.0, 19.0, 19.07, 25.0, -40.0, 1e300, -1e300, np.inf, -np.inf, 5e-324])])
+    x = torch.tensor(xs, device="cuda")
+    y = torch.empty_like(x)
+    L = _lib.lib()
+    _lib.check(L.qn_debug_tanh_table(x.data_ptr(), y.data_ptr(), x.numel(), 2, None), "qn_debug_tanh_table")
+    torch.cuda.synchronize()
+    got = y.cpu().numpy()
+    ref = _ref_tanh(xs)
+    err = np.abs(got.astype(np.longdouble) - ref).astype(np.float64)
+    assert err.max() < 2.0 ** -51, (err.max(), xs[np.argmax(err)])
+    ulp = np.spacing(np.abs(ref.astype(np.float64)))
+    assert np.max(err / np.maximum(ulp, 5e-324)) < 4.0
+    assert got[np.where(xs == np.inf)[0][0]] == 1.0 and got[np.where(xs == -np.inf)[0][0]] == -1.0
+    assert (np.abs(got) <= 1.0).all() and (np.sign(got) == np.sign(xs)).all()
