@@ -46,7 +46,7 @@ from ..ops import BatchedMLP
 
 class DeviceAMCMC:
     def __init__(self, op: BatchedMLP, sigma, gamma=0.1, t0=100, tadapt=1000, cov_ini=None, seed=0,
-                 use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=True, groups=1):
+                 use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=True, groups=1, max_rows=4096):
         if op.dtype != "float64":
             raise NotImplementedError("the device AMCMC engine runs the float64 operator")
         self.op, self.sigma = op, float(sigma)
@@ -56,6 +56,12 @@ class DeviceAMCMC:
         self.seed = int(seed) & (2 ** 63 - 1)
         self.use_graph = use_graph
         self.max_history_bytes = int(max_history_bytes)
+        # bound on the stored distinct states per chain (rows of p float32).  When a chain's history could overflow
+        # before the next adaptation it is THINNED in place: every second row is dropped and its multiplicity goes to
+        # the row of the following accepted state (one proposal step away), so the weights still add up to the number
+        # of samples and the mean (kept exactly, `sumx`) is untouched; cost and memory of the adapted proposal stay
+        # bounded however long the chain runs (`_thin_history`)
+        self.max_rows = int(max_rows)
         # next step's proposal written by the accept kernel (bit-identical to the separate proposal kernel; A/B on one
         # box: 2-3 % slower while the accept kernel ran one workgroup per chain, 1 % faster now that it spreads a
         # chain over several)
@@ -137,14 +143,14 @@ class DeviceAMCMC:
         # ---- several groups of chains side by side
         bounds = [C * g // G for g in range(G + 1)]
         pstride = (p + 3) // 4 * 4
-        if C * (nmcmc + 1) * pstride * 4 > self.max_history_bytes:
-            raise MemoryError(f"state history {C} x {nmcmc + 1} x {pstride} float32 exceeds max_history_bytes="
-                              f"{self.max_history_bytes}: run fewer steps per call or raise the limit")
+        if C * self._kcap(nmcmc) * pstride * 4 > self.max_history_bytes:
+            raise MemoryError(f"state history {C} x {self._kcap(nmcmc)} x {pstride} float32 exceeds max_history_bytes="
+                              f"{self.max_history_bytes}: lower max_rows or raise the limit")
         if self._subs is None or [e.chain0 - self.chain0 for e in self._subs[0]] != bounds[:-1]:
             op = self.op
             engs = [DeviceAMCMC(BatchedMLP(op.arch, op.X, op.Y, device=op.device, dtype=op.dtype), self.sigma, self.gamma,
                                 self.t0, self.tadapt, self.cov_ini, self.seed, self.use_graph, self.max_history_bytes,
-                                self.chain0 + bounds[g], self.fuse_propose) for g in range(G)]
+                                self.chain0 + bounds[g], self.fuse_propose, max_rows=self.max_rows) for g in range(G)]
             self._subs = (engs, [torch.cuda.Stream(device=self.dev) for _ in range(G)])
         engs, streams = self._subs
         chain = torch.empty(C, nmcmc + 1, p, dtype=torch.float64, device=self.dev) if store_chain else None
@@ -168,6 +174,48 @@ class DeviceAMCMC:
         out['chain'] = chain
         return out
 
+    def _kcap(self, nmcmc):
+        """Rows of the history buffer: every accepted move of the run if that fits max_rows, else max_rows (which must
+        hold two windows between thinning checks: after a thinning at most half the rows are in use)."""
+        if nmcmc + 1 <= self.max_rows:
+            return nmcmc + 1
+        need = 2 * (self.tadapt + 2)
+        if self.max_rows < need:
+            raise ValueError(f"max_rows = {self.max_rows} is too small for tadapt = {self.tadapt}: need >= {need}")
+        return self.max_rows
+
+    @staticmethod
+    def _thin_history(s, room):
+        """Halve the stored history of every chain that has fewer than `room` free rows (host-synchronising; called once
+        per adaptation window).  Rows of the parity of the CURRENT state's row are kept (so the current state keeps a row
+        of its own: the accept kernel adds its further dwell time there); a dropped row r hands its multiplicity to row
+        r + 1.  New index of row r: (r + 1 - par) // 2."""
+        kcap = s['hist'].shape[1]
+        kc = s['kcur'][s['par']]
+        full = torch.nonzero(kc + 1 + room > kcap).flatten().tolist()          # (the one device->host read)
+        for c in full:
+            k = int(kc[c])
+            par = k & 1
+            h, m = s['hist'][c], s['mult'][c]
+            nk = (k + 1 - par) // 2                                             # new index of the current row
+            src = 2 * torch.arange(nk + 1, device=h.device) + par              # kept rows, ascending
+            mnew = m[src].clone()
+            prev = src - 1
+            ok = prev >= 0
+            mnew[ok] += m[prev[ok]]
+            # in place, ascending: destination j reads source 2 j + par >= j; ranges [lo, 2 lo) never overlap their sources
+            if par:
+                h[0].copy_(h[1])
+            lo = 1
+            while lo <= nk:
+                hi = min(2 * lo, nk + 1)
+                h[lo:hi].copy_(h[2 * lo + par:2 * (hi - 1) + par + 1:2])
+                lo *= 2
+            m.zero_()
+            m[:nk + 1] = mnew
+            s['kcur'][s['par'], c] = nk
+        return len(full)
+
     def _run_gen(self, nmcmc, param_ini, store_chain=True, verbose=False, chain_out=None):
         """The run as a generator: yields after every block of at most TB enqueued steps (nothing is awaited)."""
         dev, f64 = self.dev, torch.float64
@@ -176,11 +224,12 @@ class DeviceAMCMC:
         n = self.op.N
         const = (n / 2) * np.log(2 * np.pi) + n * np.log(self.sigma)
         cur_lp = -(0.5 * self.op.sse(cur) / self.sigma ** 2 + const)
-        # history of distinct states: one row per accepted move at most -> nmcmc + 1 rows always suffice
-        kcap, pstride = nmcmc + 1, (p + 3) // 4 * 4
+        # history of distinct states: one row per accepted move at most -> nmcmc + 1 rows always suffice; capped at
+        # max_rows (thinned when it could fill up before the next adaptation)
+        kcap, pstride = self._kcap(nmcmc), (p + 3) // 4 * 4
         if C * kcap * pstride * 4 > self.max_history_bytes:
             raise MemoryError(f"state history {C} x {kcap} x {pstride} float32 exceeds max_history_bytes="
-                              f"{self.max_history_bytes}: run fewer steps per call or raise the limit")
+                              f"{self.max_history_bytes}: lower max_rows or raise the limit")
         # per-chain scalars the accept kernel maintains are double-buffered by step parity ([2, C]; slot `par` is current)
         s = {'cur': cur, 'cur_lp': torch.stack([cur_lp, cur_lp]), 'best': cur.clone(),
              'best_lp': torch.stack([cur_lp, cur_lp]), 'x0': cur.clone(), 'par': 0,
@@ -253,6 +302,10 @@ class DeviceAMCMC:
         graphs = {}
         i = 0
         while i < nmcmc:
+            if kcap < nmcmc + 1 and i > 0:
+                # room for every step up to the next check (each may append a row); thin the chains that lack it
+                while self._thin_history(s, min(nmcmc, (i // self.tadapt + 1) * self.tadapt) - i + 1):
+                    pass
             if i > self.t0 and i % self.tadapt == 0:
                 # adaptation (admcmc.py:66-67) = snapshot of the history x_0..x_i: n = i + 1 samples
                 scale = self.gamma * 2.4 ** 2 / p
@@ -298,5 +351,6 @@ class DeviceAMCMC:
             i += nrun
             if verbose:
                 print('%d / %d completed, acceptance rate %lg' % (i, nmcmc, float(s['nacc'].double().mean()) / i))
+        self.last_state = s            # (tests / diagnostics: history rows, multiplicities, running sums)
         return {'chain': s['chain'], 'mapparams': s['best'], 'maxpost': s['best_lp'][s['par']].clone(),
                 'accrate': s['nacc'].double() / max(nmcmc, 1), 'logpost': s['lps'], 'alphas': s['alphas']}

@@ -24,7 +24,16 @@ def _no_gpu_yet():
 
 
 def _json_lines(text):
-    return [json.loads(ln) for ln in text.splitlines() if ln.startswith("{")]
+    """Every top-level JSON object in `text` (two ranks may print onto one line)."""
+    dec, out, i = json.JSONDecoder(), [], text.find("{")
+    while i >= 0:
+        try:
+            obj, end = dec.raw_decode(text, i)
+            out.append(obj)
+            i = text.find("{", end)
+        except json.JSONDecodeError:
+            i = text.find("{", i + 1)
+    return out
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])

@@ -243,6 +243,49 @@ def test_graph_replay_with_odd_stretches_equals_direct_launches():
             assert torch.equal(a[k], b[k]), (kw, k)
 
 
+def test_bounded_history_keeps_the_proposal_covariance():
+    """`max_rows` caps the stored distinct states: the history is thinned in place (every second row dropped, its
+    multiplicity handed to the next accepted state) whenever a chain could overflow before the next adaptation.  The
+    covariance the adapted proposal is drawn from (weighted rows around the exact running mean, admcmc.py:52-67) must stay
+    within 5 % of numpy's covariance of the FULL chain, the multiplicities must still add up to the number of samples,
+    and the run must behave like the unbounded one."""
+    from quinn_amd.mcmc.device_amcmc import DeviceAMCMC
+    from quinn_amd.ops import MLPArch, BatchedMLP
+    x, y = _problem(3)
+    arch = MLPArch((1, 4, 1), "tanh")                                        # p = 13
+    op = BatchedMLP(arch, x, y)
+    C, nmcmc = 6, 3000
+    ini = np.stack([0.3 * np.random.RandomState(700 + c).randn(arch.nparams) for c in range(C)])
+    kw = dict(gamma=0.2, t0=100, tadapt=100, seed=8)
+    eng = DeviceAMCMC(op, 0.3, max_rows=256, **kw)
+    r = eng.run(nmcmc, ini)
+    s = eng.last_state
+    assert s['hist'].shape[1] == 256                                         # bounded buffer, 3000 steps
+    chain = r['chain'].cpu().numpy()
+    acc = r['accrate'].cpu().numpy()
+    assert np.all(acc * nmcmc + 1 > 256)                                     # more accepted moves than rows: thinning ran
+    kcur = s['kcur'][s['par']].cpu().numpy()
+    mult, hist = s['mult'].cpu().numpy(), s['hist'].cpu().numpy().astype(np.float64)
+    x0, sumx = s['x0'].cpu().numpy(), s['sumx'].cpu().numpy()
+    for c in range(C):
+        K = kcur[c] + 1
+        assert K <= 256 and mult[c, :K].sum() == nmcmc + 1 and (mult[c, K:] == 0).all() and (mult[c, :K] > 0).all()
+        np.testing.assert_allclose(hist[c, kcur[c], :13] + x0[c], chain[c, -1], rtol=1e-6, atol=1e-6)   # current state keeps its row
+        mean = sumx[c] / (nmcmc + 1)
+        np.testing.assert_allclose(mean + x0[c], chain[c].mean(axis=0), rtol=1e-9, atol=1e-10)
+        d = hist[c, :K, :13] - mean
+        cov = (d * mult[c, :K, None]).T @ d / nmcmc
+        ref = np.cov(chain[c].T)
+        assert np.linalg.norm(cov - ref) <= 0.05 * np.linalg.norm(ref), (c, np.linalg.norm(cov - ref) / np.linalg.norm(ref))
+        assert abs(np.trace(cov) - np.trace(ref)) <= 0.05 * np.trace(ref)
+    full = DeviceAMCMC(op, 0.3, max_rows=1 << 20, **kw).run(nmcmc, ini)
+    assert abs(full['accrate'].mean().item() - acc.mean()) < 0.05
+    lo, hi = full['logpost'][:, nmcmc // 2:].mean().item(), r['logpost'][:, nmcmc // 2:].mean().item()
+    assert abs(lo - hi) < 1.0, (lo, hi)
+    with pytest.raises(ValueError):
+        DeviceAMCMC(op, 0.3, max_rows=100, **kw).run(nmcmc, ini)             # two windows must fit
+
+
 def test_device_engine_matches_host_sampler_in_distribution():
     x, y = _problem(1)
     torch.manual_seed(1)
