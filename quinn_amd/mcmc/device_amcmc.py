@@ -56,11 +56,10 @@ class DeviceAMCMC:
         self.seed = int(seed) & (2 ** 63 - 1)
         self.use_graph = use_graph
         self.max_history_bytes = int(max_history_bytes)
-        # bound on the stored distinct states per chain (rows of p float32).  When a chain's history could overflow
-        # before the next adaptation it is THINNED in place: every second row is dropped and its multiplicity goes to
-        # the row of the following accepted state (one proposal step away), so the weights still add up to the number
-        # of samples and the mean (kept exactly, `sumx`) is untouched; cost and memory of the adapted proposal stay
-        # bounded however long the chain runs (`_thin_history`)
+        # bound on the stored rows per chain (p float32 each).  When a chain's history could overflow before the next
+        # adaptation it is COMPRESSED in sample space (`_compress_history`: same multiplicity total and mean, scatter
+        # kept up to rank max_rows/4 -- exactly, once max_rows/4 >= p): cost and memory of the adapted proposal stay
+        # bounded however long the chain runs
         self.max_rows = int(max_rows)
         # next step's proposal written by the accept kernel (bit-identical to the separate proposal kernel; A/B on one
         # box: 2-3 % slower while the accept kernel ran one workgroup per chain, 1 % faster now that it spreads a
@@ -176,44 +175,55 @@ class DeviceAMCMC:
 
     def _kcap(self, nmcmc):
         """Rows of the history buffer: every accepted move of the run if that fits max_rows, else max_rows (which must
-        hold two windows between thinning checks: after a thinning at most half the rows are in use)."""
+        hold a compressed history, max_rows/2 + 2 rows, plus one window of new rows between two checks)."""
         if nmcmc + 1 <= self.max_rows:
             return nmcmc + 1
-        need = 2 * (self.tadapt + 2)
+        need = 2 * (self.tadapt + 4)
         if self.max_rows < need:
             raise ValueError(f"max_rows = {self.max_rows} is too small for tadapt = {self.tadapt}: need >= {need}")
         return self.max_rows
 
     @staticmethod
-    def _thin_history(s, room):
-        """Halve the stored history of every chain that has fewer than `room` free rows (host-synchronising; called once
-        per adaptation window).  Rows of the parity of the CURRENT state's row are kept (so the current state keeps a row
-        of its own: the accept kernel adds its further dwell time there); a dropped row r hands its multiplicity to row
-        r + 1.  New index of row r: (r + 1 - par) // 2."""
+    def _compress_history(s, room, p):
+        """Compress the stored history of every chain that has fewer than `room` free rows (host-synchronising; called
+        once per adaptation window) into at most kcap/2 + 2 rows that carry the SAME weighted mean and -- up to rank
+        r = kcap/4 -- the same weighted scatter about it.  With the rows h_i (multiplicities w_i, n_c = sum w_i, mean m_c)
+        of everything but the current state, B = diag(sqrt w)(H - m_c) and Q an orthonormal basis of range(B Omega)
+        (Omega: p x r Gaussian; exact when rank(B) <= r, the best r directions a single pass finds otherwise),
+        R = Q^T B satisfies R^T R ~ B^T B, and the pseudo-states
+            m_c + R_j / sqrt 2,  m_c - R_j / sqrt 2   (multiplicity 1 each, j < r),      m_c   (multiplicity n_c - 2 r)
+        have total multiplicity n_c, mean m_c and scatter R^T R: for the accept / proposal kernels they are ordinary
+        history rows (integer multiplicities adding up to the number of samples; the parallel-axis term of a later,
+        different overall mean comes out by itself).  The current state keeps a row of its own behind them."""
         kcap = s['hist'].shape[1]
+        r = kcap // 4
         kc = s['kcur'][s['par']]
         full = torch.nonzero(kc + 1 + room > kcap).flatten().tolist()          # (the one device->host read)
         for c in full:
-            k = int(kc[c])
-            par = k & 1
-            h, m = s['hist'][c], s['mult'][c]
-            nk = (k + 1 - par) // 2                                             # new index of the current row
-            src = 2 * torch.arange(nk + 1, device=h.device) + par              # kept rows, ascending
-            mnew = m[src].clone()
-            prev = src - 1
-            ok = prev >= 0
-            mnew[ok] += m[prev[ok]]
-            # in place, ascending: destination j reads source 2 j + par >= j; ranges [lo, 2 lo) never overlap their sources
-            if par:
-                h[0].copy_(h[1])
-            lo = 1
-            while lo <= nk:
-                hi = min(2 * lo, nk + 1)
-                h[lo:hi].copy_(h[2 * lo + par:2 * (hi - 1) + par + 1:2])
-                lo *= 2
+            k = int(kc[c])                                                      # current row; rows 0..k-1 are compressed
+            if k <= 2 * r + 1:
+                continue
+            h = s['hist'][c]
+            w = s['mult'][c, :k].to(torch.float32)
+            nc = int(s['mult'][c, :k].sum())
+            H = h[:k, :p]
+            mc = (w[:, None] * H).sum(dim=0) / nc
+            B = w.sqrt()[:, None] * (H - mc)
+            g = torch.Generator(device=h.device)
+            g.manual_seed(12345 + k)
+            Q, _ = torch.linalg.qr(B @ torch.randn(p, r, dtype=torch.float32, device=h.device, generator=g))
+            R = (Q.T @ B) * (0.5 ** 0.5)
+            cur_row, cur_mult = h[k, :p].clone(), s['mult'][c, k].clone()
+            h[0:2 * r:2, :p] = mc + R
+            h[1:2 * r:2, :p] = mc - R
+            h[2 * r, :p] = mc
+            h[2 * r + 1, :p] = cur_row
+            m = s['mult'][c]
             m.zero_()
-            m[:nk + 1] = mnew
-            s['kcur'][s['par'], c] = nk
+            m[:2 * r] = 1
+            m[2 * r] = nc - 2 * r
+            m[2 * r + 1] = cur_mult
+            s['kcur'][s['par'], c] = 2 * r + 1
         return len(full)
 
     def _run_gen(self, nmcmc, param_ini, store_chain=True, verbose=False, chain_out=None):
@@ -303,9 +313,8 @@ class DeviceAMCMC:
         i = 0
         while i < nmcmc:
             if kcap < nmcmc + 1 and i > 0:
-                # room for every step up to the next check (each may append a row); thin the chains that lack it
-                while self._thin_history(s, min(nmcmc, (i // self.tadapt + 1) * self.tadapt) - i + 1):
-                    pass
+                # room for every step up to the next check (each may append a row); compress the chains that lack it
+                self._compress_history(s, min(nmcmc, (i // self.tadapt + 1) * self.tadapt) - i + 1, p)
             if i > self.t0 and i % self.tadapt == 0:
                 # adaptation (admcmc.py:66-67) = snapshot of the history x_0..x_i: n = i + 1 samples
                 scale = self.gamma * 2.4 ** 2 / p

@@ -244,15 +244,15 @@ def test_graph_replay_with_odd_stretches_equals_direct_launches():
 
 
 def test_bounded_history_keeps_the_proposal_covariance():
-    """`max_rows` caps the stored distinct states: the history is thinned in place (every second row dropped, its
-    multiplicity handed to the next accepted state) whenever a chain could overflow before the next adaptation.  The
-    covariance the adapted proposal is drawn from (weighted rows around the exact running mean, admcmc.py:52-67) must stay
-    within 5 % of numpy's covariance of the FULL chain, the multiplicities must still add up to the number of samples,
-    and the run must behave like the unbounded one."""
+    """`max_rows` caps the stored history: whenever a chain could overflow before the next adaptation its rows are
+    compressed in sample space into pseudo-states with the same multiplicity total, the same mean and (up to rank
+    max_rows / 4) the same scatter.  The covariance the adapted proposal is drawn from (weighted rows around the exact
+    running mean, admcmc.py:52-67) must stay within 5 % of numpy's covariance of the FULL chain, and the run must behave
+    like the unbounded one."""
     from quinn_amd.mcmc.device_amcmc import DeviceAMCMC
     from quinn_amd.ops import MLPArch, BatchedMLP
     x, y = _problem(3)
-    arch = MLPArch((1, 4, 1), "tanh")                                        # p = 13
+    arch = MLPArch((1, 4, 1), "tanh")                                        # p = 13 <= max_rows / 4: compression is exact
     op = BatchedMLP(arch, x, y)
     C, nmcmc = 6, 3000
     ini = np.stack([0.3 * np.random.RandomState(700 + c).randn(arch.nparams) for c in range(C)])
@@ -263,17 +263,18 @@ def test_bounded_history_keeps_the_proposal_covariance():
     assert s['hist'].shape[1] == 256                                         # bounded buffer, 3000 steps
     chain = r['chain'].cpu().numpy()
     acc = r['accrate'].cpu().numpy()
-    assert np.all(acc * nmcmc + 1 > 256)                                     # more accepted moves than rows: thinning ran
+    assert np.all(acc * nmcmc + 1 > 256)                                     # more accepted moves than rows: compression ran
     kcur = s['kcur'][s['par']].cpu().numpy()
-    mult, hist = s['mult'].cpu().numpy(), s['hist'].cpu().numpy().astype(np.float64)
-    x0, sumx = s['x0'].cpu().numpy(), s['sumx'].cpu().numpy()
+    mult, x0, sumx = s['mult'].cpu().numpy(), s['x0'].cpu().numpy(), s['sumx'].cpu().numpy()
     for c in range(C):
         K = kcur[c] + 1
+        hist = s['hist'][c, :K, :13].cpu().numpy().astype(np.float64)
         assert K <= 256 and mult[c, :K].sum() == nmcmc + 1 and (mult[c, K:] == 0).all() and (mult[c, :K] > 0).all()
-        np.testing.assert_allclose(hist[c, kcur[c], :13] + x0[c], chain[c, -1], rtol=1e-6, atol=1e-6)   # current state keeps its row
+        np.testing.assert_allclose(hist[kcur[c]] + x0[c], chain[c, -1], rtol=1e-6, atol=1e-6)   # current state keeps its row
         mean = sumx[c] / (nmcmc + 1)
         np.testing.assert_allclose(mean + x0[c], chain[c].mean(axis=0), rtol=1e-9, atol=1e-10)
-        d = hist[c, :K, :13] - mean
+        np.testing.assert_allclose((mult[c, :K, None] * hist).sum(axis=0) / (nmcmc + 1), mean, rtol=1e-4, atol=1e-5)
+        d = hist - mean
         cov = (d * mult[c, :K, None]).T @ d / nmcmc
         ref = np.cov(chain[c].T)
         assert np.linalg.norm(cov - ref) <= 0.05 * np.linalg.norm(ref), (c, np.linalg.norm(cov - ref) / np.linalg.norm(ref))
@@ -283,7 +284,34 @@ def test_bounded_history_keeps_the_proposal_covariance():
     lo, hi = full['logpost'][:, nmcmc // 2:].mean().item(), r['logpost'][:, nmcmc // 2:].mean().item()
     assert abs(lo - hi) < 1.0, (lo, hi)
     with pytest.raises(ValueError):
-        DeviceAMCMC(op, 0.3, max_rows=100, **kw).run(nmcmc, ini)             # two windows must fit
+        DeviceAMCMC(op, 0.3, max_rows=100, **kw).run(nmcmc, ini)             # a compressed history + one window must fit
+
+
+def test_bounded_history_low_rank_regime():
+    """max_rows / 4 < p: the compression keeps the dominant directions of the scatter (one randomised range pass), never
+    more variance than the chain has, and most of it."""
+    from quinn_amd.mcmc.device_amcmc import DeviceAMCMC
+    from quinn_amd.ops import MLPArch, BatchedMLP
+    x, y = _problem(4)
+    arch = MLPArch((1, 16, 16, 1), "tanh")                                   # p = 321 > 64 = max_rows / 4
+    op = BatchedMLP(arch, x, y)
+    C, nmcmc = 3, 2500
+    ini = np.stack([0.3 * np.random.RandomState(720 + c).randn(arch.nparams) for c in range(C)])
+    eng = DeviceAMCMC(op, 0.3, max_rows=256, gamma=0.05, t0=100, tadapt=100, seed=9)
+    r = eng.run(nmcmc, ini)
+    s = eng.last_state
+    chain = r['chain'].cpu().numpy()
+    kcur = s['kcur'][s['par']].cpu().numpy()
+    mult, sumx = s['mult'].cpu().numpy(), s['sumx'].cpu().numpy()
+    assert np.all(r['accrate'].cpu().numpy() * nmcmc + 1 > 256)
+    for c in range(C):
+        K = kcur[c] + 1
+        hist = s['hist'][c, :K, :321].cpu().numpy().astype(np.float64)
+        assert mult[c, :K].sum() == nmcmc + 1
+        d = hist - sumx[c] / (nmcmc + 1)
+        tr = (mult[c, :K, None] * d * d).sum() / nmcmc
+        ref = np.cov(chain[c].T)
+        assert 0.6 * np.trace(ref) <= tr <= 1.001 * np.trace(ref), (tr, np.trace(ref))
 
 
 def test_device_engine_matches_host_sampler_in_distribution():
