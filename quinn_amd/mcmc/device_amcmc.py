@@ -58,7 +58,7 @@ class DeviceAMCMC:
         self.max_history_bytes = int(max_history_bytes)
         # bound on the stored rows per chain (p float32 each).  When a chain's history could overflow before the next
         # adaptation it is COMPRESSED in sample space (`_compress_history`: same multiplicity total and mean, scatter
-        # kept up to rank max_rows/4 -- exactly, once max_rows/4 >= p): cost and memory of the adapted proposal stay
+        # kept up to rank max_rows/8 -- exactly, once max_rows/8 >= p): cost and memory of the adapted proposal stay
         # bounded however long the chain runs
         self.max_rows = int(max_rows)
         # next step's proposal written by the accept kernel (bit-identical to the separate proposal kernel; A/B on one
@@ -175,10 +175,10 @@ class DeviceAMCMC:
 
     def _kcap(self, nmcmc):
         """Rows of the history buffer: every accepted move of the run if that fits max_rows, else max_rows (which must
-        hold a compressed history, max_rows/2 + 2 rows, plus one window of new rows between two checks)."""
+        hold a compressed history, max_rows/4 + 2 rows, plus one window of new rows between two checks)."""
         if nmcmc + 1 <= self.max_rows:
             return nmcmc + 1
-        need = 2 * (self.tadapt + 4)
+        need = (4 * (self.tadapt + 4) + 2) // 3
         if self.max_rows < need:
             raise ValueError(f"max_rows = {self.max_rows} is too small for tadapt = {self.tadapt}: need >= {need}")
         return self.max_rows
@@ -186,44 +186,57 @@ class DeviceAMCMC:
     @staticmethod
     def _compress_history(s, room, p):
         """Compress the stored history of every chain that has fewer than `room` free rows (host-synchronising; called
-        once per adaptation window) into at most kcap/2 + 2 rows that carry the SAME weighted mean and -- up to rank
-        r = kcap/4 -- the same weighted scatter about it.  With the rows h_i (multiplicities w_i, n_c = sum w_i, mean m_c)
-        of everything but the current state, B = diag(sqrt w)(H - m_c) and Q an orthonormal basis of range(B Omega)
-        (Omega: p x r Gaussian; exact when rank(B) <= r, the best r directions a single pass finds otherwise),
-        R = Q^T B satisfies R^T R ~ B^T B, and the pseudo-states
+        once per adaptation window) into 2 r + 2 rows, r = kcap / 8, that carry the SAME weighted mean and -- up to rank
+        r -- the same weighted scatter about it.  With the rows h_i (multiplicities w_i, n_c = sum w_i, mean m_c) of
+        everything but the current state, B = diag(sqrt w)(H - m_c), Y = B Omega (Omega: p x r Gaussian) and the
+        eigen-decomposition Y^T Y = V L V^T, Q = Y V L^-1/2 is an orthonormal basis of range(Y) and
+            R = Q^T B = L^-1/2 V^T (Y^T B)       (r x p),      R^T R ~ B^T B
+        (exactly when rank(B) <= r; the directions a single randomised range pass finds otherwise).  The pseudo-states
             m_c + R_j / sqrt 2,  m_c - R_j / sqrt 2   (multiplicity 1 each, j < r),      m_c   (multiplicity n_c - 2 r)
         have total multiplicity n_c, mean m_c and scatter R^T R: for the accept / proposal kernels they are ordinary
         history rows (integer multiplicities adding up to the number of samples; the parallel-axis term of a later,
-        different overall mean comes out by itself).  The current state keeps a row of its own behind them."""
+        different overall mean comes out by itself).  The current state keeps a row of its own behind them.  All chains
+        that need it are compressed in ONE batch of GEMMs (zero-padded to the longest history) + one batched eigh of
+        r x r matrices."""
         kcap = s['hist'].shape[1]
-        r = kcap // 4
+        r = max(8, kcap // 8)
         kc = s['kcur'][s['par']]
-        full = torch.nonzero(kc + 1 + room > kcap).flatten().tolist()          # (the one device->host read)
-        for c in full:
-            k = int(kc[c])                                                      # current row; rows 0..k-1 are compressed
-            if k <= 2 * r + 1:
-                continue
-            h = s['hist'][c]
-            w = s['mult'][c, :k].to(torch.float32)
-            nc = int(s['mult'][c, :k].sum())
-            H = h[:k, :p]
-            mc = (w[:, None] * H).sum(dim=0) / nc
-            B = w.sqrt()[:, None] * (H - mc)
-            g = torch.Generator(device=h.device)
-            g.manual_seed(12345 + k)
-            Q, _ = torch.linalg.qr(B @ torch.randn(p, r, dtype=torch.float32, device=h.device, generator=g))
-            R = (Q.T @ B) * (0.5 ** 0.5)
-            cur_row, cur_mult = h[k, :p].clone(), s['mult'][c, k].clone()
-            h[0:2 * r:2, :p] = mc + R
-            h[1:2 * r:2, :p] = mc - R
-            h[2 * r, :p] = mc
-            h[2 * r + 1, :p] = cur_row
-            m = s['mult'][c]
-            m.zero_()
-            m[:2 * r] = 1
-            m[2 * r] = nc - 2 * r
-            m[2 * r + 1] = cur_mult
-            s['kcur'][s['par'], c] = 2 * r + 1
+        full = [c for c in torch.nonzero(kc + 1 + room > kcap).flatten().tolist() if int(kc[c]) > 2 * r + 1]   # (device->host read)
+        dev = s['hist'].device
+        for g0 in range(0, len(full), 16):                                      # (groups bound the padded copy: 16 x kcap x p x 4 B)
+            grp = full[g0:g0 + 16]
+            ks = [int(kc[c]) for c in grp]                                      # current row of chain c; rows 0..k-1 are compressed
+            kmax = max(ks)
+            B = torch.zeros(len(grp), kmax, p, dtype=torch.float32, device=dev)
+            mcs, ncs = [], []
+            for i, (c, k) in enumerate(zip(grp, ks)):
+                w = s['mult'][c, :k].to(torch.float32)
+                nc = int(s['mult'][c, :k].sum())
+                H = s['hist'][c, :k, :p]
+                mc = (w[:, None] * H).sum(dim=0) / nc
+                B[i, :k] = w.sqrt()[:, None] * (H - mc)
+                mcs.append(mc)
+                ncs.append(nc)
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(12345 + kmax)
+            Y = B @ torch.randn(p, r, dtype=torch.float32, device=dev, generator=gen)          # [n, kmax, r]
+            lam, V = torch.linalg.eigh((Y.transpose(1, 2) @ Y).double())                        # [n, r], [n, r, r]
+            keep = lam > lam[:, -1:] * 1e-10                                                    # (rank(B) < r: drop the null directions)
+            scale = torch.where(keep, lam.clamp_min(1e-300).rsqrt(), torch.zeros_like(lam))
+            T = (V * scale[:, None, :]).transpose(1, 2).float()                                 # L^-1/2 V^T
+            R = (T @ (Y.transpose(1, 2) @ B)) * (0.5 ** 0.5)                                    # [n, r, p], already / sqrt 2
+            for i, (c, k) in enumerate(zip(grp, ks)):
+                h, m = s['hist'][c], s['mult'][c]
+                cur_row, cur_mult = h[k, :p].clone(), m[k].clone()
+                h[0:2 * r:2, :p] = mcs[i] + R[i]
+                h[1:2 * r:2, :p] = mcs[i] - R[i]
+                h[2 * r, :p] = mcs[i]
+                h[2 * r + 1, :p] = cur_row
+                m.zero_()
+                m[:2 * r] = 1
+                m[2 * r] = ncs[i] - 2 * r
+                m[2 * r + 1] = cur_mult
+                s['kcur'][s['par'], c] = 2 * r + 1
         return len(full)
 
     def _run_gen(self, nmcmc, param_ini, store_chain=True, verbose=False, chain_out=None):

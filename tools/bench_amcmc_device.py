@@ -21,12 +21,15 @@ UG = os.environ.get("USE_GRAPH", "0") == "1"
 res = {"use_graph": UG, "nmcmc": NMCMC}
 FUSE = os.environ.get("QN_FUSE", "1") == "1"
 res["fuse_propose"] = FUSE
-eng = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=1000, seed=1, use_graph=UG, fuse_propose=FUSE)
+MAXROWS = int(os.environ.get("MAX_ROWS", "4096"))       # bound on the stored history rows per chain (compressed beyond)
+STORE = os.environ.get("STORE_CHAIN", "1" if NMCMC <= 12000 else "0") == "1"     # 64 x 50001 x 8513 doubles do not fit
+res["max_rows"], res["store_chain"] = MAXROWS, STORE
+eng = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=1000, seed=1, use_graph=UG, fuse_propose=FUSE, max_rows=MAXROWS)
 eng.run(20, ini, store_chain=True)                      # warm-up (first launches)
 # warm the caching allocator with the run's two large buffers (chain f64, state history f32): a fresh
 # hipMalloc of ~33 GB costs several hundred ms and is not part of the stepping rate
-_a = torch.empty(C, NMCMC + 1, arch.nparams, dtype=torch.float64, device=op.device)
-_b = torch.empty(C, NMCMC + 1, (arch.nparams + 3) // 4 * 4, dtype=torch.float32, device=op.device)
+_a = torch.empty(C, NMCMC + 1, arch.nparams, dtype=torch.float64, device=op.device) if STORE else None
+_b = torch.empty(C, min(NMCMC + 1, MAXROWS), (arch.nparams + 3) // 4 * 4, dtype=torch.float32, device=op.device)
 del _a, _b
 marks = []
 
@@ -43,7 +46,7 @@ class Tick:
 torch.cuda.synchronize(); t0 = time.perf_counter()
 old = sys.stdout; sys.stdout = Tick()
 try:
-    r = eng.run(NMCMC, ini, store_chain=True, verbose=True)
+    r = eng.run(NMCMC, ini, store_chain=STORE, verbose=True)
 finally:
     sys.stdout = old
 torch.cuda.synchronize(); tt = time.perf_counter() - t0
@@ -61,4 +64,6 @@ res["accrate_mean"] = float(acc.mean()); res["accrate_min"] = float(acc.min()); 
 lp = r["logpost"]
 res["logpost_start_mean"] = float(lp[:, 0].mean()); res["logpost_end_mean"] = float(lp[:, -1].mean())
 res["peak_mem_GB"] = torch.cuda.max_memory_allocated() / 1e9
+res["history_GB"] = C * min(NMCMC + 1, MAXROWS) * ((arch.nparams + 3) // 4 * 4) * 4 / 1e9
+res["rows_in_use_end"] = [int(v) + 1 for v in eng.last_state['kcur'][eng.last_state['par']].cpu().numpy()[:8]]
 print(json.dumps(res))
