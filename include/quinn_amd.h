@@ -244,6 +244,12 @@ int qn_hmc_accept(const double* q, const double* grad_q, const double* sse_q, co
                   uint64_t seed, double* cur, double* grad_cur, double* cur_lp, double* best, double* best_lp,
                   double* chain, double* lps, double* alphas, int64_t* nacc, int64_t* step_ptr, int parity, void* stream);
 
+/* Moments of a predictive ensemble on the device (QUiNNBase.predict_mom_sample, quinn/solvers/quinn.py:75-104):
+ * Y [M, K] dtype = M members x K = N * o prediction entries as qn_mlp_sse_fwd writes them ([B, Nb, o] with B = M);
+ * mean_out [K], var_out [K] (unbiased, ddof = 1; NULL to skip; needs M >= 2), float64.  The per-output covariance of
+ * msc = 2 is a plain GEMM of the centred ensemble and is left to the BLAS of the host side. */
+int qn_pred_moments(const void* Y, int dtype, int64_t M, int64_t K, double* mean_out, double* var_out, void* stream);
+
 /* Diagnostic: y[i] = device tanh(x[i]) in float64 (the activation used by every kernel). */
 int qn_debug_tanh(const double* x, double* y, int64_t n, void* stream);
 /* Diagnostic: the variant the fused kernels use when all weights and inputs are finite and bounded

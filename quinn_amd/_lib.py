@@ -21,7 +21,7 @@ PATH_AUTO, PATH_GENERIC, PATH_FUSED, PATH_FUSED_DP = 0, 1, 2, 3
 SYMBOLS = ["qn_mlp_desc_create", "qn_rnet_desc_create", "qn_mlp_desc_destroy", "qn_mlp_num_params", "qn_workspace_bytes",
            "qn_mlp_path", "qn_mlp_desc_set_path", "qn_mlp_sse_fwd", "qn_mlp_sse_parts", "qn_mlp_sse_fwd_parts", "qn_mlp_sse_fwdbwd", "qn_vi_sample_kl",
            "qn_vi_grad", "qn_adam_batched", "qn_mcmc_propose", "qn_mcmc_propose_hist", "qn_mcmc_hist_block_steps", "qn_mcmc_propose_hist_block",
-           "qn_mcmc_apply_delta", "qn_mcmc_accept", "qn_mcmc_accept_propose", "qn_hmc_parts", "qn_hmc_begin", "qn_hmc_leap", "qn_hmc_accept", "qn_debug_tanh", "qn_debug_tanh_finite", "qn_debug_tanh_table", "qn_last_error",
+           "qn_mcmc_apply_delta", "qn_mcmc_accept", "qn_mcmc_accept_propose", "qn_hmc_parts", "qn_hmc_begin", "qn_hmc_leap", "qn_hmc_accept", "qn_pred_moments", "qn_debug_tanh", "qn_debug_tanh_finite", "qn_debug_tanh_table", "qn_last_error",
            "qn_version"]
 
 
@@ -122,6 +122,8 @@ def lib():
     L.qn_hmc_accept.argtypes = [vp, vp, vp, vp, vp, f64, i32, i32, i32, i64, i32, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                 vp, i32, vp]
     L.qn_hmc_accept.restype = i32
+    L.qn_pred_moments.argtypes = [vp, i32, i64, i64, vp, vp, vp]
+    L.qn_pred_moments.restype = i32
     L.qn_debug_tanh.argtypes = [vp, vp, i64, vp]
     L.qn_debug_tanh.restype = i32
     L.qn_debug_tanh_finite.argtypes = [vp, vp, i64, vp]

@@ -594,3 +594,42 @@ extern "C" int qn_debug_tanh_finite(const double* x, double* y, int64_t n, void*
 extern "C" int qn_debug_tanh_table(const double* x, double* y, int64_t n, int nansafe, void* stream) {
     return debug_tanh("qn_debug_tanh_table", nansafe == 2 ? 4 : (nansafe ? 2 : 3), x, y, n, stream);
 }
+
+// ---------------------------------------------------------------------------------------------- predictive moments
+// mean / unbiased variance over the M members of a predictive ensemble Y [M, K] (K = N * o columns), per column, in
+// float64 and in the member order numpy uses for axis 0 (np.mean, np.var(ddof=1) of quinn/solvers/quinn.py:93-99):
+// one thread per column, two passes over its M values, coalesced across columns.  HBM-bound: 2 x M x K reads.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void k_pred_moments(const T* __restrict__ Y, int64_t M, int64_t K, double* __restrict__ mean,
+                                                      double* __restrict__ var) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= K) return;
+    double s = 0.0;
+    for (int64_t m = 0; m < M; ++m) s += (double)Y[m * K + j];
+    const double mu = s / (double)M;
+    mean[j] = mu;
+    if (var) {
+        double q = 0.0;
+        for (int64_t m = 0; m < M; ++m) {
+            const double d = (double)Y[m * K + j] - mu;
+            q += d * d;
+        }
+        var[j] = q / (double)(M - 1);
+    }
+}
+}  // namespace
+
+extern "C" int qn_pred_moments(const void* Y, int dtype, int64_t M, int64_t K, double* mean_out, double* var_out, void* stream) {
+    if (!Y || !mean_out || M < 1 || K < 1 || (var_out && M < 2) || (dtype != QN_F64 && dtype != QN_F32)) {
+        qn_set_error("qn_pred_moments: bad argument");
+        return QN_EINVAL;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    const dim3 grid((unsigned)((K + 255) / 256));
+    if (dtype == QN_F32) hipLaunchKernelGGL(k_pred_moments<float>, grid, dim3(256), 0, st, (const float*)Y, M, K, mean_out, var_out);
+    else hipLaunchKernelGGL(k_pred_moments<double>, grid, dim3(256), 0, st, (const double*)Y, M, K, mean_out, var_out);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}

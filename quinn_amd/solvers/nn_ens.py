@@ -73,15 +73,18 @@ class NN_Ens(QUiNNBase):
         jens = np.random.randint(0, self.nens)
         return self._predict_batch(self._best_w[jens:jens + 1], x)[0]
 
-    def predict_ens(self, x, nens=None):
-        """`(M,N,o)`: predictions of (a random permutation of) the members (nn_ens.py:85-110)."""
+    def _predict_ens_dev(self, x, nens=None):
         if nens is None:
             nens = self.nens
         if nens > self.nens:
             print(f"Warning: Requested {nens} but only {self.nens} ensemble members available.")
             nens = self.nens
         order = np.random.permutation(nens)
-        return self._predict_batch(self._best_w[order], x)
+        return self._predict_batch_dev(self._best_w[order], x)
+
+    def predict_ens(self, x, nens=None):
+        """`(M,N,o)`: predictions of (a random permutation of) the members (nn_ens.py:85-110)."""
+        return self._predict_ens_dev(x, nens).double().cpu().numpy()
 
     def predict_ens_fromsamples(self, x, nens=1):
         return np.array([self.predict_sample(x) for _ in range(nens)])

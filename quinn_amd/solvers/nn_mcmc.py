@@ -202,11 +202,14 @@ class NN_MCMC(QUiNNBase):
         cm = self.cmode if np.ndim(self.cmode) == 1 else self.cmode[0]
         return self.predict_sample(x, cm)
 
+    def _predict_ens_dev(self, x, nens=10, nburn=1000, chain=0):
+        samples = self.samples if self.samples.ndim == 2 else self.samples[chain]
+        nevery = int((samples.shape[0] - nburn) / nens)
+        rows = [nburn + j * nevery for j in range(nens)]
+        return self._predict_batch_dev(samples[rows, :], x)
+
     def predict_ens(self, x, nens=10, nburn=1000, chain=0):
         """`(M,N,o)`: predictions with M thinned post-burn-in samples, rows
         nburn + j*int((len-nburn)/nens) of the chain (nn_mcmc.py:194-199) -- one batched
         forward instead of M sequential ones.  `chain` picks the chain of a multi-chain fit."""
-        samples = self.samples if self.samples.ndim == 2 else self.samples[chain]
-        nevery = int((samples.shape[0] - nburn) / nens)
-        rows = [nburn + j * nevery for j in range(nens)]
-        return self._predict_batch(samples[rows, :], x)
+        return self._predict_ens_dev(x, nens, nburn, chain).double().cpu().numpy()

@@ -53,11 +53,14 @@ class NN_VI(QUiNNBase):
         assert self.trained
         return self.best_model(np.asarray(x, dtype=np.float64), sample=True).cpu().numpy()
 
-    def predict_ens(self, x, nens=None):
-        """`(M,N,o)`: M weight samples pushed through the network in ONE batched forward."""
+    def _predict_ens_dev(self, x, nens=None):
         if nens is None:
             nens = self.nens
         assert self.trained
         bm = self.best_model
         W, _, _ = bm._sample_kl(bm.mu, bm.rho, bm._draw_eps(nens))
-        return bm.op.predict(W, np.asarray(x, dtype=np.float64)).double().cpu().numpy()
+        return bm.op.predict(W, np.asarray(x, dtype=np.float64))
+
+    def predict_ens(self, x, nens=None):
+        """`(M,N,o)`: M weight samples pushed through the network in ONE batched forward."""
+        return self._predict_ens_dev(x, nens).double().cpu().numpy()

@@ -7,10 +7,13 @@ variance / covariance over that ensemble.  The matplotlib helpers of the referen
 path and are not reproduced.
 """
 import copy
+import ctypes
 import sys
 
 import numpy as np
+import torch
 
+from .. import _lib
 from ..ops import MLPArch, BatchedMLP, flatten_module
 
 
@@ -37,15 +40,24 @@ class QUiNNBase():
         print_nnparams(self.nnmodel, names_only=names_only)
 
     # -- device operator used for predictions (dataset = the query points) --------------
-    def _predict_batch(self, W, x):
-        """f_W(x) for a stack of flat weight vectors: numpy (M, N, o)."""
+    def _predict_batch_dev(self, W, x):
+        """f_W(x) for a stack of flat weight vectors: device tensor (M, N, o) in the compute dtype."""
         x = np.asarray(x, dtype=np.float64)
         if self._pred_op is None:
             self._pred_op = BatchedMLP(self.arch, x, None, device=self._device, dtype=self._dtype)
-        return self._pred_op.predict(W, x).double().cpu().numpy()
+        return self._pred_op.predict(W, x)
+
+    def _predict_batch(self, W, x):
+        """f_W(x) for a stack of flat weight vectors: numpy (M, N, o)."""
+        return self._predict_batch_dev(W, x).double().cpu().numpy()
 
     def predict_sample(self, x):
         raise NotImplementedError
+
+    def _predict_ens_dev(self, x, nens):
+        """The predictive ensemble as a DEVICE tensor (M, N, o).  Solvers whose members come out of one batched forward
+        override this (no host round trip); the default takes whatever `predict_ens` of the solver returns."""
+        return torch.as_tensor(self.predict_ens(x, nens=nens))
 
     def predict_ens(self, x, nens=None):
         """`(M, N, o)`: M draws of `predict_sample` (quinn.py:51-70)."""
@@ -59,23 +71,36 @@ class QUiNNBase():
     def predict_mom_sample(self, x, msc=0, nsam=1000):
         """Mean `(N,o)`, variance `(N,o)` (ddof=1) and per-output covariance `(N,N,o)` of an
         `nsam`-member predictive ensemble; msc = 0 / 1 / 2 selects how much is computed
-        (quinn.py:75-104)."""
-        y = self.predict_ens(x, nens=nsam)
-        _, nx, nout = y.shape
-        ymean = np.mean(y, axis=0)
-        if msc == 2:
-            ycov = np.empty((nx, nx, nout))
-            yvar = np.empty((nx, nout))
-            for iout in range(nout):
-                ycov[:, :, iout] = np.cov(y[:, :, iout], rowvar=False, ddof=1)
-                yvar[:, iout] = np.diag(ycov[:, :, iout])
-        elif msc == 1:
-            ycov, yvar = None, np.var(y, axis=0, ddof=1)
-        elif msc == 0:
-            ycov, yvar = None, None
-        else:
+        (quinn.py:75-104).  The ensemble stays on the device: mean / variance by `qn_pred_moments`, the
+        covariance as one float64 GEMM of the centred ensemble per output; only the moments are downloaded."""
+        if msc not in (0, 1, 2):
             print(f"msc={msc}, but needs to be 0,1, or 2. Exiting.")
             sys.exit()
+        dev = torch.device(self._device) if self._device is not None else torch.device("cuda", torch.cuda.current_device())
+        y = self._predict_ens_dev(x, nsam).to(dev).contiguous()
+        M, nx, nout = y.shape
+        mean = torch.empty(nx, nout, dtype=torch.float64, device=dev)
+        var = torch.empty(nx, nout, dtype=torch.float64, device=dev) if msc == 1 else None
+        qdt = _lib.QN_F32 if y.dtype == torch.float32 else _lib.QN_F64
+        if y.dtype not in (torch.float32, torch.float64):
+            y, qdt = y.double(), _lib.QN_F64
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().qn_pred_moments(y.data_ptr(), qdt, M, nx * nout, mean.data_ptr(),
+                                                  var.data_ptr() if var is not None else None,
+                                                  ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "qn_pred_moments")
+        ymean = mean.cpu().numpy()
+        if msc == 2:
+            yc = y.double() - mean                                   # (M, N, o)
+            ycov_d = torch.empty(nx, nx, nout, dtype=torch.float64, device=dev)
+            for iout in range(nout):
+                a = yc[:, :, iout]
+                ycov_d[:, :, iout] = (a.T @ a) / (M - 1)            # np.cov(rowvar=False, ddof=1), quinn.py:88-90
+            ycov = ycov_d.cpu().numpy()
+            yvar = np.stack([np.diag(ycov[:, :, iout]) for iout in range(nout)], axis=1)
+        elif msc == 1:
+            ycov, yvar = None, var.cpu().numpy()
+        else:
+            ycov, yvar = None, None
         return ymean, yvar, ycov
 
     # -- figures (presentation only; same signatures and file names as quinn.py:106-260) ---------------

@@ -91,10 +91,17 @@ def test_predictions_from_chain():
     np.testing.assert_allclose(yens, g["yens"], rtol=1e-12, atol=1e-13)
     import functools
     solver.predict_ens = functools.partial(solver.predict_ens, nburn=int(g["nburn"]))
+    solver._predict_ens_dev = functools.partial(solver._predict_ens_dev, nburn=int(g["nburn"]))   # (the moments stay on the device)
     ymean, yvar, ycov = solver.predict_mom_sample(g["xg"], msc=2, nsam=int(g["nens"]))
     np.testing.assert_allclose(ymean, g["ymean"], rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(yvar, g["yvar"], rtol=1e-9, atol=1e-15)
     np.testing.assert_allclose(ycov, g["ycov"], rtol=1e-9, atol=1e-15)
+    m1, v1, c1 = solver.predict_mom_sample(g["xg"], msc=1, nsam=int(g["nens"]))                 # qn_pred_moments: mean + variance
+    assert c1 is None
+    np.testing.assert_allclose(m1, np.mean(g["yens"], axis=0), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(v1, np.var(g["yens"], axis=0, ddof=1), rtol=1e-11, atol=1e-18)
+    m0, v0, c0 = solver.predict_mom_sample(g["xg"], msc=0, nsam=int(g["nens"]))
+    assert v0 is None and c0 is None and np.array_equal(m0, m1)
 
 
 def test_zflag_bfgs_and_single_vector_api():

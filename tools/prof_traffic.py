@@ -22,7 +22,8 @@ for kind in ("logpost", "grad"):
                 step += avg
         tot[c] = step
     kib = 2.0 * tot.get("FETCH_SIZE", 0.0) + tot.get("WRITE_SIZE", 0.0)
-    res[f"{kind}_f64_fused"] = {"hbm_bytes_per_launch": kib * 1024.0, "fetch_kib_raw": tot.get("FETCH_SIZE"),
+    fam = "fused_i8" if any("fwd_i8" in k for k in detail) else "fused"      # (the sliced int8-product forward)
+    res[f"{kind}_f64_{fam}"] = {"hbm_bytes_per_launch": kib * 1024.0, "fetch_kib_raw": tot.get("FETCH_SIZE"),
                                 "write_kib": tot.get("WRITE_SIZE"), "detail_kib": detail}
 json.dump(res, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
