@@ -127,14 +127,16 @@ def all_gather_rows(local, n_total):
     return gather_rows(local, n_total, dst="all")
 
 
-def gather_results(res, n_total, gather="all", max_bytes=DEFAULT_MAX_GATHER_BYTES):
+def gather_results(res, n_total, gather="all", gather_chain=None, max_bytes=DEFAULT_MAX_GATHER_BYTES):
     """Gather a sampler's result dict (`chain`, `mapparams`, `maxpost`, `accrate`, `logpost`, `alphas`; device
-    tensors or numpy, this rank's shard) -> dict of numpy arrays.  The small entries always follow `gather`;
-    so does `chain` ([C, nmcmc+1, p], the large one)."""
-    return {k: (None if v is None else gather_rows(v, n_total, dst=gather, max_bytes=max_bytes)) for k, v in res.items()}
+    tensors or numpy, this rank's shard) -> dict of numpy arrays.  The small entries follow `gather`; `chain`
+    ([C, nmcmc+1, p], the large one: 43.6 GB per rank at cfg2) follows `gather_chain` (None: the same as `gather`)."""
+    gc = gather if gather_chain is None else gather_chain
+    return {k: (None if v is None else gather_rows(v, n_total, dst=gc if k == "chain" else gather, max_bytes=max_bytes))
+            for k, v in res.items()}
 
 
-def run_chains_sharded(make_sampler, nmcmc, param_ini, seeds, verbose=False, gather="all"):
+def run_chains_sharded(make_sampler, nmcmc, param_ini, seeds, verbose=False, gather="all", gather_chain=None):
     """Run len(seeds) chains split over the ranks; the result dict follows `gather` (see `gather_rows`).
 
     Args:
@@ -155,7 +157,7 @@ def run_chains_sharded(make_sampler, nmcmc, param_ini, seeds, verbose=False, gat
         res = mc.run(nmcmc, ini, rngs=rngs, verbose=verbose)
     else:
         res = empty_results(nmcmc, ini.shape[1])
-    return gather_results({k: np.asarray(v) for k, v in res.items()}, C, gather)
+    return gather_results({k: np.asarray(v) for k, v in res.items()}, C, gather, gather_chain)
 
 
 def empty_results(nmcmc, p):

@@ -86,7 +86,7 @@ class NN_MCMC(QUiNNBase):
 
     # -- fit -------------------------------------------------------------------------------
     def fit(self, xtrn, ytrn, zflag=True, datanoise=0.05, nmcmc=6000, param_ini=None, sampler='amcmc',
-            sampler_params=None, *, nchains=1, seeds=None, engine='host', gather='all', bfgs_jac=None):
+            sampler_params=None, *, nchains=1, seeds=None, engine='host', gather='all', gather_chain=None, bfgs_jac=None):
         """Run MCMC over the flat weight vector.
 
         Args (reference): xtrn `(N,d)`, ytrn `(N,o)`, zflag (BFGS pre-fit of a random start),
@@ -102,6 +102,9 @@ class NN_MCMC(QUiNNBase):
             chains (one all_gather of the result arrays, from the device buffers in bounded pieces); 'root' -- rank 0
             does, the other ranks keep their own shard; 'none' -- no communication at all.  A gather whose result
             exceeds `quinn_amd.parallel.DEFAULT_MAX_GATHER_BYTES` raises MemoryError before any traffic.
+            gather_chain: the same choice for the `chain` array alone (None: as `gather`), e.g. gather='all',
+            gather_chain='none' returns MAP / acceptance / log-posterior traces of every chain everywhere and leaves the
+            states sharded (at cfg2 they are 43.6 GB per rank).
             bfgs_jac: None -- the `zflag` BFGS pre-fit lets scipy difference the log-posterior, exactly as the reference
             does (nn_mcmc.py:125-127; p + 1 log-posterior evaluations per gradient); 'device' -- the gradient kernel is
             passed as the analytic jacobian (one evaluation per gradient; a different start point than the reference's).
@@ -156,7 +159,7 @@ class NN_MCMC(QUiNNBase):
             else:
                 res = empty_results(nmcmc, ini2.shape[1])
             # the single collective, at the end, straight from the device tensors (world == 1: a device->host copy)
-            res = gather_results(res, ctot, gather)
+            res = gather_results(res, ctot, gather, gather_chain)
             self.mcmc_results = res
             if np.ndim(param_ini) == 1:
                 self.mcmc_results = {k: v[0] for k, v in self.mcmc_results.items()}
@@ -176,7 +179,7 @@ class NN_MCMC(QUiNNBase):
 
         if rngs is not None and dist_info()[1] > 1:
             # chains shard over ranks; one all_gather of the result arrays at the end
-            self.mcmc_results = run_chains_sharded(lambda: mymcmc, nmcmc, param_ini, seeds, verbose=False, gather=gather)
+            self.mcmc_results = run_chains_sharded(lambda: mymcmc, nmcmc, param_ini, seeds, verbose=False, gather=gather, gather_chain=gather_chain)
         else:
             self.mcmc_results = mymcmc.run(nmcmc=nmcmc, param_ini=param_ini, rngs=rngs, verbose=self.verbose)
         self.samples, self.cmode = self.mcmc_results['chain'], self.mcmc_results['mapparams']

@@ -82,6 +82,10 @@ def main():
     assert resn["chain"].shape[0] == hi3 - lo3
     if rank == 0:
         assert np.array_equal(resr["chain"][lo3:hi3], resn["chain"])
+    # small entries everywhere, the chain left sharded
+    resm = run_chains_sharded(make, 25, None, seeds[:3], gather="all", gather_chain="none")
+    assert resm["chain"].shape[0] == hi3 - lo3 and resm["logpost"].shape == (3, 26) and resm["mapparams"].shape[0] == 3
+    assert np.array_equal(resm["chain"], resn["chain"])
     np.testing.assert_allclose(res1["chain"][0], g["chain"][0][:26], rtol=1e-9, atol=1e-11)
     dist.barrier()
     with open(os.path.join(os.environ["QN_DIST_OUT"], f"ok_{rank}"), "w") as f:
