@@ -237,21 +237,24 @@ __device__ __forceinline__ int stage(double* __restrict__ lds, unsigned char* __
 // The wave's 32 rows in plain float64 from the ORIGINAL weights (rare: non-finite / huge weights or inputs).  Lane j
 // owns feature j of one row at a time; the previous layer's activations are broadcast through `scr` (128 doubles).
 template <int DP>
-__device__ __noinline__ double slow_tile(const FusedArgs& a, const double* __restrict__ lds, double* __restrict__ scr,
-                                         const double* __restrict__ Wb, const double* __restrict__ X,
-                                         const double* __restrict__ Y, const int32_t* __restrict__ row_idx, int nbase, int b,
+// (the arguments it needs by value: a reference to the kernel's argument struct would force a copy of the struct into
+// scratch memory at every kernel entry -- 8 MB of writes per launch in the first version)
+__device__ __noinline__ double slow_tile(int Nb, int d, int o, int nhid, int has_bias, const double* __restrict__ lds,
+                                         double* __restrict__ scr, const double* __restrict__ Wb,
+                                         const double* __restrict__ X, const double* __restrict__ Y,
+                                         const int32_t* __restrict__ row_idx, int nbase, int b,
                                          double* __restrict__ pred_out) {
     const int lane = threadIdx.x & 63;
-    const int nb = a.has_bias ? 1 : 0, o = a.o, d = a.d;
+    const int nb = has_bias ? 1 : 0;
     const int64_t gHH = (int64_t)H * d + nb * H;
     const int lb0 = H * DP, lWl = lb0 + H, lbl = lWl + OMAX * H;
     double sse = 0.0;
-    for (int n = nbase; n < nbase + 16 * G && n < a.Nb; ++n) {
-        const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + n] : (int64_t)n;
+    for (int n = nbase; n < nbase + 16 * G && n < Nb; ++n) {
+        const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * Nb + n] : (int64_t)n;
         double z = lds[lb0 + lane];
         for (int k = 0; k < d; ++k) z = fma(lds[lane * DP + k], X[rr * d + k], z);
         double act = qn_tanh_f64(z);
-        for (int layer = 1; layer < a.nhid; ++layer) {
+        for (int layer = 1; layer < nhid; ++layer) {
             double* cur = scr + 64 * (layer & 1);
             cur[lane] = act;
             __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the wave's own LDS writes have landed
@@ -265,7 +268,7 @@ __device__ __noinline__ double slow_tile(const FusedArgs& a, const double* __res
             const double res = pr - Y[rr * o + qo];
             if (lane == 0) {
                 sse += res * res;
-                if (pred_out) pred_out[((int64_t)b * a.Nb + n) * o + qo] = pr;
+                if (pred_out) pred_out[((int64_t)b * Nb + n) * o + qo] = pr;
             }
         }
     }
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
         const bool exceptional = w_bad || __any(xbad_n);
         if (it + 1 < a.iters) fetch(it + 1);
         if (exceptional) {                                              // wave-uniform
-            sse += slow_tile<DP>(a, lds, scratch + 128 * wave, Wb, X, Y, row_idx,
+            sse += slow_tile<DP>(a.Nb, a.d, a.o, a.nhid, a.has_bias, lds, scratch + 128 * wave, Wb, X, Y, row_idx,
                                  split * a.rows_per_split + (it * (WGT / 64) + wave) * 16 * G, b, pred_out);
             continue;
         }
