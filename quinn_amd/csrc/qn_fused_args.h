@@ -18,3 +18,11 @@ int qn_fused_i8_rows_per_iteration();       // data rows one workgroup covers pe
 bool qn_fused_i8_applies(int H, int nhid, int act, int d, int o);
 size_t qn_fused_i8_lds_bytes(int d, int nhid);
 qn_fwd_fn qn_fused_i8_kernel(int d, int o);
+
+// layer-wise int8-slice forward for wide tanh networks (qn_fused_i8.hip); used by qn_generic.hip
+struct qn_desc;
+#include <hip/hip_runtime.h>
+bool qn_i8_layers_apply(const qn_desc* d);
+size_t qn_i8_layers_workspace(const qn_desc* d, int B, int Nb);
+int qn_i8_layers_forward(const qn_desc* d, const double* W, const double* X, const int32_t* row_idx, int B, int Nb,
+                         double* const* act, void* ws, hipStream_t st);

@@ -149,14 +149,14 @@ template <class F, int... I>
 __device__ __forceinline__ void for_each_stage(F&& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
 }
-template <int LMIN, int NLEV>
+template <int LMIN, int NLEV, bool FRESH = true>
 __device__ __forceinline__ void issue_product(int k, v4i (&acc)[NLEV], const v4i (&Af)[NS], const v4i (&B)[NS]) {
     // (k is a compile-time constant after unrolling; the switch makes the register indices static)
 #define QN_PRODUCT(KK)                                                                                               \
     case KK:                                                                                                         \
         if constexpr (KK < nprod(LMIN)) {                                                                            \
             constexpr int wi = prod_wi(LMIN, KK), aj = prod_aj(LMIN, KK), l = wi + aj - LMIN;                          \
-            acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Af[wi], B[aj], prod_first(LMIN, KK) ? (v4i){0, 0, 0, 0} : acc[l], 0, 0, 0); \
+            acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Af[wi], B[aj], (FRESH && prod_first(LMIN, KK)) ? (v4i){0, 0, 0, 0} : acc[l], 0, 0, 0); \
         }                                                                                                            \
         break;
     switch (k) {
@@ -579,4 +579,400 @@ qn_fwd_fn qn_fused_i8_kernel(int d, int o) {
 #endif
     (void)o;
     return d <= 2 ? k_fused_fwd_i8<2, QN_I8_LMIN, 1> : k_fused_fwd_i8<4, QN_I8_LMIN, 1>;
+}
+
+// =====================================================================================================================
+// Layer-wise int8-slice FORWARD for wide tanh networks (hidden widths that are multiples of 64: cfg3..5, h = 128 / 256),
+// where a chain's digit planes no longer fit LDS.  Same arithmetic as the fused kernel above, organised as a GEMM per
+// layer with the activations kept in HBM twice: as float64 [B][h][Nb] (what the backward pass, the last layer and the
+// exceptional path read) and as digit planes [B][6][Nb][h] bytes (row-major per data row, k-slot order inside every
+// 64-feature chunk: the MFMA B operand of the next layer is 16 consecutive bytes per lane).
+//   k_i8_slice_w   once per call: digit planes [6][h_out][h_in] (slot-swizzled per row, the LDS image of a tile) and
+//                  {scale, bias} of every hidden->hidden matrix of every chain; flags chains with unbounded weights
+//   k_i8_first     first layer on the VALU: a_1 = tanh(W0 x + b0) -> float64 + digits; flags chains that meet a NaN
+//   k_i8_gemm      one hidden->hidden layer: workgroup = 64 features x 64 data rows (4 waves x 16 rows x 4 tiles), K in
+//                  chunks of 64: weight digits of the chunk through double-buffered LDS (LDS-DMA), activation digits
+//                  straight from HBM into the B operand, 26 exact products per tile and chunk into 7 int32 level
+//                  accumulators that live across the chunks; then recombine, scale + bias, tanh, float64 + digits out.
+// A float64 GEMM tile of this size costs 64 x 64 = 4096 cycles of the vector pipe per 64 of K; here it is 104 MFMAs x
+// 16 cycles on the int8 pipe.  Flagged chains take a plain float64 loop per tile (IEEE semantics of the f64 kernels).
+namespace {
+
+struct I8Net {
+    int nl;                                   // hidden->hidden layers handled (layer li maps dims[li+1] -> dims[li+2])
+    int h[QN_MAX_LAYERS + 1];                 // h[0] = first hidden width, h[li+1] = output width of layer li
+    int64_t offW[QN_MAX_LAYERS], offB[QN_MAX_LAYERS];   // offsets into a flat weight vector
+    int64_t offD[QN_MAX_LAYERS];              // byte offset of layer li's digit planes inside a chain's block
+    int64_t offS[QN_MAX_LAYERS];              // double offset of layer li's {scale, bias} pairs inside a chain's block
+    int64_t p, dbytes, sdoubles;
+    int has_bias;
+};
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
+    x = row16_max_u32(x);
+    const unsigned a = __builtin_amdgcn_readlane((int)x, 0), b = __builtin_amdgcn_readlane((int)x, 16);
+    const unsigned c = __builtin_amdgcn_readlane((int)x, 32), d = __builtin_amdgcn_readlane((int)x, 48);
+    return max(max(a, b), max(c, d));
+}
+
+// grid (B, layers, row parts): a workgroup slices rows [part * h_out / parts, ...) of one matrix of one chain
+template <int LMIN>
+__global__ __launch_bounds__(256) void k_i8_slice_w(I8Net net, const double* __restrict__ W, unsigned char* __restrict__ Wd,
+                                                   double* __restrict__ sb, int* __restrict__ flags) {
+    const int b = blockIdx.x, li = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bad = 0;
+    const double* Wb = W + (int64_t)b * net.p;
+    const int h_in = net.h[li], h_out = net.h[li + 1], nq = h_in / 4;
+    const double* Wg = Wb + net.offW[li];
+    unsigned char* planes = Wd + (int64_t)b * net.dbytes + net.offD[li];
+    double* sbl = sb + (int64_t)b * net.sdoubles + net.offS[li];
+    const int64_t plane = (int64_t)h_out * h_in;
+    const int rows_per = (h_out + gridDim.z - 1) / gridDim.z;
+    const int r0 = blockIdx.z * rows_per, r1 = r0 + rows_per < h_out ? r0 + rows_per : h_out;
+    for (int row = r0 + wave; row < r1; row += 4) {
+        unsigned ex = 0;
+        for (int qd = lane; qd < nq; qd += 64) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = Wg[(int64_t)row * h_in + 4 * qd + r];
+                bad |= !qn_bounded(v);
+                ex = max(ex, ((unsigned)__double2hiint(v) & 0x7fffffffu) >> 20);
+            }
+        }
+        int e = (int)wave_max_u32(ex) - 1022;
+        e = e < -900 ? -900 : e;
+        for (int qd = lane; qd < nq; qd += 64) {
+            double an[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) an[r] = ldexp(Wg[(int64_t)row * h_in + 4 * qd + r], -e);
+            int S[NS];
+            slice4(an, S);
+            const int i0 = 4 * qd, kc = i0 >> 6, m = (i0 & 63) >> 4, g = (i0 & 15) >> 2;
+            unsigned char* dst = planes + (int64_t)row * h_in + 64 * kc + 16 * (g ^ slot_swz(row)) + 4 * m;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(dst + k * plane) = S[k];
+        }
+        if (lane == 0) {
+            const double bias = net.has_bias ? Wb[net.offB[li] + row] : 0.0;
+            bad |= !qn_bounded(bias);
+            sbl[2 * row] = ldexp(1.0, e - 2 * QB + 8 * LMIN);
+            sbl[2 * row + 1] = bias;
+        }
+    }
+    if (__any(bad) && lane == 0) atomicOr(&flags[b], 1);           // (flags are zeroed by a memset node ahead of this kernel)
+}
+
+struct I8First {
+    int64_t p, offW, offB;
+    int d, h, Nb, has_bias, rows_per_wg;
+};
+// first layer: a wave = 16 data rows per pass, lane (q, c) = features 16 t + 4 q + r of row c; d <= 16 inputs; the
+// workgroup (8 waves) keeps W0, b0 and the tanh table in LDS and walks rows_per_wg rows
+__global__ __launch_bounds__(512) void k_i8_first(I8First a, const double* __restrict__ W, const double* __restrict__ X,
+                                                 const int32_t* __restrict__ row_idx, double* __restrict__ act_out,
+                                                 unsigned char* __restrict__ ad_out, int* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem1[];
+    double* tanh_tab = reinterpret_cast<double*>(smem1);
+    double* w0 = tanh_tab + ((TANH_TAB + 1) & ~1);                  // [h][d + 1]: weights then bias
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c = lane & 15;
+    const double* Wb = W + (int64_t)b * a.p;
+    qn_tanh_table64_stage(tanh_tab, tid, 512);
+    const int dd = a.d + 1;
+    int bad = 0;
+    for (int e = tid; e < a.h * dd; e += 512) {
+        const int j = e / dd, k = e % dd;
+        const double v = k < a.d ? Wb[a.offW + (int64_t)j * a.d + k] : (a.has_bias ? Wb[a.offB + j] : 0.0);
+        bad |= !qn_bounded(v);
+        w0[e] = v;
+    }
+    __syncthreads();
+    const int64_t plane = (int64_t)a.Nb * a.h;
+    const int nbeg = blockIdx.x * a.rows_per_wg;
+    for (int n0 = nbeg; n0 < nbeg + a.rows_per_wg && n0 < a.Nb; n0 += 128) {
+        const int n = n0 + 16 * wave + c;
+        const bool live = n < a.Nb;
+        const int nn = live ? n : a.Nb - 1;
+        const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
+        double x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            x[k] = k < a.d ? X[rr * a.d + k] : 0.0;
+            bad |= !qn_bounded(x[k]);
+        }
+        for (int kc = 0; kc < a.h / 64; ++kc) {
+            int D[NS][4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                double av[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 64 * kc + 16 * m + 4 * q + r;
+                    double z = w0[j * dd + a.d];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (k < a.d) z = fma(w0[j * dd + k], x[k], z);
+                    // (unbounded weights / inputs are flagged: those chains are recomputed by the float64 path below)
+                    av[r] = qn_tanh_f64_tab64(z, tanh_tab);
+                    if (live) act_out[((int64_t)b * a.h + j) * a.Nb + n] = av[r];
+                }
+                int S[NS];
+                slice4(av, S);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) D[k][m] = S[k];
+            }
+            if (live && ad_out) {
+                unsigned char* dst = ad_out + (int64_t)b * NS * plane + (int64_t)n * a.h + 64 * kc + 16 * q;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) *reinterpret_cast<v4i*>(dst + k * plane) = (v4i){D[k][0], D[k][1], D[k][2], D[k][3]};
+            }
+        }
+    }
+    if (__any(bad) && lane == 0) atomicOr(&flags[b], 2);            // bit 1: the first layer must be redone in plain float64
+}
+// flagged chains (bit 1 of k_i8_first: an unbounded first-layer weight or input): the first layer again with the
+// NaN-propagating float64 tanh; hidden layers of flagged chains take the float64 path of k_i8_gemm
+__global__ __launch_bounds__(256) void k_i8_first_slow(I8First a, const double* __restrict__ W, const double* __restrict__ X,
+                                                      const int32_t* __restrict__ row_idx, double* __restrict__ act_out,
+                                                      const int* __restrict__ flags) {
+    const int b = blockIdx.y;
+    if (!(flags[b] & 2)) return;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= a.Nb) return;
+    const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + n] : (int64_t)n;
+    const double* Wb = W + (int64_t)b * a.p;
+    for (int j = 0; j < a.h; ++j) {
+        double z = a.has_bias ? Wb[a.offB + j] : 0.0;
+        for (int k = 0; k < a.d; ++k) z = fma(Wb[a.offW + (int64_t)j * a.d + k], X[rr * a.d + k], z);
+        act_out[((int64_t)b * a.h + j) * a.Nb + n] = qn_tanh_f64(z);
+    }
+}
+
+struct I8Gemm {
+    int64_t p, offW, offB, wd_chain, wd_off, sb_chain, sb_off;
+    int h_in, h_out, Nb, has_bias;
+    int mtiles, rsegs, rows_per_wg, outer_total;   // 1-D XCD-aware grid: the m-tiles of one (row segment, chain) on ONE XCD
+};
+__device__ __forceinline__ void glds16b(const unsigned char* src, unsigned char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// One hidden->hidden layer.  Workgroup = 8 waves = (chain, 64 output features, a segment of rows_per_wg data rows): the
+// tile's weight digits for the WHOLE K ([KC][6][64 rows][64 B], 24 KB per 64 of K) are fetched once into LDS and stay
+// there; the workgroup then walks its rows 128 at a time, each wave 16 rows x 64 features: activation digits straight
+// from HBM into the B operand (next chunk prefetched), 4 x 26 exact products per chunk into 4 x 7 int32 level
+// accumulators, then recombine, scale + bias, tanh, float64 + digits out.  No barrier inside the row loop.
+template <int LMIN, int KC>
+__global__ __launch_bounds__(512, 1) void k_i8_gemm(I8Gemm g, const double* __restrict__ W, const unsigned char* __restrict__ Wd,
+                                                   const double* __restrict__ sb, const unsigned char* __restrict__ ad_in,
+                                                   const double* __restrict__ act_in, const int* __restrict__ flags,
+                                                   double* __restrict__ act_out, unsigned char* __restrict__ ad_out) {
+    constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN);
+    constexpr int TILE_B = NS * 64 * 64;                   // one K-chunk of the tile's weight digits: [6][64 rows][64 B]
+    extern __shared__ __attribute__((aligned(16))) char smem8[];
+    unsigned char* wbuf = reinterpret_cast<unsigned char*>(smem8);                       // KC x 24 KB
+    double* tanh_tab = reinterpret_cast<double*>(smem8 + KC * TILE_B);
+    double* sbt = tanh_tab + ((TANH_TAB + 1) & ~1);                                      // [64][2]
+    const int seq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int mt = seq % g.mtiles, outer = (seq / g.mtiles) * 8 + xcd;
+    if (outer >= g.outer_total) return;
+    const int b = outer / g.rsegs, m0 = mt * 64, nbeg = (outer % g.rsegs) * g.rows_per_wg;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c = lane & 15;
+    const int64_t in_plane = (int64_t)g.Nb * g.h_in, out_plane = (int64_t)g.Nb * g.h_out;
+
+    if (flags[b]) {
+        // exceptional chain (a weight or input that is not finite and < 2^500): the tile in plain float64
+        const double* Wg = W + (int64_t)b * g.p + g.offW;
+        for (int n0 = nbeg; n0 < nbeg + g.rows_per_wg && n0 < g.Nb; n0 += 128) {
+            const int n = n0 + 16 * wave + c;
+            if (n >= g.Nb) continue;
+            for (int t = 0; t < 4; ++t)
+                for (int r = 0; r < 4; ++r) {
+                    const int j = m0 + 16 * t + 4 * q + r;
+                    double z = g.has_bias ? W[(int64_t)b * g.p + g.offB + j] : 0.0;
+                    for (int i = 0; i < g.h_in; ++i) z = fma(Wg[(int64_t)j * g.h_in + i], act_in[((int64_t)b * g.h_in + i) * g.Nb + n], z);
+                    act_out[((int64_t)b * g.h_out + j) * g.Nb + n] = qn_tanh_f64(z);
+                }
+        }
+        return;                                            // (the next layer of this chain takes this path too: no digits needed)
+    }
+
+    {   // the tile's digits: KC x 24 wave-instructions of 1 KB = 16 rows x 64 B each, LDS-DMA
+        const unsigned char* wd = Wd + (int64_t)b * g.wd_chain + g.wd_off;
+        const int64_t wplane = (int64_t)g.h_out * g.h_in;
+        for (int i = wave; i < KC * 24; i += 8) {
+            const int kc = i / 24, ii = i % 24, dig = ii >> 2, r16 = ii & 3;
+            glds16b(wd + dig * wplane + (int64_t)(m0 + 16 * r16 + (lane >> 2)) * g.h_in + 64 * kc + 16 * (lane & 3), wbuf + i * 1024);
+        }
+    }
+    qn_tanh_table64_stage(tanh_tab, tid, 512);
+    if (tid < 128) sbt[tid] = sb[(int64_t)b * g.sb_chain + g.sb_off + 2 * m0 + tid];
+    __syncthreads();                                       // (waits for the DMA too: vmcnt(0) ahead of the barrier)
+
+    const int lofs = c * 64 + 16 * (q ^ slot_swz(c));
+    const unsigned char* adb = ad_in + (int64_t)b * NS * in_plane + 16 * q;
+    auto loadB = [&](int nrow, int kc, v4i (&B)[NS]) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) B[k] = *reinterpret_cast<const v4i*>(adb + k * in_plane + (int64_t)nrow * g.h_in + 64 * kc);
+    };
+    auto row_of = [&](int n0) { const int n = n0 + 16 * wave + c; return n < g.Nb ? n : g.Nb - 1; };
+    v4i Bf[NS], Bnx[NS];
+    loadB(row_of(nbeg), 0, Bf);
+    for (int n0 = nbeg; n0 < nbeg + g.rows_per_wg && n0 < g.Nb; n0 += 128) {
+        const int n = n0 + 16 * wave + c;
+        const bool live = n < g.Nb;
+        const int nn = live ? n : g.Nb - 1;
+        v4i acc[4][NLEV];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int l = 0; l < NLEV; ++l) acc[t][l] = (v4i){0, 0, 0, 0};
+#pragma unroll 1
+        for (int kc = 0; kc < KC; ++kc) {                   // (not unrolled: the fragment loads of all chunks would be hoisted)
+            if (kc + 1 < KC) loadB(nn, kc + 1, Bnx);
+            else loadB(row_of(n0 + 128), 0, Bnx);           // first chunk of the next pass (clamped: harmless if there is none)
+            const unsigned char* tile = wbuf + kc * TILE_B + lofs;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                v4i Af[NS];
+#pragma unroll
+                for (int wi = 0; wi < NS; ++wi) Af[wi] = *reinterpret_cast<const v4i*>(tile + wi * 4096 + t * 1024);
+#pragma unroll
+                for (int k = 0; k < NPROD; ++k) issue_product<LMIN, NLEV, false>(k, acc[t], Af, Bf);
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) Bf[k] = Bnx[k];
+        }
+        // ---- epilogue: recombine (every level on its own: with K > 64 the pair sums would not fit int32), scale +
+        // bias, tanh, float64 out, digits out
+        int D[NS][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            double av[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double ts = (double)acc[t][NLEV - 1][r];
+#pragma unroll
+                for (int l = NLEV - 2; l >= 0; --l) ts = fma(ts, 256.0, (double)acc[t][l][r]);
+                const int jl = 16 * t + 4 * q + r;
+                const double2 sc = *reinterpret_cast<const double2*>(sbt + 2 * jl);
+                av[r] = qn_tanh_f64_tab64(fma(ts, sc.x, sc.y), tanh_tab);
+                if (live) act_out[((int64_t)b * g.h_out + m0 + jl) * g.Nb + n] = av[r];
+            }
+            if (ad_out) {
+                int S[NS];
+                slice4(av, S);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) D[k][t] = S[k];
+            }
+        }
+        if (ad_out && live) {
+            unsigned char* dst = ad_out + (int64_t)b * NS * out_plane + (int64_t)n * g.h_out + m0 + 16 * q;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) *reinterpret_cast<v4i*>(dst + k * out_plane) = (v4i){D[k][0], D[k][1], D[k][2], D[k][3]};
+        }
+    }
+}
+
+}  // namespace
+
+// ---- host side of the layer-wise int8-slice forward (called by qn_generic.hip for float64 tanh networks)
+namespace {
+bool i8net_of(const qn_desc* d, I8Net* net) {
+    const int L = d->nlayers;
+    if (d->kind != QN_KIND_MLP || d->act != QN_ACT_TANH || L < 3 || d->dims[0] > 16) return false;
+    for (int l = 1; l + 1 < L; ++l)
+        if (d->dims[l] != 128 && d->dims[l] != 256) return false;         // K resident in LDS: 2 or 4 chunks of 64
+    net->nl = L - 2;
+    net->p = d->p; net->has_bias = d->has_bias;
+    int64_t db = 0, sd = 0;
+    for (int l = 1; l + 1 < L; ++l) {
+        if (d->dims[l] % 64 || d->dims[l + 1] % 64) return false;
+        const int li = l - 1;
+        net->h[li] = d->dims[l]; net->h[li + 1] = d->dims[l + 1];
+        net->offW[li] = d->offW[l]; net->offB[li] = d->offB[l];
+        net->offD[li] = db; net->offS[li] = sd;
+        db += (int64_t)NS * d->dims[l] * d->dims[l + 1];
+        sd += 2 * (int64_t)d->dims[l + 1];
+    }
+    net->dbytes = (db + 255) / 256 * 256;
+    net->sdoubles = sd;
+    return true;
+}
+constexpr size_t i8gemm_lds(int kc) { return (size_t)kc * NS * 64 * 64 + sizeof(double) * (((TANH_TAB + 1) & ~1) + 128); }
+int i8_arm(const void* fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return QN_OK;
+    QN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return QN_OK;
+}
+}  // namespace
+
+bool qn_i8_layers_apply(const qn_desc* d) {
+    I8Net net;
+    return i8net_of(d, &net);
+}
+// bytes of: weight digit planes | {scale, bias} pairs | chain flags | two activation digit buffers
+size_t qn_i8_layers_workspace(const qn_desc* d, int B, int Nb) {
+    I8Net net;
+    if (!i8net_of(d, &net)) return 0;
+    int hmax = 0;
+    for (int li = 0; li <= net.nl; ++li) hmax = net.h[li] > hmax ? net.h[li] : hmax;
+    return qn_align((size_t)B * net.dbytes) + qn_align((size_t)B * net.sdoubles * sizeof(double)) + qn_align((size_t)B * sizeof(int)) +
+           2 * qn_align((size_t)B * NS * Nb * hmax);
+}
+// forward through the first layer and every hidden->hidden layer: act[l] (float64 [B][dims[l+1]][Nb], l = 0 .. L-2) are
+// written as the float64 layer-wise kernels would write them
+int qn_i8_layers_forward(const qn_desc* d, const double* W, const double* X, const int32_t* row_idx, int B, int Nb,
+                         double* const* act, void* ws, hipStream_t st) {
+    I8Net net;
+    if (!i8net_of(d, &net)) return QN_EUNSUPPORTED;
+    int hmax = 0;
+    for (int li = 0; li <= net.nl; ++li) hmax = net.h[li] > hmax ? net.h[li] : hmax;
+    char* base = static_cast<char*>(ws);
+    unsigned char* Wd = reinterpret_cast<unsigned char*>(base);
+    base += qn_align((size_t)B * net.dbytes);
+    double* sb = reinterpret_cast<double*>(base);
+    base += qn_align((size_t)B * net.sdoubles * sizeof(double));
+    int* flags = reinterpret_cast<int*>(base);
+    base += qn_align((size_t)B * sizeof(int));
+    unsigned char* ad[2];
+    ad[0] = reinterpret_cast<unsigned char*>(base);
+    ad[1] = ad[0] + qn_align((size_t)B * NS * Nb * hmax);
+#ifndef QN_I8_LMIN
+#define QN_I8_LMIN 4
+#endif
+    QN_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), st));
+    hipLaunchKernelGGL((k_i8_slice_w<QN_I8_LMIN>), dim3(B, net.nl, 8), dim3(256), 0, st, net, W, Wd, sb, flags);
+    I8First f;
+    f.p = d->p; f.offW = d->offW[0]; f.offB = d->offB[0]; f.d = d->dims[0]; f.h = d->dims[1]; f.Nb = Nb; f.has_bias = d->has_bias;
+    // rows per workgroup: enough workgroups for the chip (>= 2 per CU), at least one 128-row pass each
+    int rpw = 128 * (int)(((int64_t)Nb * B + 512LL * 128 - 1) / (512LL * 128));
+    if (rpw > 1024) rpw = 1024;
+    f.rows_per_wg = rpw;
+    const int rsegs = (Nb + rpw - 1) / rpw;
+    const size_t lds1 = sizeof(double) * (((TANH_TAB + 1) & ~1) + (size_t)f.h * (f.d + 1));
+    hipLaunchKernelGGL(k_i8_first, dim3(rsegs, B), dim3(512), lds1, st, f, W, X, row_idx, act[0], ad[0], flags);
+    hipLaunchKernelGGL(k_i8_first_slow, dim3((Nb + 255) / 256, B), dim3(256), 0, st, f, W, X, row_idx, act[0], (const int*)flags);
+    for (int li = 0; li < net.nl; ++li) {
+        I8Gemm g;
+        g.p = d->p; g.offW = net.offW[li]; g.offB = net.offB[li]; g.wd_chain = net.dbytes; g.wd_off = net.offD[li];
+        g.sb_chain = net.sdoubles; g.sb_off = net.offS[li]; g.h_in = net.h[li]; g.h_out = net.h[li + 1]; g.Nb = Nb;
+        g.has_bias = d->has_bias;
+        unsigned char* out_digits = li + 1 < net.nl ? ad[(li + 1) & 1] : nullptr;      // the last hidden layer feeds float64 consumers
+        g.mtiles = g.h_out / 64; g.rsegs = rsegs; g.rows_per_wg = rpw; g.outer_total = rsegs * B;
+        const unsigned grid = (unsigned)(((g.outer_total + 7) / 8) * 8 * g.mtiles);
+        if (g.h_in == 128) {
+            auto kern = k_i8_gemm<QN_I8_LMIN, 2>;
+            if (int rc = i8_arm(reinterpret_cast<const void*>(kern), i8gemm_lds(2))) return rc;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), i8gemm_lds(2), st, g, W, Wd, sb, (const unsigned char*)ad[li & 1],
+                               (const double*)act[li], (const int*)flags, act[li + 1], out_digits);
+        } else {
+            auto kern = k_i8_gemm<QN_I8_LMIN, 4>;
+            if (int rc = i8_arm(reinterpret_cast<const void*>(kern), i8gemm_lds(4))) return rc;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), i8gemm_lds(4), st, g, W, Wd, sb, (const unsigned char*)ad[li & 1],
+                               (const double*)act[li], (const int*)flags, act[li + 1], out_digits);
+        }
+    }
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
 }

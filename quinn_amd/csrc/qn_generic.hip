@@ -9,6 +9,7 @@
 // This family is the always-correct fallback; qn_fused.hip is the MFMA path for
 // LDS-resident weights.
 #include "qn_common.h"
+#include "qn_fused_args.h"
 #include "qn_math.h"
 #include <type_traits>
 #include <algorithm>
@@ -580,6 +581,18 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
             }
         if (need) dwslab = c.take<T>(need);
     }
+    // float64 tanh networks whose hidden widths are multiples of 64: the first layer and the hidden->hidden layers of
+    // the FORWARD pass run as sliced int8 products (qn_fused_i8.hip: qn_i8_layers_forward), unless a kernel family is
+    // forced on the descriptor (QN_PATH_GENERIC stays the exact float64 reference of the tests)
+    bool i8_fwd = false;
+    void* i8_ws = nullptr;
+    if constexpr (std::is_same<T, double>::value) {
+#ifndef QN_NO_I8_LAYERS
+        i8_fwd = d->path == QN_PATH_AUTO && qn_i8_layers_apply(d);
+#endif
+        const size_t nb8 = qn_i8_layers_workspace(d, B, Nb);
+        if (nb8) i8_ws = c.take<char>(nb8);
+    }
     if (c.off > ws_bytes) {
         qn_set_error("workspace too small: need %zu bytes, got %zu", c.off, ws_bytes);
         return QN_EWORKSPACE;
@@ -599,7 +612,12 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         g.ksplit = 1; g.kchunk = Nb;
         return g;
     };
-    for (int l = 0; l + 1 < L; ++l) {
+    if constexpr (std::is_same<T, double>::value) {
+        if (i8_fwd) {
+            if (int rc = qn_i8_layers_forward(d, W, X, row_idx, B, Nb, act.data(), i8_ws, st)) return rc;
+        }
+    }
+    for (int l = 0; l + 1 < L && !i8_fwd; ++l) {
         if (gemm_layer(d, l)) {
             GemmArgs g = gargs(l);
             const unsigned grid = gemm_grid(g, g.h_out / 64, (Nb + 63) / 64, B);
@@ -875,6 +893,7 @@ size_t qn_generic_workspace(const qn_desc* d, int B, int Nb, int want_grad, int 
             }
         tot += qn_align(need * e);
     }
+    if (dtype == QN_F64) tot += qn_align(qn_i8_layers_workspace(d, B, Nb));      // layer-wise int8-slice forward (0 if it does not apply)
     return tot + 256;
 }
 

@@ -143,3 +143,66 @@ def test_path_override_is_per_operator():
     assert b.set_path(_lib.PATH_FUSED_DP) == _lib.PATH_AUTO and a.set_path(_lib.PATH_AUTO) == _lib.PATH_GENERIC
     W = 0.1 * np.random.RandomState(0).randn(8, arch.nparams)
     np.testing.assert_allclose(a.sse(W).cpu().numpy(), b.sse(W).cpu().numpy(), rtol=1e-11)
+
+
+@pytest.mark.parametrize("dims,N,B", [((2, 128, 128, 128, 1), 700, 5), ((1, 256, 256, 256, 256, 1), 300, 3), ((3, 128, 256, 128, 2), 257, 2)],
+                         ids=["3x128", "4x256", "mixed_o2"])
+def test_layerwise_int8_forward_of_wide_networks(dims, N, B):
+    """Hidden widths 128 / 256: the forward part of a GRADIENT evaluation (and, at width 256, of a forward call) runs layer
+    by layer as sliced int8 products (k_i8_slice_w / k_i8_first / k_i8_gemm); QN_PATH_GENERIC is the exact float64
+    layer-wise reference.  SSE, predictions and gradients (the backward pass consumes the stored float64 activations)."""
+    x, y = _data(N, dims[0], dims[-1], seed=7)
+    arch = MLPArch(dims, "tanh")
+    rs = np.random.RandomState(sum(dims))
+    W = rs.randn(B, arch.nparams) / np.sqrt(max(dims))
+    idx = rs.randint(0, N, size=(B, N // 2 + 5))
+    op = BatchedMLP(arch, x, y)
+    res = {}
+    for path in (_lib.PATH_AUTO, _lib.PATH_GENERIC):
+        op.set_path(path)
+        s, g = op.sse_grad(W)
+        s2, pr = op.sse_pred(W, row_idx=idx)
+        res[path] = (s.cpu().numpy(), g.cpu().numpy(), s2.cpu().numpy(), pr.cpu().numpy())
+    op.set_path(_lib.PATH_AUTO)
+    a, r = res[_lib.PATH_AUTO], res[_lib.PATH_GENERIC]
+    np.testing.assert_allclose(a[0], r[0], rtol=1e-11)
+    np.testing.assert_allclose(a[2], r[2], rtol=1e-11)
+    assert np.abs(a[1] - r[1]).max() <= 1e-10 * np.abs(r[1]).max()
+    assert np.abs(a[3] - r[3]).max() <= 1e-11 * np.abs(r[3]).max()
+    mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, "tanh"))
+    ref = mlp_ref.logpost(mod, W[0], x, [v for v in y], 0.1)
+    got = -neg_log_post_from_sse(a[0][0], N * 1, 0.1) if dims[-1] == 1 else None
+    if got is not None:
+        assert abs(got - ref) <= 1e-11 * abs(ref)
+
+
+@pytest.mark.parametrize("where", ["weight_nan", "weight_inf", "weight_huge", "bias_nan", "x_nan", "x_inf", "w0_inf"])
+def test_layerwise_int8_forward_exceptional_values(where):
+    dims = (1, 128, 128, 1)
+    arch = MLPArch(dims, "tanh")
+    x, y = _data(150, 1, 1, seed=1)
+    rs = np.random.RandomState(2)
+    W = 0.2 * rs.randn(3, arch.nparams)
+    off_w1 = 128 + 128 + 5 * 128 + 7                                     # an entry of the hidden matrix
+    if where == "weight_nan": W[1, off_w1] = np.nan
+    if where == "weight_inf": W[1, off_w1] = np.inf
+    if where == "weight_huge": W[1, off_w1] = 1e200
+    if where == "bias_nan": W[1, 128 + 128 + 128 * 128 + 3] = np.nan
+    if where == "w0_inf": W[1, 3] = -np.inf
+    if where == "x_nan": x[17, 0] = np.nan
+    if where == "x_inf": x[140, 0] = -np.inf
+    op = BatchedMLP(arch, x, y)
+    res = {}
+    for path in (_lib.PATH_AUTO, _lib.PATH_GENERIC):
+        op.set_path(path)
+        s, g = op.sse_grad(W)
+        res[path] = (s.cpu().numpy(), g.cpu().numpy())
+    op.set_path(_lib.PATH_AUTO)
+    (sa, ga), (sg, gg) = res[_lib.PATH_AUTO], res[_lib.PATH_GENERIC]
+    assert np.array_equal(np.isnan(sa), np.isnan(sg)) and np.array_equal(np.isinf(sa), np.isinf(sg))
+    ok = np.isfinite(sg)
+    np.testing.assert_allclose(sa[ok], sg[ok], rtol=1e-11)
+    assert np.array_equal(np.isnan(ga), np.isnan(gg))
+    fin = np.isfinite(gg)
+    if fin.any():                                                        # (a NaN input makes every gradient NaN)
+        assert np.abs(ga[fin] - gg[fin]).max() <= 1e-9 * max(np.abs(gg[fin]).max(), 1e-300)

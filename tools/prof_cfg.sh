@@ -33,7 +33,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in agg.items():
-            if "k_gemm64<double" not in k: continue
+            if "k_gemm64<double" not in k and "k_i8_" not in k: continue
             print("==", os.path.basename(d), k)
             for c, v in sorted(cs.items()):
                 print("     %-28s avg/dispatch=%.4g (n=%d)" % (c, sum(v) / len(v), len(v)))
