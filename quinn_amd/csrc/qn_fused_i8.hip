@@ -33,7 +33,9 @@
 #include "qn_common.h"
 #include "qn_fused_args.h"
 #include "qn_math.h"
+#include <mutex>
 #include <type_traits>
+#include <unordered_set>
 #include <utility>
 
 #ifndef QN_I8_G
@@ -900,9 +902,16 @@ bool i8net_of(const qn_desc* d, I8Net* net) {
     return true;
 }
 constexpr size_t i8gemm_lds(int kc) { return (size_t)kc * NS * 64 * 64 + sizeof(double) * (((TANH_TAB + 1) & ~1) + 128); }
+// raise the dynamic-LDS limit of a kernel once per process (not per launch: the launch path stays free of non-stream
+// API calls, so it can be captured into a HIP graph)
 int i8_arm(const void* fn, size_t bytes) {
+    static std::mutex mu;
+    static std::unordered_set<const void*> armed;
     if (bytes <= 64 * 1024) return QN_OK;
+    std::lock_guard<std::mutex> lock(mu);
+    if (armed.count(fn)) return QN_OK;
     QN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    armed.insert(fn);
     return QN_OK;
 }
 }  // namespace
