@@ -1,6 +1,6 @@
 // Fused batched-MLP kernels for gfx950 with the chain's weights resident in LDS.
 //
-// Work decomposition.  grid = (nsplit, B): workgroup (s, b) stages weight vector b into LDS once
+// Work decomposition.  1-D XCD-aware grid over (split s, chain b) (qn_fused_args.h): workgroup (s, b) stages weight vector b into LDS once
 // and walks its share of the data rows; B x nsplit is sized to put >= 2 workgroups on every one
 // of the 256 CUs.  A workgroup is 4 waves; a wave processes G groups of 16 data rows at a time.
 //
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
     double* lds = reinterpret_cast<double*>(smem);
     constexpr int T = H / 16;
     constexpr int S = stride_of(H);
-    const int b = blockIdx.y, split = blockIdx.x;
+    int b, split;
+    if (!qn_fused_wg(a.nsplit, a.B, &b, &split)) return;
     const int d = a.d, o = a.o, NH = a.nhid;
     const int offW0 = 0, offb0 = H * DP, offHH = offb0 + H;
     const int offWl = offHH + (NH - 1) * (H * S + H), offbl = offWl + o * H;
@@ -350,7 +351,8 @@ __global__ __launch_bounds__(NTS, 1) void k_fused_fwd_stream_f64(FusedArgs a, co
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     constexpr int H = HS, T = H / 16, NT = NTS;
-    const int b = blockIdx.y, split = blockIdx.x;
+    int b, split;
+    if (!qn_fused_wg(a.nsplit, a.B, &b, &split)) return;
     const int d = a.d, o = a.o, NH = a.nhid;
     const int nb = a.has_bias ? 1 : 0;
     const int offW0 = 0, offb0 = H * DP, offbh = offb0 + H;
@@ -602,7 +604,8 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
     constexpr int TPW = (TT + 3) / 4;            // dW tiles per wave
     constexpr int TPF = WG / H;                  // threads per feature in the column sums
     constexpr int RPT = ROWS_IT / TPF;           // rows per such thread
-    const int b = blockIdx.y, split = blockIdx.x;
+    int b, split;
+    if (!qn_fused_wg(a.nsplit, a.B, &b, &split)) return;
     const int d = a.d, o = a.o, act_kind = a.act;
     const int nb = a.has_bias ? 1 : 0;
     const int offW0 = 0, offb0 = H * DP, offHH = offb0 + H;
@@ -939,7 +942,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
         QN_STAMP(10);                                      // 10: first-layer stage (2 barriers + sums)
     }
 #ifdef QN_BWD_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
         long long* dbg = reinterpret_cast<long long*>(partial + a.dbg_off);
         for (int k = 0; k < 12; ++k) dbg[k] = stamp_acc[k];
     }
@@ -1236,7 +1239,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
     double* slab = reinterpret_cast<double*>(static_cast<char*>(ws) + npart);
     a.dbg_off = (int64_t)(need / sizeof(double));          // the 256 spare bytes behind the slabs
     size_t lds_bytes = lds_need(H, a.d, a.o, nhid, want_grad);
-    dim3 grid(a.nsplit, B);
+    dim3 grid(qn_fused_grid(a.nsplit, B));
     (void)hipGetLastError();
     if (!want_grad) {
         fwd_fn kern = pick_fwd(H, a.act, padded_d(a.d), a.o);

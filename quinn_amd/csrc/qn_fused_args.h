@@ -10,6 +10,20 @@ struct FusedArgs {
     int64_t dbg_off;     // diagnostic builds: offset (doubles, from the partials) of a 12-word scratch
 };
 
+// Grid of the fused kernels: 1-D and XCD-aware.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (each
+// with its own L2), so workgroup id -> (chain, row split) is chosen such that all splits of a chain share id % 8: the
+// chain's weights come from HBM once and from that XCD's L2 for the other splits (grid (nsplit, B) put the 8 splits of a
+// cfg2 chain on 8 different XCDs: 8 x the weight traffic, taken as one burst at kernel start).
+inline unsigned qn_fused_grid(int nsplit, int B) { return (unsigned)(((B + 7) / 8) * 8 * nsplit); }
+#ifdef __HIPCC__
+__device__ __forceinline__ bool qn_fused_wg(int nsplit, int B, int* b, int* split) {
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    *b = (seq / nsplit) * 8 + xcd;
+    *split = seq % nsplit;
+    return *b < B;
+}
+#endif
+
 using qn_fwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*);
 
 // sliced int8-product forward for 64-wide tanh networks (qn_fused_i8.hip): same grid, block and partial-sum

@@ -286,7 +286,8 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
     constexpr int NLEV = 2 * (NS - 1) - LMIN + 1;       // levels LMIN .. 10
     double* lds = reinterpret_cast<double*>(smem);
     const int NH = a.nhid, d = a.d, o = a.o;
-    const int b = blockIdx.y, split = blockIdx.x;
+    int b, split;
+    if (!qn_fused_wg(a.nsplit, a.B, &b, &split)) return;
     const int offb0 = H * DP, offWl = offb0 + H, offbl = offWl + OMAX * H, offred = offbl + OMAX, offsb = thin_doubles(DP);
     double* tanh_tab = lds + ((offsb + (NH - 1) * 2 * H + 1) & ~1);
     double* scratch = tanh_tab + ((TANH_TAB + 1) & ~1);
