@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libquinn_amd.so")
-SOURCES = ["qn_api.hip", "qn_generic.hip", "qn_fused.hip", "qn_fused_i8.hip", "qn_mcmc.hip", "qn_rnet.hip"]
+SOURCES = ["qn_api.hip", "qn_generic.hip", "qn_fused.hip", "qn_fused_i8.hip", "qn_wide_i8.hip", "qn_mcmc.hip", "qn_rnet.hip"]
 
 QN_F64, QN_F32 = 0, 1
 ACT_CODES = {"identity": 0, "tanh": 1, "relu": 2}
@@ -33,7 +33,7 @@ def build(force=False, verbose=False):
     """Compile the HIP sources for gfx950 into quinn_amd/lib/libquinn_amd.so (hipcc
     cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "qn_common.h"), os.path.join(CSRC, "qn_math.h"), os.path.join(CSRC, "qn_tanh_table.h"), os.path.join(CSRC, "qn_tanh_table64.h"), os.path.join(CSRC, "qn_fused_args.h"), os.path.join(_HERE, "..", "include", "quinn_amd.h")]
+    deps = srcs + [os.path.join(CSRC, "qn_common.h"), os.path.join(CSRC, "qn_math.h"), os.path.join(CSRC, "qn_tanh_table.h"), os.path.join(CSRC, "qn_tanh_table64.h"), os.path.join(CSRC, "qn_fused_args.h"), os.path.join(CSRC, "qn_i8_slice.h"), os.path.join(_HERE, "..", "include", "quinn_amd.h")]
     if not force and os.path.exists(LIBPATH):
         if os.path.getmtime(LIBPATH) >= max(os.path.getmtime(d) for d in deps):
             return LIBPATH

@@ -40,3 +40,11 @@ bool qn_i8_layers_apply(const qn_desc* d);
 size_t qn_i8_layers_workspace(const qn_desc* d, int B, int Nb);
 int qn_i8_layers_forward(const qn_desc* d, const double* W, const double* X, const int32_t* row_idx, int B, int Nb,
                          double* const* act, void* ws, hipStream_t st);
+
+// fused int8-slice forward for 128 / 256-wide tanh networks (qn_wide_i8.hip); used by qn_generic.hip: one launch for the
+// whole forward pass (sse, optional pred / dz_last = 2 (pred - y) / float64 hidden activations act0 + l * act_stride)
+bool qn_i8_wide_applies(const qn_desc* d);
+size_t qn_i8_wide_workspace(const qn_desc* d, int B, int Nb);
+int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const double* Y, const int32_t* row_idx, int B,
+                       int Nb, double* act0, int64_t act_stride, double* dz_last, double* pred, double* sse, void* ws,
+                       hipStream_t st);

@@ -584,14 +584,21 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
     // float64 tanh networks whose hidden widths are multiples of 64: the first layer and the hidden->hidden layers of
     // the FORWARD pass run as sliced int8 products (qn_fused_i8.hip: qn_i8_layers_forward), unless a kernel family is
     // forced on the descriptor (QN_PATH_GENERIC stays the exact float64 reference of the tests)
-    bool i8_fwd = false;
+    bool i8_fwd = false, wide = false;
     void* i8_ws = nullptr;
+    void* wide_ws = nullptr;
     if constexpr (std::is_same<T, double>::value) {
 #ifndef QN_NO_I8_LAYERS
         i8_fwd = d->path == QN_PATH_AUTO && qn_i8_layers_apply(d);
 #endif
         const size_t nb8 = qn_i8_layers_workspace(d, B, Nb);
         if (nb8) i8_ws = c.take<char>(nb8);
+#ifndef QN_NO_I8_WIDE
+        // uniform 128 / 256-wide networks with one output: the whole forward pass is ONE launch (qn_wide_i8.hip)
+        wide = d->path == QN_PATH_AUTO && qn_i8_wide_applies(d);
+#endif
+        const size_t nbw = qn_i8_wide_workspace(d, B, Nb);
+        if (nbw) wide_ws = c.take<char>(nbw);
     }
     if (c.off > ws_bytes) {
         qn_set_error("workspace too small: need %zu bytes, got %zu", c.off, ws_bytes);
@@ -613,11 +620,16 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         return g;
     };
     if constexpr (std::is_same<T, double>::value) {
-        if (i8_fwd) {
+        if (wide) {
+            // activations are written only for the backward pass; act[l] are consecutive, equally sized blocks
+            if (int rc = qn_i8_wide_forward(d, W, X, Y, row_idx, B, Nb, grad ? act[0] : nullptr, act[1] - act[0], dz_last,
+                                            pred, sse, wide_ws, st))
+                return rc;
+        } else if (i8_fwd) {
             if (int rc = qn_i8_layers_forward(d, W, X, row_idx, B, Nb, act.data(), i8_ws, st)) return rc;
         }
     }
-    for (int l = 0; l + 1 < L && !i8_fwd; ++l) {
+    for (int l = 0; l + 1 < L && !i8_fwd && !wide; ++l) {
         if (gemm_layer(d, l)) {
             GemmArgs g = gargs(l);
             const unsigned grid = gemm_grid(g, g.h_out / 64, (Nb + 63) / 64, B);
@@ -630,7 +642,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         hipLaunchKernelGGL((k_fwd_hidden<T, JB>), grid, dim3(BLK), 0, st, a, W, l ? act[l - 1] : (const T*)nullptr,
                            X, row_idx, act[l]);
     }
-    {
+    if (!wide) {
         LayerArgs a = largs(L - 1);
         dim3 grid(nblk, B);
         hipLaunchKernelGGL((k_fwd_last<T>), grid, dim3(BLK), 0, st, a, W, L > 1 ? act[L - 2] : (const T*)nullptr, X, Y,
@@ -894,6 +906,7 @@ size_t qn_generic_workspace(const qn_desc* d, int B, int Nb, int want_grad, int 
         tot += qn_align(need * e);
     }
     if (dtype == QN_F64) tot += qn_align(qn_i8_layers_workspace(d, B, Nb));      // layer-wise int8-slice forward (0 if it does not apply)
+    if (dtype == QN_F64) tot += qn_align(qn_i8_wide_workspace(d, B, Nb));        // fused int8-slice forward (0 if it does not apply)
     return tot + 256;
 }
 

@@ -1,0 +1,538 @@
+// Fused float64 forward for 128- and 256-wide tanh networks (BASELINE configs 3..5) with every hidden->hidden GEMM as
+// SLICED EXACT PRODUCTS on the int8 matrix pipe -- the arithmetic of qn_fused_i8.hip (see its header) for widths whose
+// digit planes no longer fit LDS (6 x 128^2 = 96 KB, 6 x 256^2 = 384 KB per layer).
+//
+// Replaces, for these shapes, the reference's per-sample / per-member forward loops (quinn/vi/bnet.py:202-205,
+// quinn/nns/nnfit.py:133-140, quinn/mcmc/hmc.py:48-60 through quinn/nns/mlp.py:92-101) in ONE launch: first layer,
+// hidden layers, last layer, residual and SSE; with `act0` set it also writes every hidden activation as float64
+// [B][h][Nb] (what the layer-wise backward kernels of qn_generic.hip read), so the gradient path needs no other forward.
+//
+// Organisation.  Workgroup = 4 waves = one chain x 64 data rows per iteration, ONE wave per SIMD (512 registers):
+//   * activations never leave the register file between layers: a wave's 16 rows x h features are h/64 x 6 digit
+//     operands (v4i each); the layer's INPUT digits live in AccVGPRs and feed the MFMAs' B operand directly, the OUTPUT
+//     digits are collected 64 features at a time in VGPRs and parked in AccVGPRs (2 x 96 registers at h = 256);
+//   * the weight digits of a layer are consumed as a stream of TILES (16 output features x whole K: h/64 x 6 KB) that
+//     the four waves fetch together by LDS-DMA into a ring of 3 tile buffers, two tiles ahead; one s_barrier per tile
+//     (raw s_barrier behind an explicit s_waitcnt: the activation stores of the previous epilogue stay in flight);
+//   * per tile: h/64 x 26 exact digit products into 7 int32 level accumulators, then the staged epilogue of
+//     qn_fused_i8.hip (recombine, scale + bias, tanh(n/64)-table activation, digits) with the NEXT tile's MFMAs dealt
+//     out between its stages.  At h = 256 a tile is 104 MFMAs = 1664 cycles of the int8 pipe against ~700 cycles of
+//     vector work: the kernel is bound by the int8 matrix pipe (a float64-MFMA tile of this size: 4096 cycles + tanh).
+// The digit planes come from k_i8_slice_w (once per call, qn_i8_slice.h).  A chain with an unbounded weight, or 64 rows
+// with an unbounded input, take a plain float64 loop (IEEE semantics of the layer-wise kernels).
+#include "qn_common.h"
+#include "qn_fused_args.h"
+#include "qn_math.h"
+#include "qn_i8_slice.h"
+#include <mutex>
+#include <unordered_set>
+
+namespace {
+
+constexpr int WNBUF = 3;                    // ring of weight-tile buffers
+constexpr int WWG = 256;                    // threads per workgroup
+
+struct WideArgs {
+    int64_t p, act_stride;                  // act_stride: doubles between the stashed activations of consecutive layers
+    int B, Nb, d, nhid, has_bias;
+    int nsplit, rows_per_split, iters;
+};
+
+// LDS, doubles first: W0 [h][DP] | b0 [h] | Wl [h] | bl, pad | red [8] | {scale, bias} (nhid-1) x [h][2] | tanh table |
+// slow-path scratch 4 waves x 2 x h | then bytes: ring of WNBUF tiles [h/64][6][16 rows][64 B]
+__host__ __device__ constexpr int wide_thin(int hid, int dp) { return hid * dp + hid + hid + 2 + 8; }
+__host__ __device__ constexpr int wide_head(int hid, int dp, int nhid) {
+    return ((wide_thin(hid, dp) + (nhid - 1) * 2 * hid + 1) & ~1) + ((TANH_TAB + 1) & ~1) + 4 * 2 * hid;
+}
+__host__ __device__ constexpr size_t wide_lds_bytes(int kc, int dp, int nhid) {
+    return sizeof(double) * (size_t)wide_head(64 * kc, dp, nhid) + (size_t)WNBUF * kc * NS * 1024;
+}
+
+__device__ __forceinline__ void wglds16(const unsigned char* src, unsigned char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+// a 128-bit value into AccVGPRs (the compiler makes the copy: v_accvgpr_write); MFMA operands read it from there
+__device__ __forceinline__ v4i to_acc(v4i v) {
+    v4i r;
+    asm volatile("" : "=a"(r) : "0"(v));
+    return r;
+}
+
+// The workgroup's rows of one iteration in plain float64 from the ORIGINAL weights (rare: unbounded weights / inputs).
+// A wave takes its 16 rows one at a time, lane j owns features j, j + 64, ...; the previous layer's activations are
+// broadcast through `scr` (2 x h doubles per wave).  Returns the wave's SSE share in lane 0.
+template <int KC>
+__device__ __noinline__ double wide_slow_rows(int Nb, int d, int nhid, int has_bias, int64_t act_stride,
+                                              const double* __restrict__ Wb, const double* __restrict__ X,
+                                              const double* __restrict__ Y, const int32_t* __restrict__ row_idx, int nbase,
+                                              int b, double* __restrict__ scr, double* __restrict__ act0,
+                                              double* __restrict__ dz_last, double* __restrict__ pred_out) {
+    constexpr int HID = 64 * KC;
+    const int lane = threadIdx.x & 63, nb = has_bias ? 1 : 0;
+    const int64_t gb0 = (int64_t)HID * d, gHH = gb0 + nb * HID, blk = (int64_t)HID * HID + nb * HID;
+    const int64_t gWl = gHH + (int64_t)(nhid - 1) * blk, gbl = gWl + HID;
+    double sse = 0.0;
+    for (int n = nbase; n < nbase + 16 && n < Nb; ++n) {
+        const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * Nb + n] : (int64_t)n;
+        double act[KC];
+#pragma unroll
+        for (int m = 0; m < KC; ++m) {
+            const int f = lane + 64 * m;
+            double z = nb ? Wb[gb0 + f] : 0.0;
+            for (int k = 0; k < d; ++k) z = fma(Wb[(int64_t)f * d + k], X[rr * d + k], z);
+            act[m] = qn_tanh_f64(z);
+            if (act0) act0[((int64_t)b * HID + f) * Nb + n] = act[m];
+        }
+        for (int layer = 1; layer < nhid; ++layer) {
+            double* cur = scr + HID * (layer & 1);
+#pragma unroll
+            for (int m = 0; m < KC; ++m) cur[lane + 64 * m] = act[m];
+            __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the wave's own LDS writes have landed
+            const double* Wg = Wb + gHH + (int64_t)(layer - 1) * blk;
+#pragma unroll
+            for (int m = 0; m < KC; ++m) {
+                const int f = lane + 64 * m;
+                double z = nb ? Wg[(int64_t)HID * HID + f] : 0.0;
+                for (int i = 0; i < HID; ++i) z = fma(Wg[(int64_t)f * HID + i], cur[i], z);
+                act[m] = qn_tanh_f64(z);
+                if (act0) act0[layer * act_stride + ((int64_t)b * HID + f) * Nb + n] = act[m];
+            }
+        }
+        double pp = 0.0;
+#pragma unroll
+        for (int m = 0; m < KC; ++m) pp = fma(Wb[gWl + lane + 64 * m], act[m], pp);
+        const double pr = wave_sum(pp) + (nb ? Wb[gbl] : 0.0);      // lane 0 holds the sum
+        const double res = pr - Y[rr];
+        if (lane == 0) {
+            sse += res * res;
+            if (pred_out) pred_out[(int64_t)b * Nb + n] = pr;
+            if (dz_last) dz_last[(int64_t)b * Nb + n] = 2.0 * res;
+        }
+    }
+    return sse;
+}
+
+template <int KC, int DP, int LMIN>
+__global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double* __restrict__ W, const double* __restrict__ X,
+                                                       const double* __restrict__ Y, const int32_t* __restrict__ row_idx,
+                                                       const unsigned char* __restrict__ Wd, const double* __restrict__ sbg,
+                                                       const int* __restrict__ flags, double* __restrict__ act0,
+                                                       double* __restrict__ dz_last, double* __restrict__ pred_out,
+                                                       double* __restrict__ partial) {
+    constexpr int HID = 64 * KC, TL = 4 * KC, TILE_B = KC * NS * 1024, PLANE = HID * HID, LAYERB = NS * PLANE;
+    constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN), NPT = NPROD * KC;
+    extern __shared__ __attribute__((aligned(16))) char smemw[];
+    double* lds = reinterpret_cast<double*>(smemw);
+    int b, split;
+    if (!qn_fused_wg(a.nsplit, a.B, &b, &split)) return;
+    const int NH = a.nhid, NHH = NH - 1, d = a.d, nb = a.has_bias ? 1 : 0;
+    const int offb0 = HID * DP, offWl = offb0 + HID, offbl = offWl + HID, offred = offbl + 2, offsb = wide_thin(HID, DP);
+    double* tanh_tab = lds + ((offsb + NHH * 2 * HID + 1) & ~1);
+    double* scratch = tanh_tab + ((TANH_TAB + 1) & ~1);
+    unsigned char* ring = reinterpret_cast<unsigned char*>(lds + wide_head(HID, DP, NH));
+    double* red = lds + offred;
+    const double* Wb = W + (int64_t)b * a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c = lane & 15;
+    const bool stash = act0 != nullptr;
+
+    // ---- the weight-tile stream: tile (li, T) = output features 16 T .. 16 T + 15 of hidden->hidden layer li, whole K
+    const unsigned char* wdc = Wd + (int64_t)b * NHH * LAYERB + (int64_t)(lane >> 2) * HID + 16 * (lane & 3);
+    int pf_li = 0, pf_T = 0, pf_slot = 0;
+    auto dma_next = [&]() {
+        const unsigned char* src = wdc + (int64_t)pf_li * LAYERB + (int64_t)(16 * pf_T) * HID;
+        unsigned char* dst = ring + pf_slot * TILE_B;
+#pragma unroll
+        for (int u = 0; u < KC * NS / 4; ++u) {
+            const int i = wave + 4 * u, kc = i / NS, wi = i - kc * NS;
+            wglds16(src + (int64_t)wi * PLANE + 64 * kc, dst + i * 1024);
+        }
+        if (++pf_T == TL) {
+            pf_T = 0;
+            if (++pf_li == NHH) pf_li = 0;
+        }
+        pf_slot = pf_slot + 1 == WNBUF ? 0 : pf_slot + 1;
+    };
+    dma_next();
+    dma_next();
+    int rd_slot = 0;
+    // the next tile has landed for every wave and every wave is done reading the tile before the current one, whose
+    // buffer receives the tile after next.  With the activation stash on, the epilogue's 4 stores stay in flight
+    // (vmcnt counts in issue order: at least one later tile's DMA or 4 more stores were issued behind any DMA waited for)
+    bool relaxed = false;                   // per wave and iteration: the 4 stores of every epilogue are really issued
+    auto sync_tile = [&]() {
+        if (relaxed) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        dma_next();
+    };
+
+    // ---- resident pieces
+    qn_tanh_table64_stage(tanh_tab, tid, WWG);
+    int bad = flags[b];
+    {
+        auto chk = [&](double v) { bad |= !qn_bounded(v); return v; };
+        const int64_t gb0 = (int64_t)HID * d, gHH = gb0 + nb * HID, blk = (int64_t)HID * HID + nb * HID;
+        const int64_t gWl = gHH + (int64_t)NHH * blk, gbl = gWl + HID;
+        for (int e = tid; e < HID * DP; e += WWG) {
+            const int j = e / DP, k = e % DP;
+            lds[e] = k < d ? chk(Wb[(int64_t)j * d + k]) : 0.0;
+        }
+        for (int e = tid; e < HID; e += WWG) {
+            lds[offb0 + e] = nb ? chk(Wb[gb0 + e]) : 0.0;
+            lds[offWl + e] = chk(Wb[gWl + e]);
+        }
+        if (tid == 0) lds[offbl] = nb ? chk(Wb[gbl]) : 0.0;
+        const double* sbs = sbg + (int64_t)b * NHH * 2 * HID;
+        for (int e = tid; e < NHH * 2 * HID; e += WWG) lds[offsb + e] = sbs[e];
+    }
+    const bool w_bad = block_or(bad, red + 6);
+
+    const int lofs = c * 64 + 16 * (q ^ slot_swz(c));          // this lane's 16 bytes inside one [16 rows][64 B] block
+    double sse = 0.0;
+    double xn[DP], yn;
+    int nrow_n, xbad_n;
+    auto fetch = [&](int it) {
+        xbad_n = 0;
+        const int n = split * a.rows_per_split + (it * 4 + wave) * 16 + c;
+        nrow_n = n;
+        const int nn = n < a.Nb ? n : 0;
+        const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            xn[k] = k < d ? X[rr * d + k] : 0.0;
+            xbad_n |= !qn_bounded(xn[k]);
+        }
+        yn = Y[rr];
+    };
+    fetch(0);
+    for (int it = 0; it < a.iters; ++it) {
+        double xk[DP];
+#pragma unroll
+        for (int k = 0; k < DP; ++k) xk[k] = xn[k];
+        const double yk = yn;
+        const int nrow = nrow_n;
+        const bool live = nrow < a.Nb;
+        relaxed = stash && __any(live);
+        // (workgroup-uniform: the tile barriers below need all four waves)
+        const bool exceptional = block_or(w_bad | xbad_n, red + 6);
+        if (it + 1 < a.iters) fetch(it + 1);
+        if (exceptional) {
+            sse += wide_slow_rows<KC>(a.Nb, d, NH, a.has_bias, a.act_stride, Wb, X, Y, row_idx,
+                                      split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave, act0,
+                                      dz_last, pred_out);
+            continue;
+        }
+        const int64_t srow = ((int64_t)b * HID + 4 * q) * a.Nb + (live ? nrow : 0);   // stash: feature 4 q, this lane's row
+
+        // ---- first layer (VALU): a_1 = tanh(W0 x + b0), sliced into the B operand of the first hidden layer
+        v4i Bin[KC][NS];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            v4i Bcur[NS];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                double av[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 64 * kc + 16 * t + 4 * q + r;
+                    double z = lds[offb0 + j];
+#pragma unroll
+                    for (int k = 0; k < DP; ++k) z = fma(lds[j * DP + k], xk[k], z);
+                    av[r] = qn_tanh_f64_tab64(z, tanh_tab);
+                    if (stash && live) act0[srow + (int64_t)(64 * kc + 16 * t + r) * a.Nb] = av[r];
+                }
+                int S[NS];
+                slice4(av, S);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) Bcur[k][t] = S[k];
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) Bin[kc][k] = to_acc(Bcur[k]);
+        }
+
+        // ---- hidden -> hidden layers
+        double prt = 0.0;
+        auto load_frags = [&](v4i (&Af)[NS], const unsigned char* blk) {
+#pragma unroll
+            for (int wi = 0; wi < NS; ++wi) Af[wi] = *reinterpret_cast<const v4i*>(blk + wi * 1024);
+        };
+        // all of a tile's MFMAs back to back (the first tile of a layer: nothing to hide them behind)
+        auto burst = [&](v4i (&acc)[NLEV], const unsigned char* tile) {
+            v4i Af[2][NS];
+            load_frags(Af[0], tile);
+            for_each_stage([&](auto k_tag) {
+                constexpr int k = decltype(k_tag)::value, kc = k / NPROD, kk = k - kc * NPROD;
+                if constexpr (kk == 0 && kc + 1 < KC) load_frags(Af[(kc + 1) & 1], tile + (kc + 1) * NS * 1024);
+                issue_product_c<LMIN, NLEV, kc == 0, kk>(acc, Af[kc & 1], Bin[kc]);
+            }, std::make_integer_sequence<int, NPT>{});
+        };
+        // Epilogue of one tile in STAGES of a few vector instructions for each of its 4 elements, with the MFMAs of the
+        // NEXT tile dealt out between the stages (see qn_fused_i8.hip); K > 64: the levels are recombined one by one in
+        // float64 (pair sums would not fit int32)
+        auto epilogue = [&](auto last_tag, auto next_tag, const v4i (&acc)[NLEV], v4i (&accn)[NLEV], const unsigned char* tile_next,
+                            const double* sbt, const double* wlt, double* stp, int (&S)[NS]) {
+            constexpr bool LAST = decltype(last_tag)::value, NEXT = decltype(next_tag)::value;
+            constexpr int NSTAGE = 20;
+            v4i Af[2][NS];
+            double2 sc[4];
+            double ts[4], z[4], ax[4], zm[4], Tt[4], bb[4], b2[4], pp[4], tb[4], num[4], den[4], y0[4], e0[4], av[4];
+            int lo[4], hi[4], p01, q01, p23, q23, r01, r23;
+            auto stage = [&](auto st_tag) {
+                constexpr int st = decltype(st_tag)::value;
+                if constexpr (NEXT) {
+                    constexpr int from = st ? stage_quota(st - 1, NPT) : 0, upto = stage_quota(st, NPT);
+                    for_each_stage([&](auto k_tag) {
+                        constexpr int k = from + decltype(k_tag)::value, kc = k / NPROD, kk = k - kc * NPROD;
+                        if constexpr (kk == 0 && kc + 1 < KC) load_frags(Af[(kc + 1) & 1], tile_next + (kc + 1) * NS * 1024);
+                        issue_product_c<LMIN, NLEV, kc == 0, kk>(accn, Af[kc & 1], Bin[kc]);
+                    }, std::make_integer_sequence<int, upto - from>{});
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    switch (st) {
+                    case 0:
+                        sc[r] = *reinterpret_cast<const double2*>(sbt + 2 * r);
+                        ts[r] = (double)acc[NLEV - 1][r];
+                        break;
+                    case 1:
+                        ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 2][r]);
+                        ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 3][r]);
+                        break;
+                    case 2:
+                        ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 4][r]);
+                        ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 5][r]);
+                        break;
+                    case 3:
+                        ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 6][r]);
+                        if constexpr (NLEV >= 7) ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 7][r]);
+                        z[r] = fma(ts[r], sc[r].x, sc[r].y);
+                        break;
+                    case 4:
+                        asm("v_min_f64 %0, |%1|, %2" : "=v"(ax[r]) : "v"(z[r]), "s"(20.0));
+                        zm[r] = fma(ax[r], 64.0, 6755399441055744.0);
+                        break;
+                    case 5:
+                        Tt[r] = tanh_tab[__double2loint(zm[r])];
+                        bb[r] = fma(zm[r] - 6755399441055744.0, -0.015625, ax[r]);
+                        break;
+                    case 6:
+                        b2[r] = bb[r] * bb[r];
+                        break;
+                    case 7:
+                        pp[r] = fma(b2[r], 1.33333333333333333e-01, -3.33333333333333333e-01);
+                        b2[r] = bb[r] * b2[r];
+                        break;
+                    case 8:
+                        tb[r] = fma(b2[r], pp[r], bb[r]);
+                        break;
+                    case 9:
+                        num[r] = Tt[r] + tb[r];
+                        den[r] = fma(Tt[r], tb[r], 1.0);
+                        break;
+                    case 10:
+                        y0[r] = __builtin_amdgcn_rcp(den[r]);
+                        break;
+                    case 11:
+                        e0[r] = fma(-den[r], y0[r], 1.0);
+                        break;
+                    case 12:
+                        e0[r] = fma(e0[r], e0[r], e0[r]);
+                        break;
+                    case 13:
+                        y0[r] = fma(y0[r], e0[r], y0[r]);
+                        break;
+                    case 14:
+                        av[r] = __builtin_copysign(num[r] * y0[r], z[r]);
+                        if (stp) stp[(int64_t)r * a.Nb] = av[r];
+                        break;
+                    case 15:
+                        if constexpr (LAST) {
+                            prt = fma(wlt[r], av[r], prt);
+                        } else {
+                            const double x = fma(av[r], 0x1p46, kMagic);
+                            lo[r] = __double2loint(x);
+                            hi[r] = __double2hiint(x);
+                        }
+                        break;
+                    default: break;
+                    }
+                }
+                if (st == 0 && NEXT) load_frags(Af[0], tile_next);
+                if constexpr (!LAST) {
+                    if (st == 16) {
+                        p01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400); q01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602);
+                        p23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400); q23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602);
+                    }
+                    if (st == 17) {
+                        r01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400); r23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400);
+                        S[0] = __builtin_amdgcn_perm(p23, p01, 0x05040100) ^ 0x80808080;
+                        S[1] = __builtin_amdgcn_perm(p23, p01, 0x07060302) ^ 0x80808080;
+                    }
+                    if (st == 18) {
+                        S[2] = __builtin_amdgcn_perm(q23, q01, 0x05040100) ^ 0x80808080;
+                        S[3] = __builtin_amdgcn_perm(q23, q01, 0x07060302) ^ 0x80808080;
+                    }
+                    if (st == 19) {
+                        S[4] = __builtin_amdgcn_perm(r23, r01, 0x05040100) ^ 0x80808080;
+                        S[5] = __builtin_amdgcn_perm(r23, r01, 0x07060302);
+                    }
+                }
+            };
+            for_each_stage(stage, std::make_integer_sequence<int, NSTAGE>{});
+        };
+        auto hidden_layer = [&](auto last_tag, int li) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            const double* sb = lds + offsb + li * 2 * HID + 2 * 4 * q;       // this lane group's features 16 T + 4 q + r
+            const double* wl = lds + offWl + 4 * q;
+            double* stl = stash && live ? act0 + (int64_t)(li + 1) * a.act_stride + srow : nullptr;
+            v4i Bout[KC][NS];
+            v4i Bcur[NS];
+            v4i accA[NLEV], accB[NLEV];
+            sync_tile();
+            burst(accA, ring + rd_slot * TILE_B + lofs);
+            auto tile = [&](auto t_tag) {
+                constexpr int Tt_ = decltype(t_tag)::value;
+                int S[NS];
+                rd_slot = rd_slot + 1 == WNBUF ? 0 : rd_slot + 1;            // (now the slot of tile Tt_ + 1)
+                const unsigned char* nxt = ring + rd_slot * TILE_B + lofs;
+                double* stp = stl ? stl + (int64_t)(16 * Tt_) * a.Nb : nullptr;
+                if constexpr (Tt_ + 1 < TL) {
+                    sync_tile();
+                    if constexpr (Tt_ & 1) epilogue(last_tag, std::true_type{}, accB, accA, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S);
+                    else epilogue(last_tag, std::true_type{}, accA, accB, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S);
+                } else {
+                    if constexpr (Tt_ & 1) epilogue(last_tag, std::false_type{}, accB, accA, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S);
+                    else epilogue(last_tag, std::false_type{}, accA, accB, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S);
+                }
+                if constexpr (!LAST) {
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) Bcur[k][Tt_ & 3] = S[k];
+                    if constexpr ((Tt_ & 3) == 3) {
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) Bout[Tt_ >> 2][k] = to_acc(Bcur[k]);
+                    }
+                }
+            };
+            for_each_stage(tile, std::make_integer_sequence<int, TL>{});
+            if constexpr (!LAST) {
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) Bin[kc][k] = Bout[kc][k];
+            }
+        };
+        for (int li = 0; li < NHH - 1; ++li) hidden_layer(std::false_type{}, li);
+        hidden_layer(std::true_type{}, NHH - 1);
+
+        // ---- last layer: finish the dot over the four lane groups, residual, SSE
+        double pq = prt;
+        pq += __shfl_xor(pq, 16, 64);
+        pq += __shfl_xor(pq, 32, 64);
+        const double pr = pq + lds[offbl];
+        const double res = pr - yk;
+        if (live && q == 0) {
+            sse += res * res;
+            if (pred_out) pred_out[(int64_t)b * a.Nb + nrow] = pr;
+            if (dz_last) dz_last[(int64_t)b * a.Nb + nrow] = 2.0 * res;
+        }
+    }
+    sse = wave_sum(sse);
+    if (lane == 0) red[wave] = sse;
+    __syncthreads();                                     // (vmcnt(0): the two tiles fetched ahead have landed too)
+    if (tid == 0) partial[(int64_t)b * a.nsplit + split] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void k_wide_sum(const double* __restrict__ partial, int nsplit, int B, double* __restrict__ sse) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s = 0.0;
+    for (int i = 0; i < nsplit; ++i) s += partial[(int64_t)b * nsplit + i];
+    sse[b] = s;
+}
+
+void wide_plan(int B, int Nb, WideArgs* a) {
+    const int rows_it = 64, target = 256;                // one workgroup per CU
+    const int max_split = (Nb + rows_it - 1) / rows_it;
+    int nsplit = (target + B - 1) / B;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    int rps = (Nb + nsplit - 1) / nsplit;
+    rps = (rps + rows_it - 1) / rows_it * rows_it;
+    a->nsplit = (Nb + rps - 1) / rps;
+    a->rows_per_split = rps;
+    a->iters = rps / rows_it;
+}
+
+int wide_arm(const void* fn, size_t bytes) {
+    static std::mutex mu;
+    static std::unordered_set<const void*> armed;
+    std::lock_guard<std::mutex> lock(mu);
+    if (armed.count(fn)) return QN_OK;
+    QN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    armed.insert(fn);
+    return QN_OK;
+}
+
+}  // namespace
+
+bool qn_i8_wide_applies(const qn_desc* d) {
+    const int L = d->nlayers;
+    if (d->kind != QN_KIND_MLP || d->act != QN_ACT_TANH || L < 3 || d->dims[0] > 4 || d->dims[L] != 1) return false;
+    const int h = d->dims[1];
+    if (h != 128 && h != 256) return false;
+    for (int l = 1; l < L; ++l)
+        if (d->dims[l] != h) return false;
+    return wide_lds_bytes(h / 64, d->dims[0] <= 2 ? 2 : 4, L - 1) <= 160 * 1024;
+}
+// bytes of: weight digit planes | {scale, bias} pairs | chain flags | SSE partials
+size_t qn_i8_wide_workspace(const qn_desc* d, int B, int Nb) {
+    if (!qn_i8_wide_applies(d)) return 0;
+    const int h = d->dims[1], nhh = d->nlayers - 2;
+    WideArgs a;
+    wide_plan(B, Nb, &a);
+    return qn_align((size_t)B * nhh * NS * h * h) + qn_align((size_t)B * nhh * 2 * h * sizeof(double)) +
+           qn_align((size_t)B * sizeof(int)) + qn_align((size_t)B * a.nsplit * sizeof(double));
+}
+// One launch: sse [B] (+ pred [B][Nb], dz_last [B][Nb] = 2 (pred - y), hidden activations act0 + l * act_stride
+// [B][h][Nb] for l = 0 .. L-2, each optional)
+int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const double* Y, const int32_t* row_idx, int B,
+                       int Nb, double* act0, int64_t act_stride, double* dz_last, double* pred, double* sse, void* ws,
+                       hipStream_t st) {
+    if (!qn_i8_wide_applies(d)) return QN_EUNSUPPORTED;
+    const int h = d->dims[1], nhh = d->nlayers - 2;
+    I8Net net;
+    net.nl = nhh; net.p = d->p; net.has_bias = d->has_bias;
+    for (int li = 0; li < nhh; ++li) {
+        net.h[li] = h; net.h[li + 1] = h;
+        net.offW[li] = d->offW[li + 1]; net.offB[li] = d->offB[li + 1];
+        net.offD[li] = (int64_t)li * NS * h * h; net.offS[li] = (int64_t)li * 2 * h;
+    }
+    net.dbytes = (int64_t)nhh * NS * h * h;
+    net.sdoubles = (int64_t)nhh * 2 * h;
+    char* base = static_cast<char*>(ws);
+    unsigned char* Wd = reinterpret_cast<unsigned char*>(base);
+    base += qn_align((size_t)B * net.dbytes);
+    double* sb = reinterpret_cast<double*>(base);
+    base += qn_align((size_t)B * net.sdoubles * sizeof(double));
+    int* flags = reinterpret_cast<int*>(base);
+    base += qn_align((size_t)B * sizeof(int));
+    double* partial = reinterpret_cast<double*>(base);
+    WideArgs a;
+    a.p = d->p; a.act_stride = act_stride; a.B = B; a.Nb = Nb; a.d = d->dims[0]; a.nhid = d->nlayers - 1;
+    a.has_bias = d->has_bias;
+    wide_plan(B, Nb, &a);
+    QN_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), st));
+    hipLaunchKernelGGL((k_i8_slice_w<QN_I8_LMIN>), dim3(B, nhh, 8), dim3(256), 0, st, net, W, Wd, sb, flags);
+    const int dp = a.d <= 2 ? 2 : 4;
+    const size_t lds = wide_lds_bytes(h / 64, dp, a.nhid);
+    using kfn = void (*)(WideArgs, const double*, const double*, const double*, const int32_t*, const unsigned char*,
+                         const double*, const int*, double*, double*, double*, double*);
+    kfn kern = h == 128 ? (dp == 2 ? k_i8_wide_fwd<2, 2, QN_I8_LMIN> : k_i8_wide_fwd<2, 4, QN_I8_LMIN>)
+                        : (dp == 2 ? k_i8_wide_fwd<4, 2, QN_I8_LMIN> : k_i8_wide_fwd<4, 4, QN_I8_LMIN>);
+    if (int rc = wide_arm(reinterpret_cast<const void*>(kern), lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3(qn_fused_grid(a.nsplit, B)), dim3(WWG), lds, st, a, W, X, Y, row_idx,
+                       (const unsigned char*)Wd, (const double*)sb, (const int*)flags, act0, dz_last, pred, partial);
+    hipLaunchKernelGGL(k_wide_sum, dim3((B + 63) / 64), dim3(64), 0, st, (const double*)partial, a.nsplit, B, sse);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
