@@ -48,9 +48,18 @@ __host__ __device__ constexpr size_t wide_lds_bytes(int kc, int dp, int nhid) {
     return sizeof(double) * (size_t)wide_head(64 * kc, dp, nhid) + (size_t)WNBUF * kc * NS * 1024;
 }
 
-__device__ __forceinline__ void wglds16(const unsigned char* src, unsigned char* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+// LDS-DMA of 16 bytes per lane, issued as inline assembly ON PURPOSE: for the builtin the compiler's wait-count pass
+// puts an s_waitcnt vmcnt(0) in front of the next LDS read that may alias the destination (it cannot tell the ring's
+// buffers apart) -- i.e. right behind the prefetch, which then is no prefetch.  The kernel synchronises the ring itself
+// (sync_tile).  `lds_addr`: byte address in LDS of the wave's 1 KB destination (wave-uniform).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"         // (m0 on the clobber list: that is the point)
+__device__ __forceinline__ void wglds16(const unsigned char* src, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
 // a 128-bit value into AccVGPRs (the compiler makes the copy: v_accvgpr_write); MFMA operands read it from there
 __device__ __forceinline__ v4i to_acc(v4i v) {
@@ -113,13 +122,13 @@ __device__ __noinline__ double wide_slow_rows(int Nb, int d, int nhid, int has_b
     return sse;
 }
 
-template <int KC, int DP, int LMIN>
+template <int KC, int DP, int LMIN, bool STASH>
 __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double* __restrict__ W, const double* __restrict__ X,
                                                        const double* __restrict__ Y, const int32_t* __restrict__ row_idx,
                                                        const unsigned char* __restrict__ Wd, const double* __restrict__ sbg,
                                                        const int* __restrict__ flags, double* __restrict__ act0,
                                                        double* __restrict__ dz_last, double* __restrict__ pred_out,
-                                                       double* __restrict__ partial) {
+                                                       double* __restrict__ partial, double* __restrict__ dump) {
     constexpr int HID = 64 * KC, TL = 4 * KC, TILE_B = KC * NS * 1024, PLANE = HID * HID, LAYERB = NS * PLANE;
     constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN), NPT = NPROD * KC;
     extern __shared__ __attribute__((aligned(16))) char smemw[];
@@ -134,17 +143,18 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
     double* red = lds + offred;
     const double* Wb = W + (int64_t)b * a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c = lane & 15;
-    const bool stash = act0 != nullptr;
 
     // ---- the weight-tile stream: tile (li, T) = output features 16 T .. 16 T + 15 of hidden->hidden layer li, whole K
     const unsigned char* wdc = Wd + (int64_t)b * NHH * LAYERB + (int64_t)(lane >> 2) * HID + 16 * (lane & 3);
+    const unsigned ring_addr = lds_addr_of(ring);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     int pf_li = 0, pf_T = 0, pf_slot = 0;
     auto dma_next = [&]() {
         const unsigned char* src = wdc + (int64_t)pf_li * LAYERB + (int64_t)(16 * pf_T) * HID;
-        unsigned char* dst = ring + pf_slot * TILE_B;
+        const unsigned dst = ring_addr + pf_slot * TILE_B;
 #pragma unroll
         for (int u = 0; u < KC * NS / 4; ++u) {
-            const int i = wave + 4 * u, kc = i / NS, wi = i - kc * NS;
+            const int i = wave_u + 4 * u, kc = i / NS, wi = i - kc * NS;
             wglds16(src + (int64_t)wi * PLANE + 64 * kc, dst + i * 1024);
         }
         if (++pf_T == TL) {
@@ -159,9 +169,8 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
     // the next tile has landed for every wave and every wave is done reading the tile before the current one, whose
     // buffer receives the tile after next.  With the activation stash on, the epilogue's 4 stores stay in flight
     // (vmcnt counts in issue order: at least one later tile's DMA or 4 more stores were issued behind any DMA waited for)
-    bool relaxed = false;                   // per wave and iteration: the 4 stores of every epilogue are really issued
     auto sync_tile = [&]() {
-        if (relaxed) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        if constexpr (STASH) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         dma_next();
     };
@@ -212,17 +221,19 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
         const double yk = yn;
         const int nrow = nrow_n;
         const bool live = nrow < a.Nb;
-        relaxed = stash && __any(live);
         // (workgroup-uniform: the tile barriers below need all four waves)
         const bool exceptional = block_or(w_bad | xbad_n, red + 6);
         if (it + 1 < a.iters) fetch(it + 1);
         if (exceptional) {
             sse += wide_slow_rows<KC>(a.Nb, d, NH, a.has_bias, a.act_stride, Wb, X, Y, row_idx,
-                                      split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave, act0,
-                                      dz_last, pred_out);
+                                      split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave,
+                                      STASH ? act0 : nullptr, dz_last, pred_out);
             continue;
         }
-        const int64_t srow = ((int64_t)b * HID + 4 * q) * a.Nb + (live ? nrow : 0);   // stash: feature 4 q, this lane's row
+        // stash: feature 4 q of this lane's row; rows beyond Nb write to a dump area (no branch in the epilogue: it has
+        // to stay one scheduling region, and every epilogue really issues its 4 stores: sync_tile counts on them)
+        const int64_t srow = ((int64_t)b * HID + 4 * q) * a.Nb + (live ? nrow : 0);
+        double* const dmp = dump + lane;
 
         // ---- first layer (VALU): a_1 = tanh(W0 x + b0), sliced into the B operand of the first hidden layer
         v4i Bin[KC][NS];
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
 #pragma unroll
                     for (int k = 0; k < DP; ++k) z = fma(lds[j * DP + k], xk[k], z);
                     av[r] = qn_tanh_f64_tab64(z, tanh_tab);
-                    if (stash && live) act0[srow + (int64_t)(64 * kc + 16 * t + r) * a.Nb] = av[r];
+                    if constexpr (STASH) (live ? act0 + srow + (int64_t)(64 * kc + 16 * t) * a.Nb : dmp)[(int64_t)r * a.Nb] = av[r];
                 }
                 int S[NS];
                 slice4(av, S);
@@ -266,125 +277,108 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
                 issue_product_c<LMIN, NLEV, kc == 0, kk>(acc, Af[kc & 1], Bin[kc]);
             }, std::make_integer_sequence<int, NPT>{});
         };
-        // Epilogue of one tile in STAGES of a few vector instructions for each of its 4 elements, with the MFMAs of the
-        // NEXT tile dealt out between the stages (see qn_fused_i8.hip); K > 64: the levels are recombined one by one in
-        // float64 (pair sums would not fit int32)
+        // Epilogue of one tile as a PINNED sequence of micro-steps (one or two vector instructions of one element each,
+        // stage-major over the tile's 4 elements), with the NEXT tile's MFMAs dealt out evenly between them.  With one wave
+        // per SIMD nothing else fills the pipes: a burst of MFMAs stalls the wave's in-order issue for 16 cycles each
+        // (vector pipe idle), a run of vector instructions leaves the matrix pipe idle -- the first version of this
+        // kernel (MFMAs in bursts ahead of each stage) measured MFMA busy 40 % + VALU 34 % + waits 25 %, i.e. serial.  One
+        // MFMA every <= 3 vector instructions keeps the int8 pipe busy back to back (16 cycles per MFMA >= 4 issue cycles
+        // + 2..3 x 4); scheduling fences keep the compiler from regrouping.  K > 64: levels are recombined one by one
+        // in float64 (pair sums would not fit int32).
         auto epilogue = [&](auto last_tag, auto next_tag, const v4i (&acc)[NLEV], v4i (&accn)[NLEV], const unsigned char* tile_next,
                             const double* sbt, const double* wlt, double* stp, int (&S)[NS]) {
             constexpr bool LAST = decltype(last_tag)::value, NEXT = decltype(next_tag)::value;
-            constexpr int NSTAGE = 20;
+            constexpr int NST = 11 + NLEV;                        // per-element stages (NLEV recombination stages first)
+            constexpr int NMICRO = NST * 4 + 4;                   // + 4 steps: digit transposition, or the last layer's dot
+            constexpr int LEAD = 3;                               // micro-steps before the first MFMA (its fragments are in flight)
             v4i Af[2][NS];
             double2 sc[4];
             double ts[4], z[4], ax[4], zm[4], Tt[4], bb[4], b2[4], pp[4], tb[4], num[4], den[4], y0[4], e0[4], av[4];
             int lo[4], hi[4], p01, q01, p23, q23, r01, r23;
-            auto stage = [&](auto st_tag) {
-                constexpr int st = decltype(st_tag)::value;
-                if constexpr (NEXT) {
-                    constexpr int from = st ? stage_quota(st - 1, NPT) : 0, upto = stage_quota(st, NPT);
+            auto micro = [&](auto id_tag) {
+                constexpr int id = decltype(id_tag)::value;
+                if constexpr (id == 0 && NEXT) load_frags(Af[0], tile_next);
+                if constexpr (NEXT && id >= LEAD) {
+                    constexpr int from = ((id - LEAD) * NPT + (NMICRO - LEAD) - 1) / (NMICRO - LEAD);
+                    constexpr int upto = ((id - LEAD + 1) * NPT + (NMICRO - LEAD) - 1) / (NMICRO - LEAD);
                     for_each_stage([&](auto k_tag) {
                         constexpr int k = from + decltype(k_tag)::value, kc = k / NPROD, kk = k - kc * NPROD;
                         if constexpr (kk == 0 && kc + 1 < KC) load_frags(Af[(kc + 1) & 1], tile_next + (kc + 1) * NS * 1024);
                         issue_product_c<LMIN, NLEV, kc == 0, kk>(accn, Af[kc & 1], Bin[kc]);
                     }, std::make_integer_sequence<int, upto - from>{});
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    switch (st) {
-                    case 0:
+                if constexpr (id < NST * 4) {
+                    constexpr int st = id >> 2, r = id & 3;
+                    if constexpr (st == 0) {
                         sc[r] = *reinterpret_cast<const double2*>(sbt + 2 * r);
                         ts[r] = (double)acc[NLEV - 1][r];
-                        break;
-                    case 1:
-                        ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 2][r]);
-                        ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 3][r]);
-                        break;
-                    case 2:
-                        ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 4][r]);
-                        ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 5][r]);
-                        break;
-                    case 3:
-                        ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 6][r]);
-                        if constexpr (NLEV >= 7) ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 7][r]);
+                    } else if constexpr (st < NLEV) {
+                        ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 1 - st][r]);
+                    } else if constexpr (st == NLEV) {
                         z[r] = fma(ts[r], sc[r].x, sc[r].y);
-                        break;
-                    case 4:
                         asm("v_min_f64 %0, |%1|, %2" : "=v"(ax[r]) : "v"(z[r]), "s"(20.0));
+                    } else if constexpr (st == NLEV + 1) {
                         zm[r] = fma(ax[r], 64.0, 6755399441055744.0);
-                        break;
-                    case 5:
                         Tt[r] = tanh_tab[__double2loint(zm[r])];
+                    } else if constexpr (st == NLEV + 2) {
                         bb[r] = fma(zm[r] - 6755399441055744.0, -0.015625, ax[r]);
-                        break;
-                    case 6:
+                    } else if constexpr (st == NLEV + 3) {
                         b2[r] = bb[r] * bb[r];
-                        break;
-                    case 7:
                         pp[r] = fma(b2[r], 1.33333333333333333e-01, -3.33333333333333333e-01);
+                    } else if constexpr (st == NLEV + 4) {
                         b2[r] = bb[r] * b2[r];
-                        break;
-                    case 8:
                         tb[r] = fma(b2[r], pp[r], bb[r]);
-                        break;
-                    case 9:
+                    } else if constexpr (st == NLEV + 5) {
                         num[r] = Tt[r] + tb[r];
                         den[r] = fma(Tt[r], tb[r], 1.0);
-                        break;
-                    case 10:
+                    } else if constexpr (st == NLEV + 6) {
                         y0[r] = __builtin_amdgcn_rcp(den[r]);
-                        break;
-                    case 11:
+                    } else if constexpr (st == NLEV + 7) {
                         e0[r] = fma(-den[r], y0[r], 1.0);
-                        break;
-                    case 12:
                         e0[r] = fma(e0[r], e0[r], e0[r]);
-                        break;
-                    case 13:
+                    } else if constexpr (st == NLEV + 8) {
                         y0[r] = fma(y0[r], e0[r], y0[r]);
-                        break;
-                    case 14:
-                        av[r] = __builtin_copysign(num[r] * y0[r], z[r]);
-                        if (stp) stp[(int64_t)r * a.Nb] = av[r];
-                        break;
-                    case 15:
-                        if constexpr (LAST) {
-                            prt = fma(wlt[r], av[r], prt);
-                        } else {
+                        num[r] = num[r] * y0[r];
+                    } else if constexpr (st == NLEV + 9) {
+                        av[r] = __builtin_copysign(num[r], z[r]);
+                        if constexpr (STASH) stp[(int64_t)r * a.Nb] = av[r];
+                    } else {
+                        if constexpr (!LAST) {
                             const double x = fma(av[r], 0x1p46, kMagic);
                             lo[r] = __double2loint(x);
                             hi[r] = __double2hiint(x);
                         }
-                        break;
-                    default: break;
                     }
-                }
-                if (st == 0 && NEXT) load_frags(Af[0], tile_next);
-                if constexpr (!LAST) {
-                    if (st == 16) {
+                } else {
+                    constexpr int ps = id - NST * 4;
+                    if constexpr (LAST) {
+                        prt = fma(wlt[ps], av[ps], prt);
+                    } else if constexpr (ps == 0) {
                         p01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400); q01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602);
                         p23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400); q23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602);
-                    }
-                    if (st == 17) {
+                    } else if constexpr (ps == 1) {
                         r01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400); r23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400);
                         S[0] = __builtin_amdgcn_perm(p23, p01, 0x05040100) ^ 0x80808080;
                         S[1] = __builtin_amdgcn_perm(p23, p01, 0x07060302) ^ 0x80808080;
-                    }
-                    if (st == 18) {
+                    } else if constexpr (ps == 2) {
                         S[2] = __builtin_amdgcn_perm(q23, q01, 0x05040100) ^ 0x80808080;
                         S[3] = __builtin_amdgcn_perm(q23, q01, 0x07060302) ^ 0x80808080;
-                    }
-                    if (st == 19) {
+                    } else {
                         S[4] = __builtin_amdgcn_perm(r23, r01, 0x05040100) ^ 0x80808080;
                         S[5] = __builtin_amdgcn_perm(r23, r01, 0x07060302);
                     }
                 }
+#ifndef QN_WIDE_NOFENCE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             };
-            for_each_stage(stage, std::make_integer_sequence<int, NSTAGE>{});
+            for_each_stage(micro, std::make_integer_sequence<int, NMICRO>{});
         };
         auto hidden_layer = [&](auto last_tag, int li) {
             constexpr bool LAST = decltype(last_tag)::value;
             const double* sb = lds + offsb + li * 2 * HID + 2 * 4 * q;       // this lane group's features 16 T + 4 q + r
             const double* wl = lds + offWl + 4 * q;
-            double* stl = stash && live ? act0 + (int64_t)(li + 1) * a.act_stride + srow : nullptr;
+            double* stl = STASH ? act0 + (int64_t)(li + 1) * a.act_stride + srow : nullptr;
             v4i Bout[KC][NS];
             v4i Bcur[NS];
             v4i accA[NLEV], accB[NLEV];
@@ -395,7 +389,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
                 int S[NS];
                 rd_slot = rd_slot + 1 == WNBUF ? 0 : rd_slot + 1;            // (now the slot of tile Tt_ + 1)
                 const unsigned char* nxt = ring + rd_slot * TILE_B + lofs;
-                double* stp = stl ? stl + (int64_t)(16 * Tt_) * a.Nb : nullptr;
+                double* stp = STASH ? (live ? stl + (int64_t)(16 * Tt_) * a.Nb : dmp) : nullptr;
                 if constexpr (Tt_ + 1 < TL) {
                     sync_tile();
                     if constexpr (Tt_ & 1) epilogue(last_tag, std::true_type{}, accB, accA, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S);
@@ -484,14 +478,15 @@ bool qn_i8_wide_applies(const qn_desc* d) {
         if (d->dims[l] != h) return false;
     return wide_lds_bytes(h / 64, d->dims[0] <= 2 ? 2 : 4, L - 1) <= 160 * 1024;
 }
-// bytes of: weight digit planes | {scale, bias} pairs | chain flags | SSE partials
+// bytes of: weight digit planes | {scale, bias} pairs | chain flags | SSE partials | dump area of the activation stash
 size_t qn_i8_wide_workspace(const qn_desc* d, int B, int Nb) {
     if (!qn_i8_wide_applies(d)) return 0;
     const int h = d->dims[1], nhh = d->nlayers - 2;
     WideArgs a;
     wide_plan(B, Nb, &a);
     return qn_align((size_t)B * nhh * NS * h * h) + qn_align((size_t)B * nhh * 2 * h * sizeof(double)) +
-           qn_align((size_t)B * sizeof(int)) + qn_align((size_t)B * a.nsplit * sizeof(double));
+           qn_align((size_t)B * sizeof(int)) + qn_align((size_t)B * a.nsplit * sizeof(double)) +
+           qn_align(((size_t)3 * Nb + 64) * sizeof(double));
 }
 // One launch: sse [B] (+ pred [B][Nb], dz_last [B][Nb] = 2 (pred - y), hidden activations act0 + l * act_stride
 // [B][h][Nb] for l = 0 .. L-2, each optional)
@@ -518,20 +513,27 @@ int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const
     base += qn_align((size_t)B * sizeof(int));
     double* partial = reinterpret_cast<double*>(base);
     WideArgs a;
+    wide_plan(B, Nb, &a);
+    base += qn_align((size_t)B * a.nsplit * sizeof(double));
+    double* dump = reinterpret_cast<double*>(base);
     a.p = d->p; a.act_stride = act_stride; a.B = B; a.Nb = Nb; a.d = d->dims[0]; a.nhid = d->nlayers - 1;
     a.has_bias = d->has_bias;
-    wide_plan(B, Nb, &a);
     QN_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), st));
     hipLaunchKernelGGL((k_i8_slice_w<QN_I8_LMIN>), dim3(B, nhh, 8), dim3(256), 0, st, net, W, Wd, sb, flags);
     const int dp = a.d <= 2 ? 2 : 4;
     const size_t lds = wide_lds_bytes(h / 64, dp, a.nhid);
     using kfn = void (*)(WideArgs, const double*, const double*, const double*, const int32_t*, const unsigned char*,
-                         const double*, const int*, double*, double*, double*, double*);
-    kfn kern = h == 128 ? (dp == 2 ? k_i8_wide_fwd<2, 2, QN_I8_LMIN> : k_i8_wide_fwd<2, 4, QN_I8_LMIN>)
-                        : (dp == 2 ? k_i8_wide_fwd<4, 2, QN_I8_LMIN> : k_i8_wide_fwd<4, 4, QN_I8_LMIN>);
+                         const double*, const int*, double*, double*, double*, double*, double*);
+    kfn kern;
+    if (act0)
+        kern = h == 128 ? (dp == 2 ? k_i8_wide_fwd<2, 2, QN_I8_LMIN, true> : k_i8_wide_fwd<2, 4, QN_I8_LMIN, true>)
+                        : (dp == 2 ? k_i8_wide_fwd<4, 2, QN_I8_LMIN, true> : k_i8_wide_fwd<4, 4, QN_I8_LMIN, true>);
+    else
+        kern = h == 128 ? (dp == 2 ? k_i8_wide_fwd<2, 2, QN_I8_LMIN, false> : k_i8_wide_fwd<2, 4, QN_I8_LMIN, false>)
+                        : (dp == 2 ? k_i8_wide_fwd<4, 2, QN_I8_LMIN, false> : k_i8_wide_fwd<4, 4, QN_I8_LMIN, false>);
     if (int rc = wide_arm(reinterpret_cast<const void*>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(qn_fused_grid(a.nsplit, B)), dim3(WWG), lds, st, a, W, X, Y, row_idx,
-                       (const unsigned char*)Wd, (const double*)sb, (const int*)flags, act0, dz_last, pred, partial);
+                       (const unsigned char*)Wd, (const double*)sb, (const int*)flags, act0, dz_last, pred, partial, dump);
     hipLaunchKernelGGL(k_wide_sum, dim3((B + 63) / 64), dim3(64), 0, st, (const double*)partial, a.nsplit, B, sse);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
