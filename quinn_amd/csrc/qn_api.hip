@@ -1,6 +1,7 @@
 // C-ABI entry points (include/quinn_amd.h): descriptor, dispatch between the kernel
 // families, and the small elementwise kernels of the VI / ensemble trainers.
 #include "qn_common.h"
+#include "qn_fused_args.h"
 #include "qn_math.h"
 #include <cmath>
 #include <cstring>
@@ -147,8 +148,14 @@ static const qn_desc* fused_desc(const qn_desc* d) { return d->padded ? d->padde
 static bool fused_ok(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
     return d->kind == QN_KIND_MLP && qn_fused_supported(fused_desc(d), B, Nb, want_grad, dtype);
 }
+// 128-wide float64 tanh networks, forward only: the fused int8-slice forward of the layer-wise family (qn_wide_i8.hip,
+// one launch) is faster than the float64-MFMA streaming kernel (cfg3 shape: 1.25 vs 1.52 ms); QN_PATH_FUSED keeps the latter
+static bool prefer_wide(const qn_desc* d, int want_grad, int dtype) {
+    return d->path == QN_PATH_AUTO && !want_grad && dtype == QN_F64 && d->kind == QN_KIND_MLP &&
+           qn_i8_wide_applies(d->padded ? d->padded : d);        // (a zero-padded twin runs through run_padded)
+}
 static bool use_fused(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
-    if (d->path == QN_PATH_GENERIC) return false;
+    if (d->path == QN_PATH_GENERIC || prefer_wide(d, want_grad, dtype)) return false;
     return fused_ok(d, B, Nb, want_grad, dtype);
 }
 static size_t fused_ws(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
@@ -280,7 +287,7 @@ extern "C" size_t qn_workspace_bytes(const qn_desc* d, int B, int Nb, int want_g
     // sized for either family so that qn_mlp_desc_set_path never invalidates a caller's buffer
     size_t g = qn_generic_workspace(d, B, Nb, want_grad, dtype);
     size_t f = fused_ok(d, B, Nb, want_grad, dtype) ? fused_ws(d, B, Nb, want_grad, dtype) : 0;
-    if (d->path == QN_PATH_AUTO && f) return f;
+    if (d->path == QN_PATH_AUTO && f && !prefer_wide(d, want_grad, dtype)) return f;
     if (use_padded_generic(d)) {
         const size_t pg = padded_generic_ws(d, B, Nb, want_grad, dtype);
         g = pg > g ? pg : g;
