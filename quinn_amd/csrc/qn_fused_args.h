@@ -44,7 +44,12 @@ int qn_i8_layers_forward(const qn_desc* d, const double* W, const double* X, con
 // fused int8-slice forward for 128 / 256-wide tanh networks (qn_wide_i8.hip); used by qn_generic.hip: one launch for the
 // whole forward pass (sse, optional pred / dz_last = 2 (pred - y) / float64 hidden activations act0 + l * act_stride)
 bool qn_i8_wide_applies(const qn_desc* d);
-size_t qn_i8_wide_workspace(const qn_desc* d, int B, int Nb);
+size_t qn_i8_wide_workspace(const qn_desc* d, int B, int Nb, int want_grad);
 int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const double* Y, const int32_t* row_idx, int B,
                        int Nb, double* act0, int64_t act_stride, double* dz_last, double* pred, double* sse, void* ws,
                        hipStream_t st);
+// the backward pass through the hidden layers of the same networks: dZ_l (float64 [B][h][Nb] at dz0 + l * dz_stride,
+// l = 0 .. L-2) from the stashed activations and dz_last; same workspace as the forward call of the evaluation
+int qn_i8_wide_backward(const qn_desc* d, const double* W, const double* X, const int32_t* row_idx, int B, int Nb,
+                        const double* act0, int64_t act_stride, const double* dz_last, double* dz0, int64_t dz_stride, void* ws,
+                        hipStream_t st);

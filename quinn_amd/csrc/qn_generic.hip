@@ -566,6 +566,11 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
     if (grad && L > 1) {
         dzbuf[0] = c.take<T>((size_t)B * d->hmax * Nb);
         dzbuf[1] = c.take<T>((size_t)B * d->hmax * Nb);
+        // the fused int8-slice backward writes dZ of EVERY hidden layer before the weight-gradient kernels run: L - 1
+        // consecutive buffers, the two above being the first
+        if constexpr (std::is_same<T, double>::value)
+            if (qn_i8_wide_applies(d))
+                for (int l = 2; l < L - 1; ++l) c.take<T>((size_t)B * d->hmax * Nb);
     }
     const int nblk = (Nb + BLK - 1) / BLK;
     double* partial = c.take<double>((size_t)B * nblk);
@@ -597,7 +602,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         // uniform 128 / 256-wide networks with one output: the whole forward pass is ONE launch (qn_wide_i8.hip)
         wide = d->path == QN_PATH_AUTO && qn_i8_wide_applies(d);
 #endif
-        const size_t nbw = qn_i8_wide_workspace(d, B, Nb);
+        const size_t nbw = qn_i8_wide_workspace(d, B, Nb, grad);
         if (nbw) wide_ws = c.take<char>(nbw);
     }
     if (c.off > ws_bytes) {
@@ -652,8 +657,22 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
     if (grad) {
         constexpr int TJ = 8, TK = 8, KB = 8;
         const T* dz = dz_last;
+        // fused int8-slice backward through the hidden layers (qn_wide_i8.hip): dZ_l of every hidden layer in one launch
+        bool wide_bwd = false;
+        const int64_t dz_stride = (int64_t)(qn_align((size_t)B * d->hmax * Nb * sizeof(T)) / sizeof(T));
+        if constexpr (std::is_same<T, double>::value) {
+#ifndef QN_NO_I8_WIDE_BWD
+            wide_bwd = wide;
+#endif
+            if (wide_bwd) {
+                if (int rc = qn_i8_wide_backward(d, W, X, row_idx, B, Nb, act[0], act[1] - act[0], dz_last, dzbuf[0], dz_stride,
+                                                 wide_ws, st))
+                    return rc;
+            }
+        }
         for (int l = L - 1; l >= 0; --l) {
             LayerArgs a = largs(l);
+            if (wide_bwd && l < L - 1) dz = dzbuf[0] + (int64_t)l * dz_stride;
             if (gemm_layer(d, l)) {
                 GemmArgs g = gargs(l);
                 const int tiles = (g.h_in / 64) * (g.h_out / 64);
@@ -673,6 +692,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                     hipLaunchKernelGGL(k_slab_reduce<T>, dim3(gx, B), dim3(BLK), 0, st, (const T*)dwslab, ks, nW, d->p,
                                        d->offW[l], gradW);
                 }
+                if (wide_bwd) continue;
                 T* dzp = dzbuf[l & 1];
                 g.ksplit = 1; g.kchunk = Nb;
                 hipLaunchKernelGGL((k_gemm64<T, GEMM_DA>), dim3(gemm_grid(g, g.h_in / 64, (Nb + 63) / 64, B)), dim3(BLK), 0,
@@ -683,7 +703,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
             dim3 gridw((a.h_in + TK - 1) / TK, (a.h_out + TJ - 1) / TJ, B);
             hipLaunchKernelGGL((k_dW<T, TJ, TK>), gridw, dim3(BLK), 0, st, a, dz, l ? act[l - 1] : (const T*)nullptr,
                                X, row_idx, gradW);
-            if (l > 0) {
+            if (l > 0 && !wide_bwd) {
                 T* dzp = dzbuf[l & 1];
                 dim3 grida(nblk, (a.h_in + KB - 1) / KB, B);
                 hipLaunchKernelGGL((k_bwd_dA<T, KB>), grida, dim3(BLK), 0, st, a, W, dz, act[l - 1], dzp);
@@ -893,6 +913,8 @@ size_t qn_generic_workspace(const qn_desc* d, int B, int Nb, int want_grad, int 
     if (want_grad) {
         tot += qn_align((size_t)B * d->dims[L] * Nb * e);
         if (L > 1) tot += 2 * qn_align((size_t)B * d->hmax * Nb * e);
+        if (dtype == QN_F64 && qn_i8_wide_applies(d))
+            for (int l = 2; l < L - 1; ++l) tot += qn_align((size_t)B * d->hmax * Nb * e);
     }
     tot += qn_align((size_t)B * ((Nb + BLK - 1) / BLK) * sizeof(double));
     if (want_grad) {
@@ -906,7 +928,7 @@ size_t qn_generic_workspace(const qn_desc* d, int B, int Nb, int want_grad, int 
         tot += qn_align(need * e);
     }
     if (dtype == QN_F64) tot += qn_align(qn_i8_layers_workspace(d, B, Nb));      // layer-wise int8-slice forward (0 if it does not apply)
-    if (dtype == QN_F64) tot += qn_align(qn_i8_wide_workspace(d, B, Nb));        // fused int8-slice forward (0 if it does not apply)
+    if (dtype == QN_F64) tot += qn_align(qn_i8_wide_workspace(d, B, Nb, want_grad));        // fused int8-slice forward (0 if it does not apply)
     return tot + 256;
 }
 

@@ -436,6 +436,360 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
     if (tid == 0) partial[(int64_t)b * a.nsplit + split] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// =====================================================================================================================
+// BACKWARD through the hidden layers as sliced int8 products: dZ_l = (W_l^T dZ_{l+1}) . (1 - a_l^2), l = nhid-1 .. 0,
+// written as float64 [B][h][Nb] per layer (what the weight-gradient kernels read).  Replaces the layer-wise float64
+// GEMMs `dzp = act'(a) . W^T dz` (k_gemm64<DA>, k_bwd_dA of qn_generic.hip), i.e. the reference's autograd through
+// quinn/nns/mlp.py:92-101 (quinn/nns/nnwrap.py:128-150).
+//
+// Same organisation as k_i8_wide_fwd (one wave per SIMD, weight tiles streamed through the LDS ring, B operand in
+// AccVGPRs), with the transposed matrices' digit planes (k_i8_slice_wT: per INPUT feature i a scale 2^e_i over the
+// column W[:, i]).  The B operand are the gradients dZ[j, n], which are not bounded like tanh outputs: every data row n
+// gets its own scale 2^f_n > max_j |dZ[j, n]| (exponent of the row maximum over all h features: in-lane over the 16
+// tiles, then across the 4 lane groups), so a layer's outputs are kept as float64 in AccVGPRs (h/4 values per lane) until
+// the last tile is done and are sliced then.  Error of an element: ~2^-47 of (column scale x row scale) per term, i.e.
+// ~1e-14 of the largest contribution to the sum -- gradients agree with the float64 GEMMs to ~1e-13 of max |g| (tests).
+// Chains with a weight >= 2^100 (or not finite) and 64-row iterations with an unbounded input or |dz_last| >= 2^100 take
+// a plain float64 loop (no overflow can occur below those bounds for up to 8 hidden layers).
+struct WideBwdArgs {
+    int64_t p, act_stride, dz_stride;
+    int B, Nb, d, nhid, has_bias;
+    int nsplit, rows_per_split, iters;
+};
+__host__ __device__ constexpr int wideb_head(int hid, int nhid) {       // Wl [h] | red [8] | scales (nhid-1) x [h] | scratch 4 x 2 h
+    return ((hid + 8 + (nhid - 1) * hid + 1) & ~1) + 4 * 2 * hid;
+}
+__host__ __device__ constexpr size_t wideb_lds_bytes(int kc, int nhid) {
+    return sizeof(double) * (size_t)wideb_head(64 * kc, nhid) + (size_t)WNBUF * kc * NS * 1024;
+}
+__device__ __forceinline__ double to_acc_d(double v) {
+    double r;
+    asm volatile("" : "=a"(r) : "0"(v));
+    return r;
+}
+__device__ __forceinline__ bool qn_bounded100(double v) {              // |v| < 2^100 (and not NaN)
+    return (unsigned)(__double2hiint(v) & 0x7fffffff) < 0x46300000u;
+}
+// four float64 values times `scale` (a power of two that brings them into (-1, 1) x 2^46) -> six digit words
+__device__ __forceinline__ void slice4s(const double (&a)[4], double scale, int (&S)[NS]) {
+    int lo[4], hi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double x = fma(a[r], scale, kMagic);
+        lo[r] = __double2loint(x);
+        hi[r] = __double2hiint(x);
+    }
+    const int p01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400), q01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602);
+    const int p23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400), q23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602);
+    const int r01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400), r23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400);
+    S[0] = __builtin_amdgcn_perm(p23, p01, 0x05040100) ^ 0x80808080;
+    S[1] = __builtin_amdgcn_perm(p23, p01, 0x07060302) ^ 0x80808080;
+    S[2] = __builtin_amdgcn_perm(q23, q01, 0x05040100) ^ 0x80808080;
+    S[3] = __builtin_amdgcn_perm(q23, q01, 0x07060302) ^ 0x80808080;
+    S[4] = __builtin_amdgcn_perm(r23, r01, 0x05040100) ^ 0x80808080;
+    S[5] = __builtin_amdgcn_perm(r23, r01, 0x07060302);
+}
+
+// digit planes of the TRANSPOSED hidden matrices: "row" i of plane = input feature i, K = output feature j; scale per i.
+// grid (B, layers, parts): a workgroup takes K range [part * h / parts, ...) of every row; thread = row i (coalesced
+// reads along i).  flags: bit 0 = a weight that is not finite and < 2^100.
+template <int LMIN>
+__global__ __launch_bounds__(256) void k_i8_slice_wT(I8Net net, const double* __restrict__ W, unsigned char* __restrict__ Wd,
+                                                    double* __restrict__ sc, int* __restrict__ flags) {
+    const int b = blockIdx.x, li = blockIdx.y, tid = threadIdx.x;
+    const int h = net.h[li];                                     // square hidden matrices
+    const double* Wg = W + (int64_t)b * net.p + net.offW[li];
+    unsigned char* planes = Wd + (int64_t)b * net.dbytes + net.offD[li];
+    double* scl = sc + (int64_t)b * net.sdoubles + net.offS[li];
+    const int64_t plane = (int64_t)h * h;
+    const int kper = h / gridDim.z, j0 = blockIdx.z * kper;
+    int bad = 0;
+    for (int i = tid; i < h; i += 256) {
+        unsigned ex = 0;
+        for (int j = 0; j < h; ++j) {
+            const double v = Wg[(int64_t)j * h + i];
+            bad |= !qn_bounded100(v);
+            ex = max(ex, ((unsigned)__double2hiint(v) & 0x7fffffffu) >> 20);
+        }
+        int e = (int)ex - 1022;
+        e = e < -900 ? -900 : e;
+        const double dn = ldexp(1.0, -e);
+        for (int j = j0; j < j0 + kper; j += 4) {
+            double an[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) an[r] = Wg[(int64_t)(j + r) * h + i] * dn;      // exact
+            int S[NS];
+            slice4(an, S);
+            const int kc = j >> 6, m = (j & 63) >> 4, g = (j & 15) >> 2;
+            unsigned char* dst = planes + (int64_t)i * h + 64 * kc + 16 * (g ^ slot_swz(i)) + 4 * m;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(dst + k * plane) = S[k];
+        }
+        if (blockIdx.z == 0) scl[i] = ldexp(1.0, e - 2 * QB + 8 * LMIN);
+    }
+    if (net.has_bias && blockIdx.z == 0)
+        for (int i = tid; i < h; i += 256) bad |= !qn_bounded100(W[(int64_t)b * net.p + net.offB[li] + i]);
+    if (__any(bad) && (tid & 63) == 0) atomicOr(&flags[b], 1);
+}
+
+// the workgroup's rows of one iteration in plain float64 (rare); lane j owns features j, j + 64, ...
+template <int KC>
+__device__ __noinline__ void wide_slow_bwd_rows(int Nb, int d, int nhid, int has_bias, int64_t act_stride, int64_t dz_stride,
+                                                const double* __restrict__ Wb, int nbase, int b, double* __restrict__ scr,
+                                                const double* __restrict__ act0, const double* __restrict__ dz_last,
+                                                double* __restrict__ dz0) {
+    constexpr int HID = 64 * KC;
+    const int lane = threadIdx.x & 63, nb = has_bias ? 1 : 0;
+    const int64_t gHH = (int64_t)HID * d + nb * HID, blk = (int64_t)HID * HID + nb * HID, gWl = gHH + (int64_t)(nhid - 1) * blk;
+    for (int n = nbase; n < nbase + 16 && n < Nb; ++n) {
+        const double dzl = dz_last[(int64_t)b * Nb + n];
+        double g[KC];
+#pragma unroll
+        for (int m = 0; m < KC; ++m) {
+            const int64_t idx = ((int64_t)b * HID + lane + 64 * m) * Nb + n;
+            const double av = act0[(nhid - 1) * act_stride + idx];
+            g[m] = (Wb[gWl + lane + 64 * m] * dzl) * (1.0 - av * av);
+            dz0[(nhid - 1) * dz_stride + idx] = g[m];
+        }
+        for (int li = nhid - 2; li >= 0; --li) {
+            double* cur = scr + HID * (li & 1);
+#pragma unroll
+            for (int m = 0; m < KC; ++m) cur[lane + 64 * m] = g[m];
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            const double* Wg = Wb + gHH + (int64_t)li * blk;
+#pragma unroll
+            for (int m = 0; m < KC; ++m) {
+                const int i = lane + 64 * m;
+                double acc = 0.0;
+                for (int j = 0; j < HID; ++j) acc = fma(Wg[(int64_t)j * HID + i], cur[j], acc);
+                const int64_t idx = ((int64_t)b * HID + i) * Nb + n;
+                const double av = act0[li * act_stride + idx];
+                g[m] = acc * (1.0 - av * av);
+                dz0[li * dz_stride + idx] = g[m];
+            }
+        }
+    }
+}
+
+template <int KC, int DP, int LMIN>
+__global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const double* __restrict__ W, const double* __restrict__ X,
+                                                       const int32_t* __restrict__ row_idx, const unsigned char* __restrict__ WdT,
+                                                       const double* __restrict__ scT, const int* __restrict__ flags,
+                                                       const double* __restrict__ act0, const double* __restrict__ dz_last,
+                                                       double* __restrict__ dz0, double* __restrict__ dump) {
+    constexpr int HID = 64 * KC, TL = 4 * KC, TILE_B = KC * NS * 1024, PLANE = HID * HID, LAYERB = NS * PLANE;
+    constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN), NPT = NPROD * KC;
+    extern __shared__ __attribute__((aligned(16))) char smemb[];
+    double* lds = reinterpret_cast<double*>(smemb);
+    int b, split;
+    if (!qn_fused_wg(a.nsplit, a.B, &b, &split)) return;
+    const int NH = a.nhid, NHH = NH - 1, d = a.d, nb = a.has_bias ? 1 : 0;
+    const int offred = HID, offsc = HID + 8;
+    double* scratch = lds + ((offsc + NHH * HID + 1) & ~1);
+    unsigned char* ring = reinterpret_cast<unsigned char*>(lds + wideb_head(HID, NH));
+    double* red = lds + offred;
+    const double* Wb = W + (int64_t)b * a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c = lane & 15;
+
+    // ---- weight-tile stream: layers from the top down (li = NHH-1 .. 0), tiles T = 16 input features of layer li
+    const unsigned char* wdc = WdT + (int64_t)b * NHH * LAYERB + (int64_t)(lane >> 2) * HID + 16 * (lane & 3);
+    const unsigned ring_addr = lds_addr_of(ring);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int pf_li = NHH - 1, pf_T = 0, pf_slot = 0;
+    auto dma_next = [&]() {
+        const unsigned char* src = wdc + (int64_t)pf_li * LAYERB + (int64_t)(16 * pf_T) * HID;
+        const unsigned dst = ring_addr + pf_slot * TILE_B;
+#pragma unroll
+        for (int u = 0; u < KC * NS / 4; ++u) {
+            const int i = wave_u + 4 * u, kc = i / NS, wi = i - kc * NS;
+            wglds16(src + (int64_t)wi * PLANE + 64 * kc, dst + i * 1024);
+        }
+        if (++pf_T == TL) {
+            pf_T = 0;
+            if (--pf_li < 0) pf_li = NHH - 1;
+        }
+        pf_slot = pf_slot + 1 == WNBUF ? 0 : pf_slot + 1;
+    };
+    dma_next();
+    dma_next();
+    int rd_slot = 0;
+    // (vmcnt in issue order: behind any tile DMA waited for come at least one epilogue's 4 loads + 4 stores and a later
+    // tile's DMA; the newest 8 -- the loads for the next tile and this tile's stores -- may stay in flight)
+    auto sync_tile = [&]() {
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        dma_next();
+    };
+
+    int bad = flags[b];
+    {
+        const int64_t gHH = (int64_t)HID * d + nb * HID, blk = (int64_t)HID * HID + nb * HID, gWl = gHH + (int64_t)NHH * blk;
+        for (int e = tid; e < HID; e += WWG) {
+            const double v = Wb[gWl + e];
+            bad |= !qn_bounded100(v);
+            lds[e] = v;
+        }
+        for (int e = tid; e < HID * d; e += WWG) bad |= !qn_bounded100(Wb[e]);          // (first layer: part of the chain's bound)
+        const double* scs = scT + (int64_t)b * NHH * HID;
+        for (int e = tid; e < NHH * HID; e += WWG) lds[offsc + e] = scs[e];
+    }
+    const bool w_bad = block_or(bad, red + 6);
+
+    const int lofs = c * 64 + 16 * (q ^ slot_swz(c));
+    for (int it = 0; it < a.iters; ++it) {
+        const int nrow = split * a.rows_per_split + (it * 4 + wave) * 16 + c;
+        const bool live = nrow < a.Nb;
+        const int nn = live ? nrow : 0;
+        const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
+        const double dzl = dz_last[(int64_t)b * a.Nb + nn];
+        int xbad = !qn_bounded100(dzl);
+#pragma unroll
+        for (int k = 0; k < DP; ++k)
+            if (k < d) xbad |= !qn_bounded(X[rr * d + k]);
+        const bool exceptional = block_or(w_bad | xbad, red + 6);
+        if (exceptional) {
+            wide_slow_bwd_rows<KC>(a.Nb, d, NH, a.has_bias, a.act_stride, a.dz_stride, Wb,
+                                   split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave, act0, dz_last, dz0);
+            continue;
+        }
+        // element (feature 4 q [+ 16 T + r], this lane's row); rows beyond Nb read row 0 and write to the dump area
+        const int64_t erow = ((int64_t)b * HID + 4 * q) * a.Nb + nn;
+        double* const dmp = dump + lane;
+
+        // ---- top: dZ_{nhid-1} = (1 - a^2) wl dz_last (VALU), kept as float64 until the row maximum is known
+        double V[TL][4];
+        double amax = 0.0;
+        {
+            const double* ap = act0 + (int64_t)(NH - 1) * a.act_stride + erow;
+            double* zp = dz0 + (int64_t)(NH - 1) * a.dz_stride + erow;
+#pragma unroll
+            for (int t = 0; t < TL; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double av = ap[(int64_t)(16 * t + r) * a.Nb];
+                    const double v = (lds[16 * t + 4 * q + r] * dzl) * fma(-av, av, 1.0);
+                    (live ? zp + (int64_t)(16 * t) * a.Nb : dmp)[(int64_t)r * a.Nb] = v;
+                    amax = fmax(amax, fabs(v));
+                    V[t][r] = to_acc_d(v);
+                }
+        }
+        v4i Bin[KC][NS];
+        double rs = 0.0;                                           // 2^f_n: this row's scale of the current B operand
+        // row maximum over the 4 lane groups -> exponent -> digits of the whole row set
+        auto slice_rows = [&]() {
+            double m = amax;
+            m = fmax(m, __shfl_xor(m, 16, 64));
+            m = fmax(m, __shfl_xor(m, 32, 64));
+            int E = (__double2hiint(m) >> 20) & 0x7ff;             // |v| < 2^(E - 1022) for every v of the row
+            E = E < 122 ? 122 : E;
+            const double sl = __hiloint2double((2091 - E) << 20, 0);        // 2^(46 - f), f = E - 1022
+            rs = __hiloint2double((E + 1) << 20, 0);                        // 2^f
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                v4i Bcur[NS];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    double vv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[r] = V[4 * kc + t][r];
+                    int S[NS];
+                    slice4s(vv, sl, S);
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) Bcur[k][t] = S[k];
+                }
+#pragma unroll
+                for (int k = 0; k < NS; ++k) Bin[kc][k] = to_acc(Bcur[k]);
+            }
+            amax = 0.0;
+        };
+        slice_rows();
+
+        auto load_frags = [&](v4i (&Af)[NS], const unsigned char* blk) {
+#pragma unroll
+            for (int wi = 0; wi < NS; ++wi) Af[wi] = *reinterpret_cast<const v4i*>(blk + wi * 1024);
+        };
+        auto burst = [&](v4i (&acc)[NLEV], const unsigned char* tile) {
+            v4i Af[2][NS];
+            load_frags(Af[0], tile);
+            for_each_stage([&](auto k_tag) {
+                constexpr int k = decltype(k_tag)::value, kc = k / NPROD, kk = k - kc * NPROD;
+                if constexpr (kk == 0 && kc + 1 < KC) load_frags(Af[(kc + 1) & 1], tile + (kc + 1) * NS * 1024);
+                issue_product_c<LMIN, NLEV, kc == 0, kk>(acc, Af[kc & 1], Bin[kc]);
+            }, std::make_integer_sequence<int, NPT>{});
+        };
+        for (int li = NHH - 1; li >= 0; --li) {
+            const double* sct = lds + offsc + li * HID + 4 * q;
+            const double* apl = act0 + (int64_t)li * a.act_stride + erow;
+            double* zpl = dz0 + (int64_t)li * a.dz_stride + erow;
+            double an[4], ac[4];                                       // a_l of the next / the current tile's 4 elements
+#pragma unroll
+            for (int r = 0; r < 4; ++r) an[r] = apl[(int64_t)r * a.Nb];
+            v4i accA[NLEV], accB[NLEV];
+            sync_tile();
+            burst(accA, ring + rd_slot * TILE_B + lofs);
+            // epilogue of tile T (pinned micro-steps, the next tile's MFMAs dealt out between them)
+            auto epilogue = [&](auto next_tag, auto t_tag, const v4i (&acc)[NLEV], v4i (&accn)[NLEV], const unsigned char* tile_next) {
+                constexpr bool NEXT = decltype(next_tag)::value;
+                constexpr int Tt_ = decltype(t_tag)::value;
+                constexpr int NST = NLEV + 3, NMICRO = NST * 4, LEAD = 2;
+                v4i Af[2][NS];
+                double ts[4], g[4], v[4];
+                double* stp = live ? zpl + (int64_t)(16 * Tt_) * a.Nb : dmp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ac[r] = an[r];
+                if constexpr (NEXT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) an[r] = apl[(int64_t)(16 * (Tt_ + 1) + r) * a.Nb];
+                }
+                auto micro = [&](auto id_tag) {
+                    constexpr int id = decltype(id_tag)::value;
+                    if constexpr (id == 0 && NEXT) load_frags(Af[0], tile_next);
+                    if constexpr (NEXT && id >= LEAD) {
+                        constexpr int from = ((id - LEAD) * NPT + (NMICRO - LEAD) - 1) / (NMICRO - LEAD);
+                        constexpr int upto = ((id - LEAD + 1) * NPT + (NMICRO - LEAD) - 1) / (NMICRO - LEAD);
+                        for_each_stage([&](auto k_tag) {
+                            constexpr int k = from + decltype(k_tag)::value, kc = k / NPROD, kk = k - kc * NPROD;
+                            if constexpr (kk == 0 && kc + 1 < KC) load_frags(Af[(kc + 1) & 1], tile_next + (kc + 1) * NS * 1024);
+                            issue_product_c<LMIN, NLEV, kc == 0, kk>(accn, Af[kc & 1], Bin[kc]);
+                        }, std::make_integer_sequence<int, upto - from>{});
+                    }
+                    constexpr int st = id >> 2, r = id & 3;
+                    if constexpr (st == 0) {
+                        ts[r] = (double)acc[NLEV - 1][r];
+                    } else if constexpr (st < NLEV) {
+                        ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 1 - st][r]);
+                    } else if constexpr (st == NLEV) {
+                        g[r] = fma(-ac[r], ac[r], 1.0) * rs;
+                    } else if constexpr (st == NLEV + 1) {
+                        v[r] = (ts[r] * sct[16 * Tt_ + r]) * g[r];
+                    } else {
+                        stp[(int64_t)r * a.Nb] = v[r];
+                        amax = fmax(amax, fabs(v[r]));
+                        V[Tt_][r] = to_acc_d(v[r]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                for_each_stage(micro, std::make_integer_sequence<int, NMICRO>{});
+            };
+            auto tile = [&](auto t_tag) {
+                constexpr int Tt_ = decltype(t_tag)::value;
+                rd_slot = rd_slot + 1 == WNBUF ? 0 : rd_slot + 1;
+                const unsigned char* nxt = ring + rd_slot * TILE_B + lofs;
+                if constexpr (Tt_ + 1 < TL) {
+                    sync_tile();
+                    if constexpr (Tt_ & 1) epilogue(std::true_type{}, t_tag, accB, accA, nxt);
+                    else epilogue(std::true_type{}, t_tag, accA, accB, nxt);
+                } else {
+                    if constexpr (Tt_ & 1) epilogue(std::false_type{}, t_tag, accB, accA, nxt);
+                    else epilogue(std::false_type{}, t_tag, accA, accB, nxt);
+                }
+            };
+            for_each_stage(tile, std::make_integer_sequence<int, TL>{});
+            if (li > 0) slice_rows();
+        }
+    }
+    __syncthreads();                                     // (vmcnt(0): the tiles fetched ahead have landed before the LDS is released)
+}
+
 __global__ void k_wide_sum(const double* __restrict__ partial, int nsplit, int B, double* __restrict__ sse) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -476,17 +830,21 @@ bool qn_i8_wide_applies(const qn_desc* d) {
     if (h != 128 && h != 256) return false;
     for (int l = 1; l < L; ++l)
         if (d->dims[l] != h) return false;
-    return wide_lds_bytes(h / 64, d->dims[0] <= 2 ? 2 : 4, L - 1) <= 160 * 1024;
+    return wide_lds_bytes(h / 64, d->dims[0] <= 2 ? 2 : 4, L - 1) <= 160 * 1024 && wideb_lds_bytes(h / 64, L - 1) <= 160 * 1024;
 }
 // bytes of: weight digit planes | {scale, bias} pairs | chain flags | SSE partials | dump area of the activation stash
-size_t qn_i8_wide_workspace(const qn_desc* d, int B, int Nb) {
+size_t qn_i8_wide_workspace(const qn_desc* d, int B, int Nb, int want_grad) {
     if (!qn_i8_wide_applies(d)) return 0;
     const int h = d->dims[1], nhh = d->nlayers - 2;
     WideArgs a;
     wide_plan(B, Nb, &a);
-    return qn_align((size_t)B * nhh * NS * h * h) + qn_align((size_t)B * nhh * 2 * h * sizeof(double)) +
-           qn_align((size_t)B * sizeof(int)) + qn_align((size_t)B * a.nsplit * sizeof(double)) +
-           qn_align(((size_t)3 * Nb + 64) * sizeof(double));
+    size_t tot = qn_align((size_t)B * nhh * NS * h * h) + qn_align((size_t)B * nhh * 2 * h * sizeof(double)) +
+                 qn_align((size_t)B * sizeof(int)) + qn_align((size_t)B * a.nsplit * sizeof(double)) +
+                 qn_align(((size_t)3 * Nb + 64) * sizeof(double));
+    // backward: digit planes of the transposed matrices | their scales | chain flags
+    if (want_grad)
+        tot += qn_align((size_t)B * nhh * NS * h * h) + qn_align((size_t)B * nhh * h * sizeof(double)) + qn_align((size_t)B * sizeof(int));
+    return tot;
 }
 // One launch: sse [B] (+ pred [B][Nb], dz_last [B][Nb] = 2 (pred - y), hidden activations act0 + l * act_stride
 // [B][h][Nb] for l = 0 .. L-2, each optional)
@@ -535,6 +893,54 @@ int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const
     hipLaunchKernelGGL(kern, dim3(qn_fused_grid(a.nsplit, B)), dim3(WWG), lds, st, a, W, X, Y, row_idx,
                        (const unsigned char*)Wd, (const double*)sb, (const int*)flags, act0, dz_last, pred, partial, dump);
     hipLaunchKernelGGL(k_wide_sum, dim3((B + 63) / 64), dim3(64), 0, st, (const double*)partial, a.nsplit, B, sse);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}
+
+// dZ_l = d sse / d (pre-activation of hidden layer l), l = 0 .. L-2, as float64 [B][h][Nb] at dz0 + l * dz_stride, from the
+// forward's stashed activations (act0 + l * act_stride) and dz_last = 2 (pred - y).  `ws` is the SAME workspace the forward
+// call of this evaluation used (its dump area is shared; the backward's own regions lie behind the forward's).
+int qn_i8_wide_backward(const qn_desc* d, const double* W, const double* X, const int32_t* row_idx, int B, int Nb,
+                        const double* act0, int64_t act_stride, const double* dz_last, double* dz0, int64_t dz_stride, void* ws,
+                        hipStream_t st) {
+    if (!qn_i8_wide_applies(d)) return QN_EUNSUPPORTED;
+    const int h = d->dims[1], nhh = d->nlayers - 2;
+    I8Net net;
+    net.nl = nhh; net.p = d->p; net.has_bias = d->has_bias;
+    for (int li = 0; li < nhh; ++li) {
+        net.h[li] = h; net.h[li + 1] = h;
+        net.offW[li] = d->offW[li + 1]; net.offB[li] = d->offB[li + 1];
+        net.offD[li] = (int64_t)li * NS * h * h; net.offS[li] = (int64_t)li * h;
+    }
+    net.dbytes = (int64_t)nhh * NS * h * h;
+    net.sdoubles = (int64_t)nhh * h;
+    WideArgs fa;
+    wide_plan(B, Nb, &fa);
+    char* base = static_cast<char*>(ws);
+    base += qn_align((size_t)B * net.dbytes) + qn_align((size_t)B * nhh * 2 * h * sizeof(double)) + qn_align((size_t)B * sizeof(int)) +
+            qn_align((size_t)B * fa.nsplit * sizeof(double));
+    double* dump = reinterpret_cast<double*>(base);
+    base += qn_align(((size_t)3 * Nb + 64) * sizeof(double));
+    unsigned char* WdT = reinterpret_cast<unsigned char*>(base);
+    base += qn_align((size_t)B * net.dbytes);
+    double* scT = reinterpret_cast<double*>(base);
+    base += qn_align((size_t)B * net.sdoubles * sizeof(double));
+    int* flags = reinterpret_cast<int*>(base);
+    WideBwdArgs a;
+    a.p = d->p; a.act_stride = act_stride; a.dz_stride = dz_stride; a.B = B; a.Nb = Nb; a.d = d->dims[0];
+    a.nhid = d->nlayers - 1; a.has_bias = d->has_bias;
+    a.nsplit = fa.nsplit; a.rows_per_split = fa.rows_per_split; a.iters = fa.iters;
+    QN_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), st));
+    hipLaunchKernelGGL((k_i8_slice_wT<QN_I8_LMIN>), dim3(B, nhh, 4), dim3(256), 0, st, net, W, WdT, scT, flags);
+    const int dp = a.d <= 2 ? 2 : 4;
+    const size_t lds = wideb_lds_bytes(h / 64, a.nhid);
+    using kfn = void (*)(WideBwdArgs, const double*, const double*, const int32_t*, const unsigned char*, const double*,
+                         const int*, const double*, const double*, double*, double*);
+    kfn kern = h == 128 ? (dp == 2 ? k_i8_wide_bwd<2, 2, QN_I8_LMIN> : k_i8_wide_bwd<2, 4, QN_I8_LMIN>)
+                        : (dp == 2 ? k_i8_wide_bwd<4, 2, QN_I8_LMIN> : k_i8_wide_bwd<4, 4, QN_I8_LMIN>);
+    if (int rc = wide_arm(reinterpret_cast<const void*>(kern), lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3(qn_fused_grid(a.nsplit, B)), dim3(WWG), lds, st, a, W, X, row_idx, (const unsigned char*)WdT,
+                       (const double*)scT, (const int*)flags, act0, dz_last, dz0, dump);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }
