@@ -596,7 +596,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
 #ifndef QN_NO_I8_LAYERS
         i8_fwd = d->path == QN_PATH_AUTO && qn_i8_layers_apply(d);
 #endif
-        const size_t nb8 = qn_i8_layers_workspace(d, B, Nb);
+        const size_t nb8 = qn_i8_wide_applies(d) ? 0 : qn_i8_layers_workspace(d, B, Nb);      // (the fused kernels take precedence)
         if (nb8) i8_ws = c.take<char>(nb8);
 #ifndef QN_NO_I8_WIDE
         // uniform 128 / 256-wide networks with one output: the whole forward pass is ONE launch (qn_wide_i8.hip)
@@ -927,7 +927,7 @@ size_t qn_generic_workspace(const qn_desc* d, int B, int Nb, int want_grad, int 
             }
         tot += qn_align(need * e);
     }
-    if (dtype == QN_F64) tot += qn_align(qn_i8_layers_workspace(d, B, Nb));      // layer-wise int8-slice forward (0 if it does not apply)
+    if (dtype == QN_F64 && !qn_i8_wide_applies(d)) tot += qn_align(qn_i8_layers_workspace(d, B, Nb));      // layer-wise int8-slice forward (0 if it does not apply)
     if (dtype == QN_F64) tot += qn_align(qn_i8_wide_workspace(d, B, Nb, want_grad));        // fused int8-slice forward (0 if it does not apply)
     return tot + 256;
 }

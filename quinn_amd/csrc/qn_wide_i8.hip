@@ -166,12 +166,25 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
     dma_next();
     dma_next();
     int rd_slot = 0;
-    // the next tile has landed for every wave and every wave is done reading the tile before the current one, whose
-    // buffer receives the tile after next.  With the activation stash on, the epilogue's 4 stores stay in flight
-    // (vmcnt counts in issue order: at least one later tile's DMA or 4 more stores were issued behind any DMA waited for)
+    // The next tile has landed for every wave and every wave is done reading the tile before the current one, whose buffer
+    // receives the tile after next.  s_waitcnt vmcnt(N) waits for all but the wave's N youngest vector-memory operations
+    // (loads, stores and LDS-DMA count together, in issue order): N = the DMA instructions of ONE tile (the tile fetched
+    // at the previous sync_tile stays in flight: a two-tile lead; vmcnt(0) here cut the lead to one tile and every tile
+    // waited for its successor's DMA) + the 4 activation stores of the epilogue in between.
+#ifdef QN_WIDE_STAMPS
+    long long st_sync = 0, st_burst = 0, st_epi = 0, st_first = 0, st_t0 = __builtin_amdgcn_s_memtime();
+#define QN_ST(var, code) { const long long t_ = __builtin_amdgcn_s_memtime(); code; var += __builtin_amdgcn_s_memtime() - t_; }
+#else
+#define QN_ST(var, code) { code; }
+#endif
     auto sync_tile = [&]() {
-        if constexpr (STASH) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (STASH) {
+            if constexpr (KC == 4) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
+        } else {
+            if constexpr (KC == 4) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+        }
         dma_next();
     };
 
@@ -237,6 +250,9 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
 
         // ---- first layer (VALU): a_1 = tanh(W0 x + b0), sliced into the B operand of the first hidden layer
         v4i Bin[KC][NS];
+#ifdef QN_WIDE_STAMPS
+        const long long tf0_ = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             v4i Bcur[NS];
@@ -261,6 +277,9 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
             for (int k = 0; k < NS; ++k) Bin[kc][k] = to_acc(Bcur[k]);
         }
 
+#ifdef QN_WIDE_STAMPS
+        st_first += __builtin_amdgcn_s_memtime() - tf0_;
+#endif
         // ---- hidden -> hidden layers
         double prt = 0.0;
         auto load_frags = [&](v4i (&Af)[NS], const unsigned char* blk) {
@@ -382,8 +401,8 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
             v4i Bout[KC][NS];
             v4i Bcur[NS];
             v4i accA[NLEV], accB[NLEV];
-            sync_tile();
-            burst(accA, ring + rd_slot * TILE_B + lofs);
+            QN_ST(st_sync, sync_tile())
+            QN_ST(st_burst, burst(accA, ring + rd_slot * TILE_B + lofs))
             auto tile = [&](auto t_tag) {
                 constexpr int Tt_ = decltype(t_tag)::value;
                 int S[NS];
@@ -391,12 +410,12 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
                 const unsigned char* nxt = ring + rd_slot * TILE_B + lofs;
                 double* stp = STASH ? (live ? stl + (int64_t)(16 * Tt_) * a.Nb : dmp) : nullptr;
                 if constexpr (Tt_ + 1 < TL) {
-                    sync_tile();
-                    if constexpr (Tt_ & 1) epilogue(last_tag, std::true_type{}, accB, accA, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S);
-                    else epilogue(last_tag, std::true_type{}, accA, accB, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S);
+                    QN_ST(st_sync, sync_tile())
+                    if constexpr (Tt_ & 1) QN_ST(st_epi, epilogue(last_tag, std::true_type{}, accB, accA, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S))
+                    else QN_ST(st_epi, epilogue(last_tag, std::true_type{}, accA, accB, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S))
                 } else {
-                    if constexpr (Tt_ & 1) epilogue(last_tag, std::false_type{}, accB, accA, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S);
-                    else epilogue(last_tag, std::false_type{}, accA, accB, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S);
+                    if constexpr (Tt_ & 1) QN_ST(st_epi, epilogue(last_tag, std::false_type{}, accB, accA, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S))
+                    else QN_ST(st_epi, epilogue(last_tag, std::false_type{}, accA, accB, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S))
                 }
                 if constexpr (!LAST) {
 #pragma unroll
@@ -430,6 +449,11 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
             if (dz_last) dz_last[(int64_t)b * a.Nb + nrow] = 2.0 * res;
         }
     }
+#ifdef QN_WIDE_STAMPS
+    if (blockIdx.x == 17 && tid == 64)
+        printf("wide fwd KC=%d stash=%d iters=%d: total %lld  sync %lld  burst %lld  epilogue %lld  first layer %lld\n", KC, (int)STASH,
+               a.iters, (long long)(__builtin_amdgcn_s_memtime() - st_t0), st_sync, st_burst, st_epi, st_first);
+#endif
     sse = wave_sum(sse);
     if (lane == 0) red[wave] = sse;
     __syncthreads();                                     // (vmcnt(0): the two tiles fetched ahead have landed too)
@@ -506,7 +530,8 @@ __global__ __launch_bounds__(256) void k_i8_slice_wT(I8Net net, const double* __
     int bad = 0;
     for (int i = tid; i < h; i += 256) {
         unsigned ex = 0;
-        for (int j = 0; j < h; ++j) {
+#pragma unroll 16
+        for (int j = 0; j < h; ++j) {                                 // (16 independent loads in flight)
             const double v = Wg[(int64_t)j * h + i];
             bad |= !qn_bounded100(v);
             ex = max(ex, ((unsigned)__double2hiint(v) & 0x7fffffffu) >> 20);
@@ -613,10 +638,13 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
     dma_next();
     dma_next();
     int rd_slot = 0;
-    // (vmcnt in issue order: behind any tile DMA waited for come at least one epilogue's 4 loads + 4 stores and a later
-    // tile's DMA; the newest 8 -- the loads for the next tile and this tile's stores -- may stay in flight)
+#ifdef QN_WIDE_STAMPS
+    long long st_sync = 0, st_burst = 0, st_epi = 0, st_top = 0, st_slice = 0, st_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    // (as in k_i8_wide_fwd: the youngest tile DMA + one epilogue's 4 loads and 4 stores may stay in flight)
     auto sync_tile = [&]() {
-        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        if constexpr (KC == 4) asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(11)\n\ts_barrier" ::: "memory");
         dma_next();
     };
 
@@ -658,20 +686,42 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
         // ---- top: dZ_{nhid-1} = (1 - a^2) wl dz_last (VALU), kept as float64 until the row maximum is known
         double V[TL][4];
         double amax = 0.0;
+#ifdef QN_WIDE_STAMPS
+        const long long tt0_ = __builtin_amdgcn_s_memtime();
+#endif
         {
+            // (loads in batches of 16, the next batch issued ahead of the current one's arithmetic and stores: the stores
+            // may alias the loads as far as the compiler knows, and one load -> store at a time is one HBM round trip each:
+            // measured 33 % / 53 % of the kernel at h = 256 / 128 before)
             const double* ap = act0 + (int64_t)(NH - 1) * a.act_stride + erow;
             double* zp = dz0 + (int64_t)(NH - 1) * a.dz_stride + erow;
+            double abuf[2][16];
+            auto load_batch = [&](int bi, double (&dst)[16]) {
 #pragma unroll
-            for (int t = 0; t < TL; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double av = ap[(int64_t)(16 * t + r) * a.Nb];
-                    const double v = (lds[16 * t + 4 * q + r] * dzl) * fma(-av, av, 1.0);
-                    (live ? zp + (int64_t)(16 * t) * a.Nb : dmp)[(int64_t)r * a.Nb] = v;
-                    amax = fmax(amax, fabs(v));
-                    V[t][r] = to_acc_d(v);
-                }
+                    for (int r = 0; r < 4; ++r) dst[4 * t + r] = ap[(int64_t)(16 * (4 * bi + t) + r) * a.Nb];
+            };
+            load_batch(0, abuf[0]);
+#pragma unroll
+            for (int bi = 0; bi < KC; ++bi) {
+                if (bi + 1 < KC) load_batch(bi + 1, abuf[(bi + 1) & 1]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int T_ = 4 * bi + t;
+                        const double av = abuf[bi & 1][4 * t + r];
+                        const double v = (lds[16 * T_ + 4 * q + r] * dzl) * fma(-av, av, 1.0);
+                        (live ? zp + (int64_t)(16 * T_) * a.Nb : dmp)[(int64_t)r * a.Nb] = v;
+                        amax = fmax(amax, fabs(v));
+                        V[T_][r] = to_acc_d(v);
+                    }
+            }
         }
+#ifdef QN_WIDE_STAMPS
+        st_top += __builtin_amdgcn_s_memtime() - tt0_;
+#endif
         v4i Bin[KC][NS];
         double rs = 0.0;                                           // 2^f_n: this row's scale of the current B operand
         // row maximum over the 4 lane groups -> exponent -> digits of the whole row set
@@ -701,7 +751,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
             }
             amax = 0.0;
         };
-        slice_rows();
+        QN_ST(st_slice, slice_rows())
 
         auto load_frags = [&](v4i (&Af)[NS], const unsigned char* blk) {
 #pragma unroll
@@ -720,12 +770,16 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
             const double* sct = lds + offsc + li * HID + 4 * q;
             const double* apl = act0 + (int64_t)li * a.act_stride + erow;
             double* zpl = dz0 + (int64_t)li * a.dz_stride + erow;
-            double an[4], ac[4];                                       // a_l of the next / the current tile's 4 elements
+            // a_l of the tile's 4 elements, fetched TWO tiles ahead (an HBM round trip is longer than one tile's epilogue)
+            double ab[3][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) an[r] = apl[(int64_t)r * a.Nb];
+            for (int r = 0; r < 4; ++r) {
+                ab[0][r] = apl[(int64_t)r * a.Nb];
+                ab[1][r] = apl[(int64_t)(16 + r) * a.Nb];
+            }
             v4i accA[NLEV], accB[NLEV];
-            sync_tile();
-            burst(accA, ring + rd_slot * TILE_B + lofs);
+            QN_ST(st_sync, sync_tile())
+            QN_ST(st_burst, burst(accA, ring + rd_slot * TILE_B + lofs))
             // epilogue of tile T (pinned micro-steps, the next tile's MFMAs dealt out between them)
             auto epilogue = [&](auto next_tag, auto t_tag, const v4i (&acc)[NLEV], v4i (&accn)[NLEV], const unsigned char* tile_next) {
                 constexpr bool NEXT = decltype(next_tag)::value;
@@ -734,11 +788,12 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
                 v4i Af[2][NS];
                 double ts[4], g[4], v[4];
                 double* stp = live ? zpl + (int64_t)(16 * Tt_) * a.Nb : dmp;
+                const double (&ac)[4] = ab[Tt_ % 3];
+                // (always 4 loads per epilogue: sync_tile counts on them; past the last tile they re-read the last one)
+                {
+                    constexpr int Tn = Tt_ + 2 < TL ? Tt_ + 2 : TL - 1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ac[r] = an[r];
-                if constexpr (NEXT) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) an[r] = apl[(int64_t)(16 * (Tt_ + 1) + r) * a.Nb];
+                    for (int r = 0; r < 4; ++r) ab[(Tt_ + 2) % 3][r] = apl[(int64_t)(16 * Tn + r) * a.Nb];
                 }
                 auto micro = [&](auto id_tag) {
                     constexpr int id = decltype(id_tag)::value;
@@ -775,18 +830,23 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
                 rd_slot = rd_slot + 1 == WNBUF ? 0 : rd_slot + 1;
                 const unsigned char* nxt = ring + rd_slot * TILE_B + lofs;
                 if constexpr (Tt_ + 1 < TL) {
-                    sync_tile();
-                    if constexpr (Tt_ & 1) epilogue(std::true_type{}, t_tag, accB, accA, nxt);
-                    else epilogue(std::true_type{}, t_tag, accA, accB, nxt);
+                    QN_ST(st_sync, sync_tile())
+                    if constexpr (Tt_ & 1) QN_ST(st_epi, epilogue(std::true_type{}, t_tag, accB, accA, nxt))
+                    else QN_ST(st_epi, epilogue(std::true_type{}, t_tag, accA, accB, nxt))
                 } else {
-                    if constexpr (Tt_ & 1) epilogue(std::false_type{}, t_tag, accB, accA, nxt);
-                    else epilogue(std::false_type{}, t_tag, accA, accB, nxt);
+                    if constexpr (Tt_ & 1) QN_ST(st_epi, epilogue(std::false_type{}, t_tag, accB, accA, nxt))
+                    else QN_ST(st_epi, epilogue(std::false_type{}, t_tag, accA, accB, nxt))
                 }
             };
             for_each_stage(tile, std::make_integer_sequence<int, TL>{});
-            if (li > 0) slice_rows();
+            if (li > 0) QN_ST(st_slice, slice_rows())
         }
     }
+#ifdef QN_WIDE_STAMPS
+    if (blockIdx.x == 17 && tid == 64)
+        printf("wide bwd KC=%d iters=%d: total %lld  sync %lld  burst %lld  epilogue %lld  top %lld  slice %lld\n", KC, a.iters,
+               (long long)(__builtin_amdgcn_s_memtime() - st_t0), st_sync, st_burst, st_epi, st_top, st_slice);
+#endif
     __syncthreads();                                     // (vmcnt(0): the tiles fetched ahead have landed before the LDS is released)
 }
 
