@@ -1,0 +1,286 @@
+// Weight gradient of a hidden->hidden layer as SLICED EXACT PRODUCTS on the int8 matrix pipe:
+//   dW[j][i] = sum_n dZ[j][n] a[i][n],  db[j] = sum_n dZ[j][n]        (float64 operands [B][h][Nb], n = data row)
+// -- what k_gemm64<DW> of qn_generic.hip computes with float64 MFMAs (the reference's autograd through
+// quinn/nns/mlp.py:92-101, quinn/nns/nnwrap.py:128-150), for the 128 / 256-wide tanh networks whose forward and
+// activation-gradient passes run in qn_wide_i8.hip.
+//
+// The contraction runs over data rows, so BOTH operands are sliced on the fly, 64 rows (one K-chunk) at a time:
+// a[i][n] in [-1, 1] (tanh outputs) with the fixed scale 2^-46, dZ[j][n] with one scale per feature j AND chunk
+// (2^e > the largest |dZ[j][n]| of the chunk's 64 rows: 4 DPP steps over the 16 lanes that hold the row), six balanced
+// base-256 digits each (qn_i8_slice.h).  A chunk's 26 digit products per 16 x 16 tile are exact int32 sums (pair sums of
+// adjacent levels fit int32 at K = 64); they are recombined and added into float64 accumulators chunk by chunk, because
+// the scales change from chunk to chunk.
+//
+// Workgroup = 8 waves = one 64 x 64 output tile of one chain over one K-slab, two ROLES (one wave of each per SIMD):
+//   waves 0..3  slicers: load the chunk's 64 x 64 float64 blocks of dZ and a (a 16-lane group = 64 consecutive rows of
+//               one feature: 512 contiguous bytes), scale, slice, write the digit planes [6][64 features][64 B] of both
+//               operands (slot-swizzled: conflict-free ds_read_b128 fragments) + the chunk's 64 scales into one of TWO
+//               LDS buffers; they also carry the bias row sums;
+//   waves 4..7  matrix waves: wave m owns output rows 16 m .. 16 m + 15 x all 64 columns = 4 tiles: 6 + 4 x 6 fragment
+//               reads and 4 x 26 MFMAs per chunk; tile t's int32 levels are recombined into its float64 accumulators
+//               while tile t + 1's MFMAs run (the last tile's while the next chunk's first tile runs).
+// One barrier per chunk.  The int8 pipe runs beside the slicers' vector work (tools/ubench_i8.hip: an MFMA wave keeps
+// its full rate next to a VALU wave of the same SIMD).  Per chunk and SIMD: 104 MFMAs (1700 cycles) against ~310 + 180
+// vector instructions.
+// A chunk with a value that is not finite (or >= 2^900) makes the workgroup redo its tile in plain float64 at the end.
+#include "qn_common.h"
+#include "qn_fused_args.h"
+#include "qn_math.h"
+#include "qn_i8_slice.h"
+
+namespace {
+
+constexpr int DWT = 512;                                  // threads per workgroup
+constexpr int DW_OPER = NS * 64 * 64;                     // one operand's digit planes of a chunk: 24 KB
+constexpr int DW_BUF = 2 * DW_OPER + 64 * (int)sizeof(double);      // + the chunk's scales
+
+struct DwArgs {
+    int64_t out_stride_b, out_stride_k;
+    int h_in, h_out, Nb, has_bias, kchunk;                // kchunk: rows per K-slab
+    int inner, outer_total, per_b;                        // XCD-aware 1-D grid as gemm_grid() of qn_generic.hip
+};
+
+template <int LMIN>
+__global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __restrict__ dz, const double* __restrict__ ap,
+                                                 double* __restrict__ out) {
+    constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN);
+    static_assert(NLEV == 7 || NLEV == 6, "level recombination below is written for LMIN = 4 / 5");
+    extern __shared__ __attribute__((aligned(16))) char smemd[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int inner_i = seq % g.inner, outer = (seq / g.inner) * 8 + xcd;
+    if (outer >= g.outer_total) return;
+    const int b = outer / g.per_b, slab = outer % g.per_b;
+    const int tiles_i = g.h_in / 64;
+    const int j0 = (inner_i / tiles_i) * 64, i0 = (inner_i % tiles_i) * 64;
+    const int Nb = g.Nb, kbeg = slab * g.kchunk, kend = kbeg + g.kchunk < Nb ? kbeg + g.kchunk : Nb;
+    const int nchunks = (kend - kbeg + 63) / 64;
+    const double* Z = dz + ((int64_t)b * g.h_out + j0) * Nb;
+    const double* A = ap + ((int64_t)b * g.h_in + i0) * Nb;
+    double* O = out + (int64_t)b * g.out_stride_b + (int64_t)slab * g.out_stride_k;
+    int* badflag = reinterpret_cast<int*>(smemd + 2 * DW_BUF);
+    if (tid == 0) *badflag = 0;
+    const bool want_rowsum = g.has_bias && i0 == 0;
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ slicers
+        // item (u, wave, lane): feature f = 16 u + 4 wave + (lane >> 4), rows 4 q16 .. 4 q16 + 3 of the chunk, q16 = lane & 15
+        const int q16 = lane & 15, m4 = q16 >> 2, g4 = q16 & 3, fl = 4 * wave + (lane >> 4);
+        double rsum[4] = {0.0, 0.0, 0.0, 0.0};
+        int bad = 0;
+        // a chunk's 4 x 4 + 4 x 4 values of this lane: loaded ONE CHUNK AHEAD of their slicing (two register sets; the
+        // first version loaded and sliced in the same step and spent a memory round trip per chunk: 5800 cycles per chunk
+        // against 1700 of MFMA work)
+        auto load_chunk = [&](int ch, double (&vz)[4][4], double (&va)[4][4]) {
+            const int n0 = kbeg + 64 * ch + 4 * q16;
+            if (n0 + 3 < kend) {                                        // (lane-wise at the ragged end of the slab)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if ((Nb & 1) == 0) {
+                        const double2* sz = reinterpret_cast<const double2*>(Z + (int64_t)(16 * u + fl) * Nb + n0);
+                        const double2* sa = reinterpret_cast<const double2*>(A + (int64_t)(16 * u + fl) * Nb + n0);
+                        const double2 z01 = sz[0], z23 = sz[1], a01 = sa[0], a23 = sa[1];
+                        vz[u][0] = z01.x; vz[u][1] = z01.y; vz[u][2] = z23.x; vz[u][3] = z23.y;
+                        va[u][0] = a01.x; va[u][1] = a01.y; va[u][2] = a23.x; va[u][3] = a23.y;
+                    } else {                                            // odd row count: rows of a feature are 8-byte aligned only
+                        const double* pz = Z + (int64_t)(16 * u + fl) * Nb + n0;
+                        const double* pq = A + (int64_t)(16 * u + fl) * Nb + n0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { vz[u][r] = pz[r]; va[u][r] = pq[r]; }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool in = n0 + r < kend;
+                        vz[u][r] = in ? Z[(int64_t)(16 * u + fl) * Nb + n0 + r] : 0.0;
+                        va[u][r] = in ? A[(int64_t)(16 * u + fl) * Nb + n0 + r] : 0.0;
+                    }
+            }
+        };
+        auto slice_chunk = [&](int ch, const double (&vz)[4][4], const double (&va)[4][4]) {
+            char* buf = smemd + (ch & 1) * DW_BUF;
+            unsigned char* pa = reinterpret_cast<unsigned char*>(buf);
+            unsigned char* pb = pa + DW_OPER;
+            double* scl = reinterpret_cast<double*>(buf + 2 * DW_OPER);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = 16 * u + fl;
+                unsigned ex = 0, exa = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ex = max(ex, ((unsigned)__double2hiint(vz[u][r]) & 0x7fffffffu) >> 20);
+                    exa = max(exa, ((unsigned)__double2hiint(va[u][r]) & 0x7fffffffu) >> 20);
+                }
+                bad |= (ex >= 1923u) | (exa >= 1024u);                   // |dZ| >= 2^900 or not finite; |a| >= 2 or not finite
+                int e = (int)row16_max_u32(ex) - 1022;                   // 2^e > every |dZ| of the feature's 64 rows
+                e = e < -900 ? -900 : e;
+                const double dn = __hiloint2double((1023 - e) << 20, 0);               // 2^-e
+                double an[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) an[r] = vz[u][r] * dn;       // exact, |an| < 1
+                int S[NS];
+                slice4(an, S);
+                const int ofs = f * 64 + 16 * (g4 ^ slot_swz(f)) + 4 * m4;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(pa + k * 4096 + ofs) = S[k];
+                slice4(va[u], S);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(pb + k * 4096 + ofs) = S[k];
+                if (q16 == 0) scl[f] = __hiloint2double((1023 + e - 2 * QB + 8 * LMIN) << 20, 0);   // integer sum -> dZ . a
+                if (want_rowsum) rsum[u] += (vz[u][0] + vz[u][1]) + (vz[u][2] + vz[u][3]);
+            }
+        };
+#ifdef QN_DW_STAMPS
+        long long ts_slice = 0, ts_bar = 0, ts_0 = __builtin_amdgcn_s_memtime();
+#define QN_DST(var, code) { const long long t_ = __builtin_amdgcn_s_memtime(); code; var += __builtin_amdgcn_s_memtime() - t_; }
+#else
+#define QN_DST(var, code) { code; }
+#endif
+        double z0[4][4], a0[4][4], z1[4][4], a1[4][4];
+        if (nchunks > 0) load_chunk(0, z0, a0);
+        for (int ch = 0; ch < nchunks; ch += 2) {
+            if (ch + 1 < nchunks) load_chunk(ch + 1, z1, a1);
+            QN_DST(ts_slice, slice_chunk(ch, z0, a0))
+            // chunk ch is written; the matrix waves are done with chunk ch - 1 (whose buffer chunk ch + 1 overwrites)
+            QN_DST(ts_bar, __syncthreads())
+            if (ch + 1 < nchunks) {
+                if (ch + 2 < nchunks) load_chunk(ch + 2, z0, a0);
+                QN_DST(ts_slice, slice_chunk(ch + 1, z1, a1))
+                QN_DST(ts_bar, __syncthreads())
+            }
+        }
+#ifdef QN_DW_STAMPS
+        if (blockIdx.x == 9 && tid == 0)
+            printf("dw slicer: chunks %d total %lld slice(+load wait) %lld barrier %lld\n", nchunks, (long long)(__builtin_amdgcn_s_memtime() - ts_0), ts_slice, ts_bar);
+#endif
+        __syncthreads();                                                 // (matches the matrix waves' drain step)
+        if (want_rowsum) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                double s = rsum[u];
+                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+                if (q16 == 0) O[(int64_t)g.h_in * g.h_out + j0 + 16 * u + fl] = s;
+            }
+        }
+        if (bad) *badflag = 1;
+    } else {
+        // ------------------------------------------------------------------ matrix waves
+        const int m = wave - 4, q = lane >> 4, c = lane & 15;
+        const int lofs = c * 64 + 16 * (q ^ slot_swz(c));               // this lane's 16 bytes inside a [16 rows][64 B] block
+        double facc[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) facc[t][r] = 0.0;
+        v4i acc[4][NLEV];
+        double sc[4], scp[4];                                            // this / the previous chunk's scales of rows 16 m + 4 q + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[r] = scp[r] = 0.0;
+        // recombine tile t's levels (pairs in int32, then float64) and add them into its accumulators
+        auto convert = [&](int t, const double (&s)[4]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double ts;
+                if constexpr (NLEV == 7) {
+                    ts = (double)acc[t][6][r];
+                    ts = fma(ts, 65536.0, (double)(acc[t][4][r] + (acc[t][5][r] << 8)));
+                    ts = fma(ts, 65536.0, (double)(acc[t][2][r] + (acc[t][3][r] << 8)));
+                    ts = fma(ts, 65536.0, (double)(acc[t][0][r] + (acc[t][1][r] << 8)));
+                } else {
+                    ts = (double)(acc[t][4][r] + (acc[t][5][r] << 8));
+                    ts = fma(ts, 65536.0, (double)(acc[t][2][r] + (acc[t][3][r] << 8)));
+                    ts = fma(ts, 65536.0, (double)(acc[t][0][r] + (acc[t][1][r] << 8)));
+                }
+                facc[t][r] = fma(ts, s[r], facc[t][r]);
+            }
+        };
+        auto products = [&](int t, const v4i (&Af)[NS], const unsigned char* pb) {
+            v4i Bf[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) Bf[k] = *reinterpret_cast<const v4i*>(pb + k * 4096 + t * 1024 + lofs);
+            for_each_stage([&](auto k_tag) {
+                constexpr int k = decltype(k_tag)::value;
+                issue_product_c<LMIN, NLEV, true, k>(acc[t], Af, Bf);
+            }, std::make_integer_sequence<int, NPROD>{});
+        };
+#ifdef QN_DW_STAMPS
+        long long tm_bar = 0, tm_0 = __builtin_amdgcn_s_memtime();
+#endif
+        for (int ch = 0; ch < nchunks; ++ch) {
+#ifdef QN_DW_STAMPS
+            { const long long t_ = __builtin_amdgcn_s_memtime(); __syncthreads(); tm_bar += __builtin_amdgcn_s_memtime() - t_; }
+#else
+            __syncthreads();                                             // chunk ch is in LDS
+#endif
+            const char* buf = smemd + (ch & 1) * DW_BUF;
+            const unsigned char* pa = reinterpret_cast<const unsigned char*>(buf);
+            const unsigned char* pb = pa + DW_OPER;
+            const double* scl = reinterpret_cast<const double*>(buf + 2 * DW_OPER);
+            v4i Af[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) Af[k] = *reinterpret_cast<const v4i*>(pa + k * 4096 + m * 1024 + lofs);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { scp[r] = sc[r]; sc[r] = scl[16 * m + 4 * q + r]; }
+            products(0, Af, pb);
+            if (ch > 0) convert(3, scp);                                 // the previous chunk's last tile, beside tile 0's MFMAs
+            products(1, Af, pb);
+            convert(0, sc);
+            products(2, Af, pb);
+            convert(1, sc);
+            products(3, Af, pb);
+            convert(2, sc);
+        }
+#ifdef QN_DW_STAMPS
+        if (blockIdx.x == 9 && tid == 256)
+            printf("dw matrix wave: chunks %d total %lld barrier %lld\n", nchunks, (long long)(__builtin_amdgcn_s_memtime() - tm_0), tm_bar);
+#endif
+        __syncthreads();                                                 // drain step
+        if (nchunks > 0) convert(3, sc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) O[(int64_t)(j0 + 16 * m + 4 * q + r) * g.h_in + i0 + 16 * t + c] = facc[t][r];
+    }
+    __syncthreads();
+    if (*badflag) {
+        // exceptional values: the tile again in plain float64 (thread = 8 outputs of one row j)
+        const int jl = tid >> 3, ib = (tid & 7) * 8;
+        double s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb = 0.0;
+        for (int n = kbeg; n < kend; ++n) {
+            const double zv = Z[(int64_t)jl * Nb + n];
+            sb += zv;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] = fma(zv, A[(int64_t)(ib + u) * Nb + n], s[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) O[(int64_t)(j0 + jl) * g.h_in + i0 + ib + u] = s[u];
+        if (want_rowsum && ib == 0) O[(int64_t)g.h_in * g.h_out + j0 + jl] = sb;
+    }
+}
+
+}  // namespace
+
+// dst + b * out_stride_b + slab * out_stride_k receives [h_out x h_in] weights (+ h_out bias sums behind them): the
+// conventions of k_gemm64<DW> (qn_generic.hip), whose split-K slabs and reduction kernel the caller keeps
+int qn_i8_dw(int h_in, int h_out, int has_bias, const double* dz, const double* a_prev, int B, int Nb, double* dst,
+             int64_t out_stride_b, int64_t out_stride_k, int ksplit, int kchunk, hipStream_t st) {
+    if (h_in % 64 || h_out % 64) return QN_EUNSUPPORTED;
+    DwArgs g;
+    g.out_stride_b = out_stride_b; g.out_stride_k = out_stride_k; g.h_in = h_in; g.h_out = h_out; g.Nb = Nb;
+    g.has_bias = has_bias; g.kchunk = kchunk;
+    g.inner = (h_in / 64) * (h_out / 64); g.per_b = ksplit; g.outer_total = ksplit * B;
+    const unsigned grid = (unsigned)(((g.outer_total + 7) / 8) * 8 * g.inner);
+    const size_t lds = 2 * (size_t)DW_BUF + 16;
+    static bool armed = false;                    // (set once; a race only repeats the call)
+    auto kern = k_i8_dw<QN_I8_LMIN>;
+    if (!armed) {
+        QN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        armed = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(DWT), lds, st, g, dz, a_prev, dst);
+    QN_HIP_CHECK(hipGetLastError());
+    return QN_OK;
+}

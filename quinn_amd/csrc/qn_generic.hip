@@ -684,8 +684,21 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                 T* dst = gradW + d->offW[l];
                 g.out_stride_b = d->p; g.out_stride_k = 0;
                 if (ks > 1) { dst = dwslab; g.out_stride_b = (int64_t)ks * nW; g.out_stride_k = nW; }
-                hipLaunchKernelGGL((k_gemm64<T, GEMM_DW>), dim3(gemm_grid(g, tiles, ks, B)), dim3(BLK), 0, st, g, W, dz,
-                                   (const T*)act[l - 1], dst);
+                bool dw_done = false;
+                if constexpr (std::is_same<T, double>::value) {
+#ifndef QN_NO_I8_DW
+                    if (wide_bwd) {          // (sliced int8 products, qn_dw_i8.hip; K-slabs in whole 64-row chunks)
+                        const int kc64 = ((Nb + ks - 1) / ks + 63) / 64 * 64;
+                        if (int rc = qn_i8_dw(g.h_in, g.h_out, d->has_bias, dz, act[l - 1], B, Nb, dst, g.out_stride_b,
+                                              g.out_stride_k, ks, kc64, st))
+                            return rc;
+                        dw_done = true;
+                    }
+#endif
+                }
+                if (!dw_done)
+                    hipLaunchKernelGGL((k_gemm64<T, GEMM_DW>), dim3(gemm_grid(g, tiles, ks, B)), dim3(BLK), 0, st, g, W, dz,
+                                       (const T*)act[l - 1], dst);
                 if (ks > 1) {
                     int gx = (int)((nW + BLK - 1) / BLK);
                     if (gx > 64) gx = 64;
