@@ -18,7 +18,7 @@
 //               LDS buffers; they also carry the bias row sums;
 //   waves 4..7  matrix waves: wave m owns output rows 16 m .. 16 m + 15 x all 64 columns = 4 tiles: 6 + 4 x 6 fragment
 //               reads and 4 x 26 MFMAs per chunk; tile t's int32 levels are recombined into its float64 accumulators
-//               while tile t + 1's MFMAs run (the last tile's while the next chunk's first tile runs).
+//               BETWEEN tile t + 1's MFMAs (pinned micro-steps; the last tile's beside the next chunk's first tile).
 // One barrier per chunk.  The int8 pipe runs beside the slicers' vector work (tools/ubench_i8.hip: an MFMA wave keeps
 // its full rate next to a VALU wave of the same SIMD).  Per chunk and SIMD: 104 MFMAs (1700 cycles) against ~310 + 180
 // vector instructions.
@@ -64,39 +64,37 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
 
     if (wave < 4) {
         // ------------------------------------------------------------------ slicers
-        // item (u, wave, lane): feature f = 16 u + 4 wave + (lane >> 4), rows 4 q16 .. 4 q16 + 3 of the chunk, q16 = lane & 15
+        // item (u, wave, lane): feature f = 16 u + 4 wave + (lane >> 4), 4 of the chunk's rows chosen by q16 = lane & 15
         const int q16 = lane & 15, m4 = q16 >> 2, g4 = q16 & 3, fl = 4 * wave + (lane >> 4);
         double rsum[4] = {0.0, 0.0, 0.0, 0.0};
         int bad = 0;
         // a chunk's 4 x 4 + 4 x 4 values of this lane: loaded ONE CHUNK AHEAD of their slicing (two register sets; the
         // first version loaded and sliced in the same step and spent a memory round trip per chunk: 5800 cycles per chunk
         // against 1700 of MFMA work)
+        // Of the chunk's 64 rows the lane takes rows {2 q16, 2 q16 + 1, 32 + 2 q16, 33 + 2 q16}: two 16-byte loads per
+        // operand and feature, each instruction 256 contiguous bytes per feature (whole cache lines; 4 consecutive rows
+        // per lane made every instruction touch twice the lines for the same bytes).  Both operands use the same
+        // row -> K-slot map, so any map is as good as another.
         auto load_chunk = [&](int ch, double (&vz)[4][4], double (&va)[4][4]) {
-            const int n0 = kbeg + 64 * ch + 4 * q16;
-            if (n0 + 3 < kend) {                                        // (lane-wise at the ragged end of the slab)
+            const int c0 = kbeg + 64 * ch;
+            if (c0 + 64 <= kend && (Nb & 1) == 0) {                     // wave-uniform: a whole chunk of 16-byte aligned rows
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    if ((Nb & 1) == 0) {
-                        const double2* sz = reinterpret_cast<const double2*>(Z + (int64_t)(16 * u + fl) * Nb + n0);
-                        const double2* sa = reinterpret_cast<const double2*>(A + (int64_t)(16 * u + fl) * Nb + n0);
-                        const double2 z01 = sz[0], z23 = sz[1], a01 = sa[0], a23 = sa[1];
-                        vz[u][0] = z01.x; vz[u][1] = z01.y; vz[u][2] = z23.x; vz[u][3] = z23.y;
-                        va[u][0] = a01.x; va[u][1] = a01.y; va[u][2] = a23.x; va[u][3] = a23.y;
-                    } else {                                            // odd row count: rows of a feature are 8-byte aligned only
-                        const double* pz = Z + (int64_t)(16 * u + fl) * Nb + n0;
-                        const double* pq = A + (int64_t)(16 * u + fl) * Nb + n0;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { vz[u][r] = pz[r]; va[u][r] = pq[r]; }
-                    }
+                    const double2* sz = reinterpret_cast<const double2*>(Z + (int64_t)(16 * u + fl) * Nb + c0 + 2 * q16);
+                    const double2* sa = reinterpret_cast<const double2*>(A + (int64_t)(16 * u + fl) * Nb + c0 + 2 * q16);
+                    const double2 z01 = sz[0], z23 = sz[16], a01 = sa[0], a23 = sa[16];
+                    vz[u][0] = z01.x; vz[u][1] = z01.y; vz[u][2] = z23.x; vz[u][3] = z23.y;
+                    va[u][0] = a01.x; va[u][1] = a01.y; va[u][2] = a23.x; va[u][3] = a23.y;
                 }
             } else {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const bool in = n0 + r < kend;
-                        vz[u][r] = in ? Z[(int64_t)(16 * u + fl) * Nb + n0 + r] : 0.0;
-                        va[u][r] = in ? A[(int64_t)(16 * u + fl) * Nb + n0 + r] : 0.0;
+                        const int n = c0 + 32 * (r >> 1) + 2 * q16 + (r & 1);
+                        const bool in = n < kend;
+                        vz[u][r] = in ? Z[(int64_t)(16 * u + fl) * Nb + n] : 0.0;
+                        va[u][r] = in ? A[(int64_t)(16 * u + fl) * Nb + n] : 0.0;
                     }
             }
         };
@@ -175,36 +173,44 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) facc[t][r] = 0.0;
-        v4i acc[4][NLEV];
+        v4i acc[2][NLEV];                                                // the tile in flight / the tile being recombined
         double sc[4], scp[4];                                            // this / the previous chunk's scales of rows 16 m + 4 q + r
 #pragma unroll
         for (int r = 0; r < 4; ++r) sc[r] = scp[r] = 0.0;
-        // recombine tile t's levels (pairs in int32, then float64) and add them into its accumulators
-        auto convert = [&](int t, const double (&s)[4]) {
+        // One tile step: the 26 MFMAs of tile T (into acc[T & 1]) dealt out between the micro-steps that recombine the
+        // PREVIOUS tile's levels (acc[(T - 1) & 1]: pairs in int32, then float64) into its accumulators -- pinned, as in
+        // qn_wide_i8.hip: left to itself a wave runs fragment reads, MFMAs and the recombination one after the other
+        // (measured 3500 cycles per chunk against 1700 of MFMA work).  The next tile's B fragments are fetched meanwhile.
+        auto tile_step = [&](auto t_tag, auto conv_tag, const v4i (&Af)[NS], v4i (&Bf)[2][NS], const unsigned char* pb, const double (&s)[4]) {
+            constexpr int T_ = decltype(t_tag)::value, TP = (T_ + 3) & 3;          // TP: the tile recombined here
+            constexpr bool CONV = decltype(conv_tag)::value;
+            constexpr int NMICRO = 20;
+            double ts[4];
+            if constexpr (T_ < 3) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double ts;
-                if constexpr (NLEV == 7) {
-                    ts = (double)acc[t][6][r];
-                    ts = fma(ts, 65536.0, (double)(acc[t][4][r] + (acc[t][5][r] << 8)));
-                    ts = fma(ts, 65536.0, (double)(acc[t][2][r] + (acc[t][3][r] << 8)));
-                    ts = fma(ts, 65536.0, (double)(acc[t][0][r] + (acc[t][1][r] << 8)));
-                } else {
-                    ts = (double)(acc[t][4][r] + (acc[t][5][r] << 8));
-                    ts = fma(ts, 65536.0, (double)(acc[t][2][r] + (acc[t][3][r] << 8)));
-                    ts = fma(ts, 65536.0, (double)(acc[t][0][r] + (acc[t][1][r] << 8)));
-                }
-                facc[t][r] = fma(ts, s[r], facc[t][r]);
+                for (int k = 0; k < NS; ++k) Bf[(T_ + 1) & 1][k] = *reinterpret_cast<const v4i*>(pb + k * 4096 + (T_ + 1) * 1024 + lofs);
             }
-        };
-        auto products = [&](int t, const v4i (&Af)[NS], const unsigned char* pb) {
-            v4i Bf[NS];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) Bf[k] = *reinterpret_cast<const v4i*>(pb + k * 4096 + t * 1024 + lofs);
-            for_each_stage([&](auto k_tag) {
-                constexpr int k = decltype(k_tag)::value;
-                issue_product_c<LMIN, NLEV, true, k>(acc[t], Af, Bf);
-            }, std::make_integer_sequence<int, NPROD>{});
+            for_each_stage([&](auto id_tag) {
+                constexpr int id = decltype(id_tag)::value, st = id >> 2, r = id & 3;
+                constexpr int from = (id * NPROD + NMICRO - 1) / NMICRO, upto = ((id + 1) * NPROD + NMICRO - 1) / NMICRO;
+                for_each_stage([&](auto k_tag) {
+                    constexpr int k = from + decltype(k_tag)::value;
+                    issue_product_c<LMIN, NLEV, true, k>(acc[T_ & 1], Af, Bf[T_ & 1]);
+                }, std::make_integer_sequence<int, upto - from>{});
+                if constexpr (CONV) {
+                    const v4i (&ap_)[NLEV] = acc[TP & 1];
+                    if constexpr (st == 0) {
+                        if constexpr (NLEV == 7) ts[r] = (double)ap_[6][r];
+                        else ts[r] = (double)(ap_[4][r] + (ap_[5][r] << 8));
+                    } else if constexpr (st < 4) {
+                        constexpr int lo = NLEV == 7 ? 6 - 2 * st : 4 - 2 * st;
+                        if constexpr (lo >= 0) ts[r] = fma(ts[r], 65536.0, (double)(ap_[lo][r] + (ap_[lo + 1][r] << 8)));
+                    } else {
+                        facc[TP][r] = fma(ts[r], s[r], facc[TP][r]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }, std::make_integer_sequence<int, NMICRO>{});
         };
 #ifdef QN_DW_STAMPS
         long long tm_bar = 0, tm_0 = __builtin_amdgcn_s_memtime();
@@ -219,26 +225,41 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
             const unsigned char* pa = reinterpret_cast<const unsigned char*>(buf);
             const unsigned char* pb = pa + DW_OPER;
             const double* scl = reinterpret_cast<const double*>(buf + 2 * DW_OPER);
-            v4i Af[NS];
+            v4i Af[NS], Bf[2][NS];
 #pragma unroll
             for (int k = 0; k < NS; ++k) Af[k] = *reinterpret_cast<const v4i*>(pa + k * 4096 + m * 1024 + lofs);
 #pragma unroll
+            for (int k = 0; k < NS; ++k) Bf[0][k] = *reinterpret_cast<const v4i*>(pb + k * 4096 + lofs);
+#pragma unroll
             for (int r = 0; r < 4; ++r) { scp[r] = sc[r]; sc[r] = scl[16 * m + 4 * q + r]; }
-            products(0, Af, pb);
-            if (ch > 0) convert(3, scp);                                 // the previous chunk's last tile, beside tile 0's MFMAs
-            products(1, Af, pb);
-            convert(0, sc);
-            products(2, Af, pb);
-            convert(1, sc);
-            products(3, Af, pb);
-            convert(2, sc);
+            // (tile 0 runs beside the previous chunk's last tile)
+            if (ch > 0) tile_step(std::integral_constant<int, 0>{}, std::true_type{}, Af, Bf, pb, scp);
+            else tile_step(std::integral_constant<int, 0>{}, std::false_type{}, Af, Bf, pb, scp);
+            tile_step(std::integral_constant<int, 1>{}, std::true_type{}, Af, Bf, pb, sc);
+            tile_step(std::integral_constant<int, 2>{}, std::true_type{}, Af, Bf, pb, sc);
+            tile_step(std::integral_constant<int, 3>{}, std::true_type{}, Af, Bf, pb, sc);
         }
 #ifdef QN_DW_STAMPS
         if (blockIdx.x == 9 && tid == 256)
             printf("dw matrix wave: chunks %d total %lld barrier %lld\n", nchunks, (long long)(__builtin_amdgcn_s_memtime() - tm_0), tm_bar);
 #endif
         __syncthreads();                                                 // drain step
-        if (nchunks > 0) convert(3, sc);
+        if (nchunks > 0) {                                               // the last chunk's last tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const v4i (&ap_)[NLEV] = acc[1];
+                double ts;
+                if constexpr (NLEV == 7) {
+                    ts = (double)ap_[6][r];
+                    ts = fma(ts, 65536.0, (double)(ap_[4][r] + (ap_[5][r] << 8)));
+                } else {
+                    ts = (double)(ap_[4][r] + (ap_[5][r] << 8));
+                }
+                ts = fma(ts, 65536.0, (double)(ap_[2][r] + (ap_[3][r] << 8)));
+                ts = fma(ts, 65536.0, (double)(ap_[0][r] + (ap_[1][r] << 8)));
+                facc[3][r] = fma(ts, sc[r], facc[3][r]);
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
