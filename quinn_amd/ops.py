@@ -230,7 +230,7 @@ def default_device(device=None):
 class BatchedMLP:
     """Device-resident dataset + architecture descriptor + workspace; calls the C ABI."""
 
-    def __init__(self, arch: MLPArch, x, y, device=None, dtype="float64", max_workspace_bytes=16 << 30):
+    def __init__(self, arch: MLPArch, x, y, device=None, dtype="float64", max_workspace_bytes=48 << 30):
         self.arch = arch
         self.device = default_device(device)
         if dtype not in _TORCH_DT:
