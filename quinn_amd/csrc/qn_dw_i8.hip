@@ -62,6 +62,27 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
     if (tid == 0) *badflag = 0;
     const bool want_rowsum = g.has_bias && i0 == 0;
 
+    // the 4 x 4 values of a lane's items of one operand block (items: feature 16 u + fl_; rows {2 q, 2 q + 1, 32 + 2 q, 33 + 2 q}
+    // of the chunk: two 16-byte loads per item, each instruction 256 contiguous bytes per feature)
+    auto load_block = [&](const double* base, int ch, int q16_, int fl_, double (&v)[4][4]) {
+        const int c0 = kbeg + 64 * ch;
+        if (c0 + 64 <= kend && (Nb & 1) == 0) {                          // wave-uniform: a whole chunk of 16-byte aligned rows
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double2* sp = reinterpret_cast<const double2*>(base + (int64_t)(16 * u + fl_) * Nb + c0 + 2 * q16_);
+                const double2 v01 = sp[0], v23 = sp[16];
+                v[u][0] = v01.x; v[u][1] = v01.y; v[u][2] = v23.x; v[u][3] = v23.y;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = c0 + 32 * (r >> 1) + 2 * q16_ + (r & 1);
+                    v[u][r] = n < kend ? base[(int64_t)(16 * u + fl_) * Nb + n] : 0.0;
+                }
+        }
+    };
     if (wave < 4) {
         // ------------------------------------------------------------------ slicers
         // item (u, wave, lane): feature f = 16 u + 4 wave + (lane >> 4), 4 of the chunk's rows chosen by q16 = lane & 15
@@ -75,30 +96,11 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
         // operand and feature, each instruction 256 contiguous bytes per feature (whole cache lines; 4 consecutive rows
         // per lane made every instruction touch twice the lines for the same bytes).  Both operands use the same
         // row -> K-slot map, so any map is as good as another.
-        auto load_chunk = [&](int ch, double (&vz)[4][4], double (&va)[4][4]) {
-            const int c0 = kbeg + 64 * ch;
-            if (c0 + 64 <= kend && (Nb & 1) == 0) {                     // wave-uniform: a whole chunk of 16-byte aligned rows
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double2* sz = reinterpret_cast<const double2*>(Z + (int64_t)(16 * u + fl) * Nb + c0 + 2 * q16);
-                    const double2* sa = reinterpret_cast<const double2*>(A + (int64_t)(16 * u + fl) * Nb + c0 + 2 * q16);
-                    const double2 z01 = sz[0], z23 = sz[16], a01 = sa[0], a23 = sa[16];
-                    vz[u][0] = z01.x; vz[u][1] = z01.y; vz[u][2] = z23.x; vz[u][3] = z23.y;
-                    va[u][0] = a01.x; va[u][1] = a01.y; va[u][2] = a23.x; va[u][3] = a23.y;
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = c0 + 32 * (r >> 1) + 2 * q16 + (r & 1);
-                        const bool in = n < kend;
-                        vz[u][r] = in ? Z[(int64_t)(16 * u + fl) * Nb + n] : 0.0;
-                        va[u][r] = in ? A[(int64_t)(16 * u + fl) * Nb + n] : 0.0;
-                    }
-            }
-        };
-        auto slice_chunk = [&](int ch, const double (&vz)[4][4], const double (&va)[4][4]) {
+        // (the slicer waves take the dZ block: exponents, scales, bias sums; the a block, cheaper per item, is sliced by
+        // the matrix waves between their barrier and their MFMAs -- with all slicing on these four waves they were the
+        // critical path and the matrix waves idle a third of the time)
+        auto load_chunk = [&](int ch, double (&vz)[4][4]) { load_block(Z, ch, q16, fl, vz); };
+        auto slice_chunk = [&](int ch, const double (&vz)[4][4]) {
             char* buf = smemd + (ch & 1) * DW_BUF;
             unsigned char* pa = reinterpret_cast<unsigned char*>(buf);
             unsigned char* pb = pa + DW_OPER;
@@ -106,13 +108,10 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int f = 16 * u + fl;
-                unsigned ex = 0, exa = 0;
+                unsigned ex = 0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ex = max(ex, ((unsigned)__double2hiint(vz[u][r]) & 0x7fffffffu) >> 20);
-                    exa = max(exa, ((unsigned)__double2hiint(va[u][r]) & 0x7fffffffu) >> 20);
-                }
-                bad |= (ex >= 1923u) | (exa >= 1024u);                   // |dZ| >= 2^900 or not finite; |a| >= 2 or not finite
+                for (int r = 0; r < 4; ++r) ex = max(ex, ((unsigned)__double2hiint(vz[u][r]) & 0x7fffffffu) >> 20);
+                bad |= ex >= 1923u;                                      // |dZ| >= 2^900 or not finite
                 int e = (int)row16_max_u32(ex) - 1022;                   // 2^e > every |dZ| of the feature's 64 rows
                 e = e < -900 ? -900 : e;
                 const double dn = __hiloint2double((1023 - e) << 20, 0);               // 2^-e
@@ -124,9 +123,6 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
                 const int ofs = f * 64 + 16 * (g4 ^ slot_swz(f)) + 4 * m4;
 #pragma unroll
                 for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(pa + k * 4096 + ofs) = S[k];
-                slice4(va[u], S);
-#pragma unroll
-                for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(pb + k * 4096 + ofs) = S[k];
                 if (q16 == 0) scl[f] = __hiloint2double((1023 + e - 2 * QB + 8 * LMIN) << 20, 0);   // integer sum -> dZ . a
                 if (want_rowsum) rsum[u] += (vz[u][0] + vz[u][1]) + (vz[u][2] + vz[u][3]);
             }
@@ -137,16 +133,16 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
 #else
 #define QN_DST(var, code) { code; }
 #endif
-        double z0[4][4], a0[4][4], z1[4][4], a1[4][4];
-        if (nchunks > 0) load_chunk(0, z0, a0);
+        double z0[4][4], z1[4][4];
+        if (nchunks > 0) load_chunk(0, z0);
         for (int ch = 0; ch < nchunks; ch += 2) {
-            if (ch + 1 < nchunks) load_chunk(ch + 1, z1, a1);
-            QN_DST(ts_slice, slice_chunk(ch, z0, a0))
+            if (ch + 1 < nchunks) load_chunk(ch + 1, z1);
+            QN_DST(ts_slice, slice_chunk(ch, z0))
             // chunk ch is written; the matrix waves are done with chunk ch - 1 (whose buffer chunk ch + 1 overwrites)
             QN_DST(ts_bar, __syncthreads())
             if (ch + 1 < nchunks) {
-                if (ch + 2 < nchunks) load_chunk(ch + 2, z0, a0);
-                QN_DST(ts_slice, slice_chunk(ch + 1, z1, a1))
+                if (ch + 2 < nchunks) load_chunk(ch + 2, z0);
+                QN_DST(ts_slice, slice_chunk(ch + 1, z1))
                 QN_DST(ts_bar, __syncthreads())
             }
         }
@@ -168,6 +164,32 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
         // ------------------------------------------------------------------ matrix waves
         const int m = wave - 4, q = lane >> 4, c = lane & 15;
         const int lofs = c * 64 + 16 * (q ^ slot_swz(c));               // this lane's 16 bytes inside a [16 rows][64 B] block
+        // these waves also slice the a block (tanh outputs: fixed scale, no exponent work) of the NEXT chunk, before their
+        // MFMAs on the current one; the block after that is requested right behind it
+        const int q16b = lane & 15, m4b = q16b >> 2, g4b = q16b & 3, flb = 4 * m + (lane >> 4);
+        int badb = 0;
+        double vb[4][4];
+        auto slice_b = [&](int ch) {
+            unsigned char* pbn = reinterpret_cast<unsigned char*>(smemd + (ch & 1) * DW_BUF) + DW_OPER;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = 16 * u + flb;
+                unsigned exa = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) exa = max(exa, (unsigned)__double2hiint(vb[u][r]) & 0x7fffffffu);
+                badb |= exa >= 0x40000000u;                              // |a| >= 2 or not finite
+                int S[NS];
+                slice4(vb[u], S);
+                const int ofs = f * 64 + 16 * (g4b ^ slot_swz(f)) + 4 * m4b;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(pbn + k * 4096 + ofs) = S[k];
+            }
+        };
+        if (nchunks > 0) {
+            load_block(A, 0, q16b, flb, vb);
+            slice_b(0);
+            load_block(A, nchunks > 1 ? 1 : 0, q16b, flb, vb);
+        }
         double facc[4][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -232,6 +254,8 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
             for (int k = 0; k < NS; ++k) Bf[0][k] = *reinterpret_cast<const v4i*>(pb + k * 4096 + lofs);
 #pragma unroll
             for (int r = 0; r < 4; ++r) { scp[r] = sc[r]; sc[r] = scl[16 * m + 4 * q + r]; }
+            if (ch + 1 < nchunks) slice_b(ch + 1);                       // (into the other buffer: nobody reads it before the next barrier)
+            load_block(A, ch + 2 < nchunks ? ch + 2 : ch, q16b, flb, vb);     // (unconditional: keeps the registers' live range short)
             // (tile 0 runs beside the previous chunk's last tile)
             if (ch > 0) tile_step(std::integral_constant<int, 0>{}, std::true_type{}, Af, Bf, pb, scp);
             else tile_step(std::integral_constant<int, 0>{}, std::false_type{}, Af, Bf, pb, scp);
@@ -243,6 +267,7 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
         if (blockIdx.x == 9 && tid == 256)
             printf("dw matrix wave: chunks %d total %lld barrier %lld\n", nchunks, (long long)(__builtin_amdgcn_s_memtime() - tm_0), tm_bar);
 #endif
+        if (badb) *badflag = 1;
         __syncthreads();                                                 // drain step
         if (nchunks > 0) {                                               // the last chunk's last tile
 #pragma unroll
