@@ -67,7 +67,10 @@ int qn_mlp_path(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
  * are no multiples of 64 run on a zero-padded twin of the network (padded units stay exactly 0, results equal the
  * unpadded network's).  QN_PATH_FUSED_DP is QN_PATH_FUSED restricted to the kernels that use the float64 matrix
  * instructions: it excludes the forward kernel that forms the 64-wide hidden layers as sliced exact int8 products
- * (same results to ~1e-14 relative; kept selectable as the second implementation the tests compare it with). */
+ * (same results to ~1e-14 relative; kept selectable as the second implementation the tests compare it with).  Under
+ * QN_PATH_AUTO the float64 tanh networks with hidden widths all 128 or all 256 (one output, <= 4 inputs) take the layer-wise
+ * family with their hidden layers -- forward, activation gradient, weight gradient -- as sliced exact int8 products
+ * (~1e-13 relative); QN_PATH_GENERIC is the all-float64 reference of that family as well. */
 int qn_mlp_desc_set_path(qn_desc* desc, int path);
 
 /* sse_out[b] = sum_{n,o} (Y[r(b,n),o] - f_{W[b]}(X[r(b,n),:])[o])^2 for b < B.
