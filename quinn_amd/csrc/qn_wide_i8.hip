@@ -241,6 +241,9 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
             sse += wide_slow_rows<KC>(a.Nb, d, NH, a.has_bias, a.act_stride, Wb, X, Y, row_idx,
                                       split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave,
                                       STASH ? act0 : nullptr, dz_last, pred_out);
+            // (the plain-float64 rows use flat loads / stores, which complete out of order: drain them before the counted
+            // vmcnt waits of the tile stream resume)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             continue;
         }
         // stash: feature 4 q of this lane's row; rows beyond Nb write to a dump area (no branch in the epilogue: it has
@@ -677,6 +680,8 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
         if (exceptional) {
             wide_slow_bwd_rows<KC>(a.Nb, d, NH, a.has_bias, a.act_stride, a.dz_stride, Wb,
                                    split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave, act0, dz_last, dz0);
+            // (flat loads / stores in there complete out of order: drain them before the counted vmcnt waits resume)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             continue;
         }
         // element (feature 4 q [+ 16 T + r], this lane's row); rows beyond Nb read row 0 and write to the dump area
