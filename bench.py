@@ -122,6 +122,28 @@ def extras(op, arch, batches, args):
         el = time.perf_counter() - t0
         out["amcmc_adapting_steps_per_s"] = 1000 / el
         out["amcmc_adapting_accrate"] = float(r["accrate"].mean())
+        # the other BASELINE network shapes through the same operator (configs[2], configs[3]: parity-test cases, not bench
+        # lines): forward-only and forward + backward rates of the int8-slice kernels for 128 / 256-wide networks
+        del eng
+        for name, dims, n_rows, nb in (("cfg3_3x128_N8192_S128", (2, 128, 128, 128, 1), 8192, 128),
+                                       ("cfg4_4x256_N16384_M32", (1, 256, 256, 256, 256, 1), 16384, 32)):
+            a2 = MLPArch(dims, "tanh")
+            x2, y2 = synthetic(n_rows, dims[0])
+            op2 = BatchedMLP(a2, x2, y2, device=dev)
+            W2 = op2.weights(0.1 * np.random.RandomState(7).randn(nb, a2.nparams))
+            res = {}
+            for kind, f2, fl in (("fwd", lambda: op2.sse(W2), a2.flops_fwd(n_rows)), ("grad", lambda: op2.sse_grad(W2), a2.flops_fwdbwd(n_rows))):
+                f2(); torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    f2()
+                torch.cuda.synchronize(dev)
+                el = (time.perf_counter() - t0) / 3
+                res[kind + "_evals_per_s"] = nb / el
+                res[kind + "_tflops"] = nb * fl / el / 1e12
+            out[name] = res
+            del op2, W2
+            torch.cuda.empty_cache()
     return out
 
 
