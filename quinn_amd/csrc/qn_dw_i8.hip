@@ -27,6 +27,7 @@
 #include "qn_fused_args.h"
 #include "qn_math.h"
 #include "qn_i8_slice.h"
+#include <mutex>
 
 namespace {
 
@@ -103,7 +104,6 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
         auto slice_chunk = [&](int ch, const double (&vz)[4][4]) {
             char* buf = smemd + (ch & 1) * DW_BUF;
             unsigned char* pa = reinterpret_cast<unsigned char*>(buf);
-            unsigned char* pb = pa + DW_OPER;
             double* scl = reinterpret_cast<double*>(buf + 2 * DW_OPER);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -320,11 +320,15 @@ int qn_i8_dw(int h_in, int h_out, int has_bias, const double* dz, const double* 
     g.inner = (h_in / 64) * (h_out / 64); g.per_b = ksplit; g.outer_total = ksplit * B;
     const unsigned grid = (unsigned)(((g.outer_total + 7) / 8) * 8 * g.inner);
     const size_t lds = 2 * (size_t)DW_BUF + 16;
-    static bool armed = false;                    // (set once; a race only repeats the call)
     auto kern = k_i8_dw<QN_I8_LMIN>;
-    if (!armed) {
-        QN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        armed = true;
+    {   // raise the dynamic-LDS limit once per process (not per launch: the launch path stays capturable into a HIP graph)
+        static std::mutex mu;
+        static bool armed = false;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!armed) {
+            QN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            armed = true;
+        }
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(DWT), lds, st, g, dz, a_prev, dst);
     QN_HIP_CHECK(hipGetLastError());
