@@ -89,6 +89,19 @@ def test_row_subsets_ragged_tail_and_determinism(dims):
     np.testing.assert_allclose(h1 + h2, full, rtol=1e-12)
 
 
+@pytest.mark.parametrize("h", [128, 256])
+@pytest.mark.parametrize("N,B", [(1, 1), (16, 1), (64, 3), (65, 2), (129, 300)])
+def test_tiny_row_counts_and_many_or_single_vectors(h, N, B):
+    """One row, one vector, one more row than an iteration takes, more vectors than workgroups per chip."""
+    dims = (1, h, h, 1)
+    x, y = _data(N, 1, seed=N)
+    arch = MLPArch(dims, "tanh")
+    W = 0.3 * np.random.RandomState(B).randn(B, arch.nparams)
+    op = BatchedMLP(arch, x, y)
+    a, r = _run(op, W)
+    _check(a, r)
+
+
 def test_padded_twin_takes_the_wide_kernel():
     dims = (1, 100, 100, 100, 1)                             # runs on its 128-wide zero-padded twin
     x, y = _data(500, 1, seed=9)
