@@ -22,7 +22,8 @@
 // One barrier per chunk.  The int8 pipe runs beside the slicers' vector work (tools/ubench_i8.hip: an MFMA wave keeps
 // its full rate next to a VALU wave of the same SIMD).  Per chunk and SIMD: 104 MFMAs (1700 cycles) against ~310 + 180
 // vector instructions.
-// A chunk with a value that is not finite (or >= 2^900) makes the workgroup redo its tile in plain float64 at the end.
+// A chunk with a value that is not finite (or >= 2^900), or an a block whose values are all tiny (< 2^-5: the fixed scale
+// would lose relative accuracy), makes the workgroup redo its tile in plain float64 at the end.
 #include "qn_common.h"
 #include "qn_fused_args.h"
 #include "qn_math.h"
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
         // MFMAs on the current one; the block after that is requested right behind it
         const int q16b = lane & 15, m4b = q16b >> 2, g4b = q16b & 3, flb = 4 * m + (lane >> 4);
         int badb = 0;
+        unsigned amaxb = 0;                                              // largest |a| (high word) this wave has sliced
         double vb[4][4];
         auto slice_b = [&](int ch) {
             unsigned char* pbn = reinterpret_cast<unsigned char*>(smemd + (ch & 1) * DW_BUF) + DW_OPER;
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
 #pragma unroll
                 for (int r = 0; r < 4; ++r) exa = max(exa, (unsigned)__double2hiint(vb[u][r]) & 0x7fffffffu);
                 badb |= exa >= 0x40000000u;                              // |a| >= 2 or not finite
+                amaxb = max(amaxb, exa);
                 int S[NS];
                 slice4(vb[u], S);
                 const int ofs = f * 64 + 16 * (g4b ^ slot_swz(f)) + 4 * m4b;
@@ -267,7 +270,11 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
         if (blockIdx.x == 9 && tid == 256)
             printf("dw matrix wave: chunks %d total %lld barrier %lld\n", nchunks, (long long)(__builtin_amdgcn_s_memtime() - tm_0), tm_bar);
 #endif
-        if (badb) *badflag = 1;
+        // the fixed scale of the a operand (absolute error 2^-47) is a relative accuracy only while the activations are not
+        // ALL tiny: a wave whose 16 features stayed below 2^-5 over the whole slab (and are not exactly zero: padding)
+        // sends the tile through the plain float64 loop as well
+        amaxb = wave_max_u32(amaxb);
+        if (badb || (amaxb != 0 && amaxb < TINY_ACT_HI)) *badflag = 1;
         __syncthreads();                                                 // drain step
         if (nchunks > 0) {                                               // the last chunk's last tile
 #pragma unroll

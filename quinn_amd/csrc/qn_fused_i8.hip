@@ -229,6 +229,7 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
         }
         // ---- first layer (VALU): a_1 = tanh(W0 x + b0), sliced straight into the B operand
         v4i Bc[G][NS];
+        int top = 0;                                                    // OR of the layer's top digits (see below)
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -246,7 +247,14 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
                 slice4(av, S);
 #pragma unroll
                 for (int k = 0; k < NS; ++k) Bc[g][k][t] = S[k];
+                top |= top_digits_large(S[NS - 1]);
             }
+        // Activations are sliced with the FIXED scale 2^-46 (tanh outputs lie in [-1, 1]): absolute error 2^-47, which is a
+        // RELATIVE error only as long as a layer's activations are not all tiny.  A layer whose top digit is zero for every
+        // activation of the wave's rows (top_digits_large: all |a| < ~2^-4.7, e.g. very small weights without bias) sends
+        // the wave's rows through the plain float64 loop instead (slow_tile); otherwise the error stays <= 1.8e-13 of
+        // the largest activation.  Costs two instructions per tile.
+        bool redo = !__any(top != 0);
         // ---- hidden -> hidden layers: digit products on the int8 matrix pipe.
         // Software pipeline over the 8 (row group, output tile) items of a layer: the MFMAs of item i + 1 are issued
         // BETWEEN the vector instructions of item i's epilogue (recombine, tanh, digits).  An i8 MFMA costs a
@@ -383,6 +391,7 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
             const unsigned char* plane = wq + (layer - 1) * LAYER_BYTES + lofs;
             const double* sb = lds + offsb + (layer - 1) * 2 * H + 2 * 4 * q;      // this lane group's features 16 t + 4 q + r
             const double* wl = lds + offWl + 4 * q;
+            int topl = 0;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 v4i Bn[NS];
@@ -412,11 +421,18 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
                 if constexpr (!LAST) {
 #pragma unroll
                     for (int k = 0; k < NS; ++k) Bc[g][k] = Bn[k];
+                    topl |= (top_digits_large(Bn[NS - 1][0]) | top_digits_large(Bn[NS - 1][1])) | (top_digits_large(Bn[NS - 1][2]) | top_digits_large(Bn[NS - 1][3]));
                 }
             }
+            if constexpr (!LAST) redo |= !__any(topl != 0);
         };
         for (int layer = 1; layer < NH - 1; ++layer) hidden_layer(std::false_type{}, layer);
         hidden_layer(std::true_type{}, NH - 1);
+        if (redo) {                                                     // wave-uniform; rare
+            sse += slow_tile<DP>(a.Nb, a.d, a.o, a.nhid, a.has_bias, lds, scratch + 128 * wave, Wb, X, Y, row_idx,
+                                 split * a.rows_per_split + (it * (WGT / 64) + wave) * 16 * G, b, pred_out);
+            continue;
+        }
         // ---- last layer: finish the dot over the four lane groups, residual, SSE
 #pragma unroll
         for (int g = 0; g < G; ++g)
@@ -504,6 +520,7 @@ __global__ __launch_bounds__(512) void k_i8_first(I8First a, const double* __res
     __syncthreads();
     const int64_t plane = (int64_t)a.Nb * a.h;
     const int nbeg = blockIdx.x * a.rows_per_wg;
+    bool small = false;
     for (int n0 = nbeg; n0 < nbeg + a.rows_per_wg && n0 < a.Nb; n0 += 128) {
         const int n = n0 + 16 * wave + c;
         const bool live = n < a.Nb;
@@ -515,6 +532,7 @@ __global__ __launch_bounds__(512) void k_i8_first(I8First a, const double* __res
             x[k] = k < a.d ? X[rr * a.d + k] : 0.0;
             bad |= !qn_bounded(x[k]);
         }
+        unsigned amx = 0;                                           // largest |a_1| (high word) of the wave's 16 rows
         for (int kc = 0; kc < a.h / 64; ++kc) {
             int D[NS][4];
 #pragma unroll
@@ -529,6 +547,7 @@ __global__ __launch_bounds__(512) void k_i8_first(I8First a, const double* __res
                         if (k < a.d) z = fma(w0[j * dd + k], x[k], z);
                     // (unbounded weights / inputs are flagged: those chains are recomputed by the float64 path below)
                     av[r] = qn_tanh_f64_tab64(z, tanh_tab);
+                    amx = max(amx, (unsigned)__double2hiint(av[r]) & 0x7fffffffu);
                     if (live) act_out[((int64_t)b * a.h + j) * a.Nb + n] = av[r];
                 }
                 int S[NS];
@@ -542,8 +561,13 @@ __global__ __launch_bounds__(512) void k_i8_first(I8First a, const double* __res
                 for (int k = 0; k < NS; ++k) *reinterpret_cast<v4i*>(dst + k * plane) = (v4i){D[k][0], D[k][1], D[k][2], D[k][3]};
             }
         }
+        // the digits carry an absolute error of 2^-47: rows whose activations are all tiny (< 2^-5, but not all zero) would
+        // lose relative accuracy in the next layer -- bit 2: the chain's hidden layers run in plain float64
+        amx = wave_max_u32(amx);
+        small |= amx != 0 && amx < TINY_ACT_HI;
     }
     if (__any(bad) && lane == 0) atomicOr(&flags[b], 2);            // bit 1: the first layer must be redone in plain float64
+    if (small && lane == 0) atomicOr(&flags[b], 4);
 }
 // flagged chains (bit 1 of k_i8_first: an unbounded first-layer weight or input): the first layer again with the
 // NaN-propagating float64 tanh; hidden layers of flagged chains take the float64 path of k_i8_gemm
@@ -581,7 +605,7 @@ __device__ __forceinline__ void glds16b(const unsigned char* src, unsigned char*
 template <int LMIN, int KC>
 __global__ __launch_bounds__(512, 1) void k_i8_gemm(I8Gemm g, const double* __restrict__ W, const unsigned char* __restrict__ Wd,
                                                    const double* __restrict__ sb, const unsigned char* __restrict__ ad_in,
-                                                   const double* __restrict__ act_in, const int* __restrict__ flags,
+                                                   const double* __restrict__ act_in, int* flags,
                                                    double* __restrict__ act_out, unsigned char* __restrict__ ad_out) {
     constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN);
     constexpr int TILE_B = NS * 64 * 64;                   // one K-chunk of the tile's weight digits: [6][64 rows][64 B]
@@ -662,6 +686,7 @@ __global__ __launch_bounds__(512, 1) void k_i8_gemm(I8Gemm g, const double* __re
         // ---- epilogue: recombine (every level on its own: with K > 64 the pair sums would not fit int32), scale +
         // bias, tanh, float64 out, digits out
         int D[NS][4];
+        unsigned amx = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             double av[4];
@@ -673,6 +698,7 @@ __global__ __launch_bounds__(512, 1) void k_i8_gemm(I8Gemm g, const double* __re
                 const int jl = 16 * t + 4 * q + r;
                 const double2 sc = *reinterpret_cast<const double2*>(sbt + 2 * jl);
                 av[r] = qn_tanh_f64_tab64(fma(ts, sc.x, sc.y), tanh_tab);
+                amx = max(amx, (unsigned)__double2hiint(av[r]) & 0x7fffffffu);
                 if (live) act_out[((int64_t)b * g.h_out + m0 + jl) * g.Nb + n] = av[r];
             }
             if (ad_out) {
@@ -686,6 +712,10 @@ __global__ __launch_bounds__(512, 1) void k_i8_gemm(I8Gemm g, const double* __re
             unsigned char* dst = ad_out + (int64_t)b * NS * out_plane + (int64_t)n * g.h_out + m0 + 16 * q;
 #pragma unroll
             for (int k = 0; k < NS; ++k) *reinterpret_cast<v4i*>(dst + k * out_plane) = (v4i){D[k][0], D[k][1], D[k][2], D[k][3]};
+        }
+        if (ad_out) {                                      // (as k_i8_first: tiny activations -> the chain's next layers in float64)
+            amx = wave_max_u32(amx);
+            if (amx != 0 && amx < TINY_ACT_HI && lane == 0) atomicOr(&flags[b], 4);
         }
     }
 }
@@ -788,12 +818,12 @@ int qn_i8_layers_forward(const qn_desc* d, const double* W, const double* X, con
             auto kern = k_i8_gemm<QN_I8_LMIN, 2>;
             if (int rc = i8_arm(reinterpret_cast<const void*>(kern), i8gemm_lds(2))) return rc;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), i8gemm_lds(2), st, g, W, Wd, sb, (const unsigned char*)ad[li & 1],
-                               (const double*)act[li], (const int*)flags, act[li + 1], out_digits);
+                               (const double*)act[li], flags, act[li + 1], out_digits);
         } else {
             auto kern = k_i8_gemm<QN_I8_LMIN, 4>;
             if (int rc = i8_arm(reinterpret_cast<const void*>(kern), i8gemm_lds(4))) return rc;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), i8gemm_lds(4), st, g, W, Wd, sb, (const unsigned char*)ad[li & 1],
-                               (const double*)act[li], (const int*)flags, act[li + 1], out_digits);
+                               (const double*)act[li], flags, act[li + 1], out_digits);
         }
     }
     QN_HIP_CHECK(hipGetLastError());

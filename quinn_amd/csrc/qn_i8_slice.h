@@ -58,6 +58,14 @@ __device__ __forceinline__ bool block_or(int mine, double* slot) {
     return *flag != 0;
 }
 
+// Top digits (word 5 of slice4: four values' digit 5 as signed bytes) -> nonzero if one of them is >= 4 or <= -5 (give or
+// take one: a carry may cross into the neighbouring byte), i.e. if one of the four values is at least ~2^-4.7 in
+// magnitude.  The fused forward kernels OR this over a layer's activations of a wave's rows: zero = ALL of them are tiny,
+// and the fixed activation scale 2^-46 (absolute error 2^-47) no longer gives relative accuracy -- those rows are redone in
+// plain float64.  Otherwise the slicing error stays <= 2^-47 / 2^-4.7 = 1.8e-13 of the rows' largest activation.
+__device__ __forceinline__ int top_digits_large(int s5) { return (s5 + 0x04040404) & (int)0xF8F8F8F8; }
+constexpr unsigned TINY_ACT_HI = 0x3FA00000u;       // high word of 2^-5: the same bound where float64 values are at hand
+
 // four float64 values in [-1, 1] -> six words, word k = digit k of the four values in bytes 0..3
 __device__ __forceinline__ void slice4(const double (&a)[4], int (&S)[NS]) {
     int lo[4], hi[4];

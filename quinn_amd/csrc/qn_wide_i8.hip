@@ -253,6 +253,11 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
 
         // ---- first layer (VALU): a_1 = tanh(W0 x + b0), sliced into the B operand of the first hidden layer
         v4i Bin[KC][NS];
+        // Activations are sliced with the FIXED scale 2^-46 (absolute error 2^-47): a layer whose activations are ALL
+        // tiny for the wave's 16 rows (top_digits_large: |a| < ~2^-4.7, e.g. very small weights without bias) would lose
+        // relative accuracy -- those rows are redone in plain float64 at the end of the iteration (`redo`); otherwise
+        // the error stays <= 1.8e-13 of the rows' largest activation.  Costs two instructions per tile.
+        int top = 0;
 #ifdef QN_WIDE_STAMPS
         const long long tf0_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -275,10 +280,12 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
                 slice4(av, S);
 #pragma unroll
                 for (int k = 0; k < NS; ++k) Bcur[k][t] = S[k];
+                top |= top_digits_large(S[NS - 1]);
             }
 #pragma unroll
             for (int k = 0; k < NS; ++k) Bin[kc][k] = to_acc(Bcur[k]);
         }
+        bool redo = !__any(top != 0);
 
 #ifdef QN_WIDE_STAMPS
         st_first += __builtin_amdgcn_s_memtime() - tf0_;
@@ -404,6 +411,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
             v4i Bout[KC][NS];
             v4i Bcur[NS];
             v4i accA[NLEV], accB[NLEV];
+            int topl = 0;
             QN_ST(st_sync, sync_tile())
             QN_ST(st_burst, burst(accA, ring + rd_slot * TILE_B + lofs))
             auto tile = [&](auto t_tag) {
@@ -423,6 +431,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
                 if constexpr (!LAST) {
 #pragma unroll
                     for (int k = 0; k < NS; ++k) Bcur[k][Tt_ & 3] = S[k];
+                    topl |= top_digits_large(S[NS - 1]);
                     if constexpr ((Tt_ & 3) == 3) {
 #pragma unroll
                         for (int k = 0; k < NS; ++k) Bout[Tt_ >> 2][k] = to_acc(Bcur[k]);
@@ -435,6 +444,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
                 for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
                     for (int k = 0; k < NS; ++k) Bin[kc][k] = Bout[kc][k];
+                redo |= !__any(topl != 0);
             }
         };
         for (int li = 0; li < NHH - 1; ++li) hidden_layer(std::false_type{}, li);
@@ -446,7 +456,13 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
         pq += __shfl_xor(pq, 32, 64);
         const double pr = pq + lds[offbl];
         const double res = pr - yk;
-        if (live && q == 0) {
+        if (redo) {                                                  // wave-uniform, rare: the wave's 16 rows again, exactly
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the stash stores above land before their rewrites)
+            sse += wide_slow_rows<KC>(a.Nb, d, NH, a.has_bias, a.act_stride, Wb, X, Y, row_idx,
+                                      split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave,
+                                      STASH ? act0 : nullptr, dz_last, pred_out);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        } else if (live && q == 0) {
             sse += res * res;
             if (pred_out) pred_out[(int64_t)b * a.Nb + nrow] = pr;
             if (dz_last) dz_last[(int64_t)b * a.Nb + nrow] = 2.0 * res;
@@ -783,6 +799,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
                 ab[1][r] = apl[(int64_t)(16 + r) * a.Nb];
             }
             v4i accA[NLEV], accB[NLEV];
+            int topl = 0;
             QN_ST(st_sync, sync_tile())
             QN_ST(st_burst, burst(accA, ring + rd_slot * TILE_B + lofs))
             // epilogue of tile T (pinned micro-steps, the next tile's MFMAs dealt out between them)

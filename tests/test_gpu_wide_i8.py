@@ -160,3 +160,29 @@ def test_forward_only_calls_at_width_128_leave_the_streaming_kernel():
     s_f = op.sse(W).cpu().numpy()
     op.set_path(_lib.PATH_AUTO)
     np.testing.assert_allclose(op.sse(W).cpu().numpy(), s_f, rtol=1e-11)
+
+
+TINY = [((2, 64, 64, 64, 64, 1), 700, 3, False), ((1, 64, 64, 64, 1), 130, 2, True),           # fused 64-wide forward
+        ((2, 128, 128, 128, 128, 128, 1), 1754, 1, False), ((3, 256, 256, 256, 1), 300, 4, False),   # wide forward / backward / dW
+        ((3, 128, 128, 128, 1), 200, 3, True), ((6, 128, 128, 128, 128, 1), 257, 2, False),    # d = 6: layer-wise int8 forward
+        ((2, 100, 100, 100, 1), 150, 2, False)]                                                # padded twin
+
+
+@pytest.mark.parametrize("dims,N,B,bias", TINY, ids=[f"{c[0][1]}x{len(c[0]) - 2}_d{c[0][0]}{'' if c[3] else '_nobias'}" for c in TINY])
+@pytest.mark.parametrize("wscale", [1e-3, 3e-2])
+def test_tiny_activations_keep_relative_accuracy(dims, N, B, bias, wscale):
+    """Weights ~ 1e-3 (and no bias): activations shrink layer by layer (1e-2, 1e-4, ... 1e-10).  The int8-slice kernels
+    slice activations with a fixed scale (absolute error 2^-47); rows whose activations are all below 2^-7 in some layer
+    must take the plain-float64 path so predictions and gradients keep their RELATIVE accuracy (found by
+    tools/fuzz_wide.py: 2.7e-6 on predictions, 4.7e-8 on gradients before the guard)."""
+    x, y = _data(N, dims[0], seed=11)
+    arch = MLPArch(dims, "tanh", bias=bias)
+    W = wscale * np.random.RandomState(N).randn(B, arch.nparams)
+    W[-1, : arch.nparams // 3] *= 30.0                       # one vector whose first layers are of ordinary size
+    op = BatchedMLP(arch, x, y)
+    a, r = _run(op, W)
+    _check(a, r)
+    # the bar per vector (the one with larger weights must not hide the others)
+    for b in range(B):
+        assert np.abs(a[3][b] - r[3][b]).max() <= 1e-11 * np.abs(r[3][b]).max()
+        assert np.abs(a[1][b] - r[1][b]).max() <= 1e-10 * np.abs(r[1][b]).max()
