@@ -1,0 +1,19 @@
+"""GPU: a fixed-seed slice of the randomised parity sweep (tools/fuzz_all.py): random architectures (depth, uniform / ragged
+/ odd widths, 1..16 inputs, 1..4 outputs, tanh / relu / identity, bias on / off), row subsets and weight scales through
+whichever kernel family the dispatcher picks, SSE / gradient / predictions against the oracle (the reference's torch
+float64 module + autograd).  Bars: 1e-11 on SSE and predictions, 1e-10 of max |g| on gradients."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_random_architectures_match_the_oracle(seed):
+    import fuzz_all
+    nfail, worst = fuzz_all.run(ncases=40, seed=seed, verbose=False)
+    assert nfail == 0, worst

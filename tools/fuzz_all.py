@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the whole MLP operator (QN_PATH_AUTO: whichever kernel family the dispatcher picks) against
+the oracle (oracle/mlp_ref.py: the reference's torch float64 module + autograd): random depths, uniform / ragged / odd
+widths, 1..16 inputs, 1..4 outputs, every activation, bias on / off, row subsets, weight scales.  Test infrastructure
+(imports oracle/).  usage: tools/fuzz_all.py [ncases] [seed]"""
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import mlp_ref
+from quinn_amd import _lib
+from quinn_amd.ops import MLPArch, BatchedMLP
+PATHS = {_lib.PATH_GENERIC: "generic", _lib.PATH_FUSED: "fused", _lib.PATH_FUSED_DP: "fused_dp"}
+
+
+def run(ncases=100, seed=0, verbose=True):
+    """Returns (number of failed cases, worst [sse, grad, pred] errors)."""
+    rs = np.random.RandomState(seed)
+    worst = [0.0, 0.0, 0.0]; nfail = 0
+    for case in range(ncases):
+        nhid = int(rs.randint(1, 6))
+        if rs.rand() < 0.6:
+            hid = (int(rs.choice([3, 17, 32, 64, 64, 65, 100, 128, 200, 256])),) * nhid
+        else:
+            hid = tuple(int(v) for v in rs.randint(1, 90, size=nhid))
+        d = int(rs.choice([1, 1, 2, 3, 4, 5, 8, 16])); o = int(rs.choice([1, 1, 1, 2, 3, 4]))
+        act = str(rs.choice(sorted(_lib.ACT_CODES))); bias = bool(rs.rand() < 0.75)
+        N = int(rs.choice([rs.randint(1, 40), rs.randint(40, 700)])); B = int(rs.choice([1, 2, rs.randint(3, 13)]))
+        if max(hid) > 128: N = min(N, 200)
+        dims = (d,) + hid + (o,)
+        arch = MLPArch(dims, act, bias=bias)
+        wscale = float(rs.choice([0.01, 0.3, 1.0, 3.0]))
+        x = rs.rand(N, d) * 2 - 1; y = rs.randn(N, o)
+        parts = []
+        for a_, b_ in zip(dims[:-1], dims[1:]):
+            parts.append(wscale * rs.randn(B, b_ * a_) / np.sqrt(a_))
+            if bias: parts.append(wscale * rs.randn(B, b_))
+        W = np.concatenate(parts, axis=1)
+        idx = rs.randint(0, N, size=(B, int(rs.randint(1, N + 1)))) if rs.rand() < 0.3 else None
+        op = BatchedMLP(arch, x, y)
+        s, g = op.sse_grad(W, row_idx=idx); s2, pr = op.sse_pred(W, row_idx=idx)
+        s, g, s2, pr = (t.double().cpu().numpy() for t in (s, g, s2, pr))
+        Nb = N if idx is None else idx.shape[1]
+        pth = PATHS.get(op.path(B, Nb, True), "?") + "/" + PATHS.get(op.path(B, Nb, False), "?")
+        mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, act, bias))
+        e = [0.0, 0.0, 0.0]
+        for b in range(B):
+            xb, yb = (x, y) if idx is None else (x[idx[b]], y[idx[b]])
+            sref = mlp_ref.sse(mod, W[b], xb, yb)
+            pref = mlp_ref.forward_flat(mod, W[b], xb)
+            gref = -2.0 * mlp_ref.logpostgrad(mod, W[b], xb, [v for v in yb], 1.0)          # dSSE/dw
+            e[0] = max(e[0], abs(s[b] / sref - 1), abs(s2[b] / sref - 1))
+            e[1] = max(e[1], np.abs(g[b] - gref).max() / max(np.abs(gref).max(), 1e-300))
+            e[2] = max(e[2], np.abs(pr[b].reshape(pref.shape) - pref).max() / max(np.abs(pref).max(), 1e-300))
+        f = 10.0 if wscale >= 3 else 1.0
+        ok = e[0] <= 1e-11 * f and e[1] <= 1e-10 * f and e[2] <= 1e-11 * f
+        nfail += not ok
+        worst = [max(u, v) for u, v in zip(worst, e)]
+        if verbose or not ok:
+            print(("ok  " if ok else "FAIL"), dims, act, "N", N, "B", B, "bias", bias, "rows", None if idx is None else idx.shape[1], "wscale", wscale, pth,
+              "| sse %.1e grad %.1e pred %.1e" % tuple(e), flush=True)
+        del op
+    if verbose:
+        print("worst: sse %.2e grad %.2e pred %.2e; %d of %d failed" % (*worst, nfail, ncases))
+    return nfail, worst
+
+
+if __name__ == "__main__":
+    nf, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    sys.exit(1 if nf else 0)
