@@ -1,7 +1,7 @@
 """Deep saturated networks (weights ~ N(0, 16), five 128-wide layers) amplify rounding: gradient of the int8-slice kernels and
 of the float64 kernels against the oracle (numpy float64), and against each other.  See DESIGN.md section 4.2a (accuracy contract)."""
 import sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from oracle import mlp_ref
 from quinn_amd import _lib
 from quinn_amd.ops import MLPArch, BatchedMLP

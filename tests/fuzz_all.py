@@ -2,7 +2,7 @@
 """Randomised parity sweep of the whole MLP operator (QN_PATH_AUTO: whichever kernel family the dispatcher picks) against
 the oracle (oracle/mlp_ref.py: the reference's torch float64 module + autograd): random depths, uniform / ragged / odd
 widths, 1..16 inputs, 1..4 outputs, every activation, bias on / off, row subsets, weight scales.  Test infrastructure
-(imports oracle/).  usage: tools/fuzz_all.py [ncases] [seed]"""
+(imports oracle/).  usage: tests/fuzz_all.py [ncases] [seed]"""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import mlp_ref

@@ -1,4 +1,4 @@
-"""GPU: a fixed-seed slice of the randomised parity sweep (tools/fuzz_all.py): random architectures (depth, uniform / ragged
+"""GPU: a fixed-seed slice of the randomised parity sweep (tests/fuzz_all.py): random architectures (depth, uniform / ragged
 / odd widths, 1..16 inputs, 1..4 outputs, tanh / relu / identity, bias on / off), row subsets and weight scales through
 whichever kernel family the dispatcher picks, SSE / gradient / predictions against the oracle (the reference's torch
 float64 module + autograd).  Bars: 1e-11 on SSE and predictions, 1e-10 of max |g| on gradients."""
@@ -7,7 +7,7 @@ import sys
 
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 

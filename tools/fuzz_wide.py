@@ -29,7 +29,7 @@ for case in range(ncases):
     a, r = out[_lib.PATH_AUTO], out[_lib.PATH_GENERIC]
     e = [np.abs(a[0] / r[0] - 1).max(), np.abs(a[1] - r[1]).max() / max(np.abs(r[1]).max(), 1e-300), np.abs(a[3] - r[3]).max() / max(np.abs(r[3]).max(), 1e-300)]
     # weights ~ N(0, 16): deep saturated networks amplify rounding differences (the float64 kernels differ from the oracle
-    # by up to 1e-11 there; the 47-bit operands of the int8-slice kernels by ~64 times that: tools/check_chaotic_regime.py)
+    # by up to 1e-11 there; the 47-bit operands of the int8-slice kernels by ~64 times that: tests/check_chaotic_regime.py)
     f = 30.0 if wscale * np.sqrt(h) >= 4 else 1.0
     ok = e[0] <= 1e-11 * f and e[1] <= 1e-10 * f and e[2] <= 1e-11 * f and np.abs(a[2] / r[2] - 1).max() <= 1e-11 * f
     worst = [max(u, v) for u, v in zip(worst, e)]
