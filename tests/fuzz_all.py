@@ -63,6 +63,63 @@ def run(ncases=100, seed=0, verbose=True):
     return nfail, worst
 
 
+def run_rnet(ncases=60, seed=0, verbose=True):
+    """The residual networks of the reference (quinn/nns/rnet.py) the same way: random width, depth, weight
+    parameterisation, pre / post layers, bias, plain-layer mode."""
+    from oracle.rnet_ref import RNetSpec
+    from quinn_amd.nns import rnet as R
+    rs = np.random.RandomState(seed)
+    old_dt = torch.get_default_dtype()
+    torch.set_default_dtype(torch.double)
+    worst = [0.0, 0.0, 0.0]; nfail = 0
+    try:
+        for case in range(ncases):
+            r = int(rs.choice([1, 2, 3, 3, 4, 5, 8, 9, 20, 33, 64, 70])); nl = int(rs.choice([0, 1, 2, 3, 5, 7, 15]))
+            kind = str(rs.choice(["const", "lin", "quad", "cubic", "poly", "nonpar"]))
+            arg = int(rs.randint(0, 4)) if kind == "poly" else (int(rs.choice([0, rs.randint(1, nl + 2)])) if kind == "nonpar" else 0)
+            pre, post = bool(rs.rand() < 0.6), bool(rs.rand() < 0.6)
+            spec = RNetSpec(r, nl, kind, arg, int(rs.randint(1, 6)) if pre else 0, int(rs.randint(1, 5)) if post else 0,
+                            bias=bool(rs.rand() < 0.8), nonlin=bool(rs.rand() < 0.8), mlp=bool(rs.rand() < 0.25), layer_pre=pre, layer_post=post)
+            N = int(rs.choice([rs.randint(1, 40), rs.randint(40, 600)])); B = int(rs.choice([1, 2, rs.randint(3, 40)]))
+            wp = {"const": R.Const, "lin": R.Lin, "quad": R.Quad, "cubic": R.Cubic}.get(spec.wp_kind)
+            wp = wp() if wp else R.Poly(spec.wp_arg) if spec.wp_kind == "poly" else (R.NonPar(spec.wp_arg) if spec.wp_arg else None)
+            net = R.RNet(spec.rdim, spec.nlayers, wp_function=wp, indim=spec.indim or None, outdim=spec.outdim or None, biasorno=spec.bias,
+                         nonlin=spec.nonlin, mlp=spec.mlp, layer_pre=spec.layer_pre, layer_post=spec.layer_post)
+            arch = MLPArch.from_module(net)
+            assert arch.nparams == spec.nparams
+            x = rs.uniform(-2, 2, (N, spec.d)); y = rs.randn(N, spec.o)
+            W = float(rs.choice([0.05, 0.4, 1.0])) * rs.randn(B, spec.nparams)
+            idx = rs.randint(0, N, size=(B, int(rs.randint(1, N + 1)))) if rs.rand() < 0.3 else None
+            op = BatchedMLP(arch, x, y)
+            s, g = op.sse_grad(W, row_idx=idx); s2, pr = op.sse_pred(W, row_idx=idx)
+            s, g, s2, pr = (t.double().cpu().numpy() for t in (s, g, s2, pr))
+            mod = mlp_ref.build_module(spec)
+            e = [0.0, 0.0, 0.0]
+            for b in range(B):
+                xb, yb = (x, y) if idx is None else (x[idx[b]], y[idx[b]])
+                sref = mlp_ref.sse(mod, W[b], xb, yb)
+                pref = mlp_ref.forward_flat(mod, W[b], xb)
+                gref = -2.0 * mlp_ref.logpostgrad(mod, W[b], xb, [v for v in yb], 1.0)
+                e[0] = max(e[0], abs(s[b] / sref - 1), abs(s2[b] / sref - 1))
+                e[1] = max(e[1], np.abs(g[b] - gref).max() / max(np.abs(gref).max(), 1e-300))
+                e[2] = max(e[2], np.abs(pr[b].reshape(pref.shape) - pref).max() / max(np.abs(pref).max(), 1e-300))
+            ok = e[0] <= 1e-11 and e[1] <= 1e-10 and e[2] <= 1e-11
+            nfail += not ok
+            worst = [max(u, v) for u, v in zip(worst, e)]
+            Nb = N if idx is None else idx.shape[1]
+            if verbose or not ok:
+                print(("ok  " if ok else "FAIL"), spec, "N", N, "B", B, "rows", None if idx is None else idx.shape[1],
+                      PATHS.get(op.path(B, Nb, True), "?"), "| sse %.1e grad %.1e pred %.1e" % tuple(e), flush=True)
+            del op
+    finally:
+        torch.set_default_dtype(old_dt)
+    if verbose:
+        print("rnet worst: sse %.2e grad %.2e pred %.2e; %d of %d failed" % (*worst, nfail, ncases))
+    return nfail, worst
+
+
 if __name__ == "__main__":
-    nf, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    sys.exit(1 if nf else 0)
+    nc, sd = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    nf, _ = run(nc, sd)
+    nf2, _ = run_rnet(max(10, nc // 2), sd)
+    sys.exit(1 if nf + nf2 else 0)

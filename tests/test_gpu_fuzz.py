@@ -17,3 +17,9 @@ def test_random_architectures_match_the_oracle(seed):
     import fuzz_all
     nfail, worst = fuzz_all.run(ncases=40, seed=seed, verbose=False)
     assert nfail == 0, worst
+
+
+def test_random_residual_networks_match_the_oracle():
+    import fuzz_all
+    nfail, worst = fuzz_all.run_rnet(ncases=30, seed=5, verbose=False)
+    assert nfail == 0, worst
