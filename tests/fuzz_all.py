@@ -118,8 +118,68 @@ def run_rnet(ncases=60, seed=0, verbose=True):
     return nfail, worst
 
 
+def run_mcmc(ncases=12, seed=0, verbose=True):
+    """NN_MCMC (host engine: the reference's random-number stream) against the oracle's sequential chains
+    (oracle/mcmc_ref.py = quinn/mcmc): random small networks, data sizes, noise levels, sampler settings, chain counts.
+    AMCMC: chains and acceptance indices bit for bit; HMC / MALA: acceptance indices equal, states to 1e-8."""
+    from oracle import mcmc_ref
+    from quinn_amd.nns.mlp import MLP
+    from quinn_amd.solvers.nn_mcmc import NN_MCMC
+    rs = np.random.RandomState(seed)
+    old_dt = torch.get_default_dtype()
+    torch.set_default_dtype(torch.double)
+    nfail = 0
+    try:
+        for case in range(ncases):
+            d = int(rs.randint(1, 4)); o = int(rs.choice([1, 1, 2])); hid = tuple(int(v) for v in rs.choice([2, 3, 5, 8, 16, 64, 70], size=rs.randint(1, 4)))
+            act = str(rs.choice(["tanh", "relu"])); N = int(rs.randint(5, 300)); sigma = float(rs.choice([0.05, 0.2, 1.0]))
+            sampler = str(rs.choice(["amcmc", "amcmc", "hmc", "mala"])); C = int(rs.randint(1, 5)); nmcmc = int(rs.randint(40, 160))
+            seeds = [int(v) for v in rs.randint(0, 10000, size=C)]
+            x = rs.rand(N, d) * 4 - 2; y = np.sin(x.sum(axis=1, keepdims=True)) * np.ones((1, o)) + sigma * rs.randn(N, o)
+            dims = (d,) + hid + (o,)
+            spec = mlp_ref.MLPSpec(dims, act)
+            if spec.nparams > (500 if sampler == "amcmc" else 3000):      # (the reference's proposal is an SVD of p x p per step)
+                hid = hid[:1]; dims = (d,) + hid + (o,); spec = mlp_ref.MLPSpec(dims, act)
+            yd = [v for v in y]
+            if sampler == "amcmc":
+                sp = {'gamma': float(rs.choice([0.01, 0.1, 0.5])), 't0': int(rs.randint(3, 40)), 'tadapt': int(rs.randint(2, 30))}
+                mk = lambda: mcmc_ref.AmcmcState(gamma=sp['gamma'], t0=sp['t0'], tadapt=sp['tadapt'])
+            elif sampler == "hmc":
+                sp = {'epsilon': float(rs.choice([1e-3, 5e-3, 2e-2])) * sigma, 'L': int(rs.randint(1, 6))}
+                mk = lambda: mcmc_ref.HmcState(epsilon=sp['epsilon'], L=sp['L'])
+            else:
+                sp = {'epsilon': float(rs.choice([1e-3, 5e-3, 2e-2])) * sigma}
+                mk = lambda: mcmc_ref.MalaState(epsilon=sp['epsilon'])
+            mods = []
+            def mkmod():
+                mods.append(mlp_ref.build_module(spec)); return mods[-1]
+            ref = mcmc_ref.run_multichain(lambda: (lambda w, m=mkmod(): mlp_ref.logpost(m, w, x, yd, sigma)), mk, nmcmc, spec.nparams, seeds,
+                                          make_logpostgrad=None if sampler == "amcmc" else (lambda: (lambda w, m=mkmod(): mlp_ref.logpostgrad(m, w, x, yd, sigma))))
+            solver = NN_MCMC(MLP(d, o, hid, activ=act), verbose=False)
+            solver.fit(x, y, zflag=False, datanoise=sigma, nmcmc=nmcmc, sampler=sampler, sampler_params=dict(sp), seeds=seeds)
+            chain = np.asarray(solver.samples).reshape(C, nmcmc + 1, -1)
+            acc = (chain[:, 1:] != chain[:, :-1]).any(axis=2)
+            ok = np.array_equal(acc, ref["accepted"])
+            if sampler == "amcmc":
+                ok = ok and np.array_equal(chain, ref["chain"])
+            else:
+                ok = ok and np.allclose(chain, ref["chain"], rtol=1e-8, atol=1e-8)
+            lp = np.asarray(solver.mcmc_results["logpost"]).reshape(C, -1)
+            ok = ok and np.allclose(lp, ref["logpost"], rtol=1e-9)
+            nfail += not ok
+            if verbose or not ok:
+                print(("ok  " if ok else "FAIL"), dims, act, "N", N, "sigma", sigma, sampler, sp, "chains", C, "steps", nmcmc,
+                      "| accept %.2f  max |dchain| %.1e" % (acc.mean(), np.abs(chain - ref["chain"]).max()), flush=True)
+    finally:
+        torch.set_default_dtype(old_dt)
+    if verbose:
+        print("mcmc: %d of %d failed" % (nfail, ncases))
+    return nfail
+
+
 if __name__ == "__main__":
     nc, sd = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0
     nf, _ = run(nc, sd)
     nf2, _ = run_rnet(max(10, nc // 2), sd)
-    sys.exit(1 if nf + nf2 else 0)
+    nf3 = run_mcmc(max(6, nc // 10), sd)
+    sys.exit(1 if nf + nf2 + nf3 else 0)

@@ -23,3 +23,9 @@ def test_random_residual_networks_match_the_oracle():
     import fuzz_all
     nfail, worst = fuzz_all.run_rnet(ncases=30, seed=5, verbose=False)
     assert nfail == 0, worst
+
+
+def test_random_sampler_settings_reproduce_the_oracle_chains():
+    """AMCMC chains bit for bit, HMC / MALA acceptance indices (tests/fuzz_all.py: run_mcmc)."""
+    import fuzz_all
+    assert fuzz_all.run_mcmc(ncases=4, seed=9, verbose=False) == 0
