@@ -150,11 +150,16 @@ __device__ __forceinline__ double qn_tanh_f64_tab64(double x, const double* __re
     return __builtin_copysign(num * y1, x);
 }
 
-// tanh for float32: 1 - 2 / (exp(2|x|) + 1) on the hardware exp2 / rcp (7 instructions, absolute error
-// ~2e-7, i.e. float32-level; NaN propagates through v_exp_f32).
+// tanh for float32: 1 - 2 / (exp(2|x|) + 1) on the hardware exp2 / rcp (absolute error ~2e-7; NaN propagates through
+// v_exp_f32), and below 0.3 -- where that form cancels and would only be ABSOLUTELY accurate: a network with small weights
+// and no bias has activations of 1e-4 .. 1e-10, and tests/fuzz_all.py caught predictions that were pure rounding noise --
+// the odd Taylor polynomial through x^9 (relative error < 6e-8 at 0.3).
 __device__ __forceinline__ float qn_tanh_f32(float x) {
     const float ax = fminf(fabsf(x), 10.0f);
     const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);
     const float t = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
-    return x != x ? x : __builtin_copysignf(t, x);
+    const float x2 = x * x;
+    const float p = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 2.1869488536155203e-02f, -5.3968253968253971e-02f), 1.3333333333333333e-01f),
+                                      -3.3333333333333331e-01f), 1.0f);
+    return x != x ? x : (ax < 0.3f ? p : __builtin_copysignf(t, x));
 }

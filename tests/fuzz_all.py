@@ -35,7 +35,8 @@ def run(ncases=100, seed=0, verbose=True):
             if bias: parts.append(wscale * rs.randn(B, b_))
         W = np.concatenate(parts, axis=1)
         idx = rs.randint(0, N, size=(B, int(rs.randint(1, N + 1)))) if rs.rand() < 0.3 else None
-        op = BatchedMLP(arch, x, y)
+        dtype = "float32" if rs.rand() < 0.25 else "float64"
+        op = BatchedMLP(arch, x, y, dtype=dtype)
         s, g = op.sse_grad(W, row_idx=idx); s2, pr = op.sse_pred(W, row_idx=idx)
         s, g, s2, pr = (t.double().cpu().numpy() for t in (s, g, s2, pr))
         Nb = N if idx is None else idx.shape[1]
@@ -51,11 +52,12 @@ def run(ncases=100, seed=0, verbose=True):
             e[1] = max(e[1], np.abs(g[b] - gref).max() / max(np.abs(gref).max(), 1e-300))
             e[2] = max(e[2], np.abs(pr[b].reshape(pref.shape) - pref).max() / max(np.abs(pref).max(), 1e-300))
         f = 10.0 if wscale >= 3 else 1.0
-        ok = e[0] <= 1e-11 * f and e[1] <= 1e-10 * f and e[2] <= 1e-11 * f
+        ts, tg = (1e-11, 1e-10) if dtype == "float64" else (2e-4, 2e-3)      # (float32: the bars of tests/test_gpu_rnet_parity.py)
+        ok = e[0] <= ts * f and e[1] <= tg * f and e[2] <= (ts if dtype == "float64" else tg) * f
         nfail += not ok
-        worst = [max(u, v) for u, v in zip(worst, e)]
+        if dtype == "float64": worst = [max(u, v) for u, v in zip(worst, e)]
         if verbose or not ok:
-            print(("ok  " if ok else "FAIL"), dims, act, "N", N, "B", B, "bias", bias, "rows", None if idx is None else idx.shape[1], "wscale", wscale, pth,
+            print(("ok  " if ok else "FAIL"), dims, act, "N", N, "B", B, "bias", bias, "rows", None if idx is None else idx.shape[1], "wscale", wscale, dtype, pth,
               "| sse %.1e grad %.1e pred %.1e" % tuple(e), flush=True)
         del op
     if verbose:

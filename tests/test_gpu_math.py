@@ -111,3 +111,17 @@ def test_absolute_accuracy_tanh_of_the_int8_slice_kernel():
     assert np.max(err[big] / ulp[big]) < 4.0
     assert got[np.where(xs == np.inf)[0][0]] == 1.0 and got[np.where(xs == -np.inf)[0][0]] == -1.0
     assert (np.abs(got) <= 1.0).all() and (np.sign(got) == np.sign(xs)).all()
+
+
+def test_float32_tanh_is_relatively_accurate_from_1e_minus_30_to_saturation():
+    """The float32 kernels' tanh through a (1, 1, 1) network with unit weights: relative error <= 1e-6 over 30 decades
+    (the exp-based form alone is only absolutely accurate: 100 % error below 1e-7; tests/fuzz_all.py found it)."""
+    from quinn_amd.ops import BatchedMLP, MLPArch
+    mag = np.logspace(-30, 1.2, 4000)
+    x = np.concatenate([mag, -mag, [0.0, 0.2999, 0.3, 0.3001]])[:, None].astype(np.float32).astype(np.float64)
+    op = BatchedMLP(MLPArch((1, 1, 1), "tanh", bias=False), x, np.zeros_like(x), dtype="float32")
+    got = op.predict(np.ones((1, 2))).double().cpu().numpy().reshape(-1)
+    ref = np.tanh(x.reshape(-1))
+    nz = ref != 0
+    assert np.abs(got[nz] / ref[nz] - 1).max() <= 1e-6
+    assert np.all(got[~nz] == 0)
