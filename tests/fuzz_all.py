@@ -179,9 +179,56 @@ def run_mcmc(ncases=12, seed=0, verbose=True):
     return nfail
 
 
+def run_vi(ncases=40, seed=0, verbose=True):
+    """The ELBO Monte-Carlo estimator (BNet.viloss: quinn/vi/bnet.py:178-232) and its gradient with respect to (mu, rho)
+    against the oracle (oracle/vi_ref.py) on the same standard normals: random networks, MC sample counts, mixture
+    priors, noise levels, batch counts."""
+    from oracle import vi_ref
+    from quinn_amd.nns.mlp import MLP
+    from quinn_amd.vi.bnet import BNet
+    rs = np.random.RandomState(seed)
+    old_dt = torch.get_default_dtype()
+    torch.set_default_dtype(torch.double)
+    worst = [0.0, 0.0]; nfail = 0
+    try:
+        for case in range(ncases):
+            d = int(rs.randint(1, 5)); o = int(rs.choice([1, 1, 2, 3]))
+            hid = tuple(int(v) for v in rs.choice([2, 5, 11, 16, 64, 64, 70, 128], size=rs.randint(1, 4)))
+            act = str(rs.choice(["tanh", "tanh", "relu"])); N = int(rs.choice([rs.randint(1, 30), rs.randint(30, 500)])); S = int(rs.choice([1, 2, 5, 16, 33]))
+            prior = dict(pi=float(rs.choice([0.5, 0.25, 1.0])), sigma1=float(rs.choice([1.0, 0.5, 2.0])), sigma2=float(rs.choice([1.0, 0.1, 0.0025])))
+            sig = float(rs.choice([0.05, 0.3, 1.0])); nb = int(rs.randint(1, 9))
+            dims = (d,) + hid + (o,)
+            spec = mlp_ref.MLPSpec(dims, act)
+            p = spec.nparams
+            mu = rs.uniform(-0.5, 0.5, p); rho = rs.uniform(-6.0, -1.0, p); eps = rs.randn(S, p)
+            x = rs.rand(N, d) * 4 - 2; y = rs.randn(N, o)
+            ref = vi_ref.viloss(spec, mu, rho, eps, x, y, sig, nb, **prior)
+            bm = BNet(MLP(d, o, hid, activ=act), **prior)
+            with torch.no_grad():
+                bm.theta.copy_(torch.as_tensor(np.concatenate([mu, rho]), device=bm.theta.device))
+            bm._draw_eps = lambda n: torch.as_tensor(eps, device=bm.device)
+            bm.loss_params = [sig, S, nb]
+            loss = bm.viloss(x, y)
+            loss.backward()
+            gr = bm.theta.grad.cpu().numpy()
+            sc = max(np.abs(ref["dmu"]).max(), np.abs(ref["drho"]).max())
+            e = [abs(loss.item() / ref["loss"] - 1), max(np.abs(gr[:p] - ref["dmu"]).max(), np.abs(gr[p:] - ref["drho"]).max()) / sc]
+            ok = e[0] <= 1e-11 and e[1] <= 1e-10
+            nfail += not ok
+            worst = [max(u, v) for u, v in zip(worst, e)]
+            if verbose or not ok:
+                print(("ok  " if ok else "FAIL"), dims, act, "N", N, "S", S, prior, "sigma", sig, "batches", nb, "| loss %.1e grad %.1e" % tuple(e), flush=True)
+    finally:
+        torch.set_default_dtype(old_dt)
+    if verbose:
+        print("vi worst: loss %.2e grad %.2e; %d of %d failed" % (*worst, nfail, ncases))
+    return nfail, worst
+
+
 if __name__ == "__main__":
     nc, sd = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0
     nf, _ = run(nc, sd)
     nf2, _ = run_rnet(max(10, nc // 2), sd)
+    nf4, _ = run_vi(max(10, nc // 4), sd)
     nf3 = run_mcmc(max(6, nc // 10), sd)
-    sys.exit(1 if nf + nf2 + nf3 else 0)
+    sys.exit(1 if nf + nf2 + nf3 + nf4 else 0)

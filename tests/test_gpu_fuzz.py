@@ -29,3 +29,9 @@ def test_random_sampler_settings_reproduce_the_oracle_chains():
     """AMCMC chains bit for bit, HMC / MALA acceptance indices (tests/fuzz_all.py: run_mcmc)."""
     import fuzz_all
     assert fuzz_all.run_mcmc(ncases=4, seed=9, verbose=False) == 0
+
+
+def test_random_elbo_estimates_and_gradients_match_the_oracle():
+    import fuzz_all
+    nfail, worst = fuzz_all.run_vi(ncases=25, seed=6, verbose=False)
+    assert nfail == 0, worst
