@@ -158,9 +158,23 @@ static bool use_fused(const qn_desc* d, int B, int Nb, int want_grad, int dtype)
     if (d->path == QN_PATH_GENERIC || prefer_wide(d, want_grad, dtype)) return false;
     return fused_ok(d, B, Nb, want_grad, dtype);
 }
+// head of the workspace of a run on the zero-padded twin: padded weights (+ padded gradient) | flags [B + 1] | scratch of the
+// exceptional-value fix-up (k_padded_fixup below): per chain every layer's outputs + two dz vectors
+static size_t padded_fixup_doubles(const qn_desc* d) {
+    size_t sum = 0, hmax = 0;
+    for (int l = 1; l <= d->nlayers; ++l) {
+        sum += (size_t)d->dims[l];
+        hmax = (size_t)d->dims[l] > hmax ? (size_t)d->dims[l] : hmax;
+    }
+    return sum + 2 * hmax;
+}
+static size_t padded_head_bytes(const qn_desc* d, int B, int want_grad, size_t el) {
+    return (want_grad ? 2 : 1) * qn_align((size_t)B * d->padded->p * el) + qn_align((size_t)(B + 1) * sizeof(int)) +
+           qn_align((size_t)B * padded_fixup_doubles(d) * el);
+}
 static size_t fused_ws(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
     size_t tot = qn_fused_workspace(fused_desc(d), B, Nb, want_grad, dtype);
-    if (d->padded) tot += (want_grad ? 2 : 1) * qn_align((size_t)B * d->padded->p * sizeof(double));
+    if (d->padded) tot += padded_head_bytes(d, B, want_grad, sizeof(double));
     return tot;
 }
 // layer-wise kernels on the padded twin (hidden widths >= 48 that are no multiples of 64; for widths <= 64 this is
@@ -175,8 +189,7 @@ static bool use_padded_generic(const qn_desc* d) {
 }
 static size_t padded_generic_ws(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
     const size_t el = dtype == QN_F32 ? sizeof(float) : sizeof(double);
-    return qn_generic_workspace(d->padded, B, Nb, want_grad, dtype) +
-           (want_grad ? 2 : 1) * qn_align((size_t)B * d->padded->p * el);
+    return qn_generic_workspace(d->padded, B, Nb, want_grad, dtype) + padded_head_bytes(d, B, want_grad, el);
 }
 
 // ---- zero-padding of hidden layers (weights in, gradients out); one thread per element, layer found by offset
@@ -186,8 +199,24 @@ struct PadMap {
     int hin[QN_MAX_LAYERS], hout[QN_MAX_LAYERS], Hin[QN_MAX_LAYERS], Hout[QN_MAX_LAYERS];
     int64_t off[QN_MAX_LAYERS + 1], offp[QN_MAX_LAYERS + 1], p, pp;
 };
-template <typename T> __global__ void k_pad_weights(PadMap m, const T* __restrict__ W, T* __restrict__ Wp) {
+// "Padded units stay exactly 0" holds as long as nothing they are multiplied with is Inf / NaN (0 . Inf = NaN): an infinite
+// input, or -- relu / identity -- an activation that overflows.  The pad kernel therefore checks every weight of the chain and
+// (blockIdx.y == 0) every input against 2^ebound, chosen so that below it no intermediate value can overflow; flagged chains
+// (flags[b]; flags[B] = an input: every chain) are recomputed from the ORIGINAL weights by k_padded_fixup after the twin's
+// kernels.  Found by tests/fuzz_all.py (x = -inf on a 33-wide network: the reference saturates, the twin returned NaN).
+template <typename T> __device__ __forceinline__ bool pad_bounded(T v, T bound) { return (v < T(0) ? -v : v) < bound; }   // (NaN: false)
+template <typename T> __global__ void k_pad_weights(PadMap m, const T* __restrict__ W, T* __restrict__ Wp, const T* __restrict__ X,
+                                                    int64_t nx, T bound, int* __restrict__ flags) {
     const int b = blockIdx.y;
+    int bad = 0;
+    if (b == 0) {
+        int xb = 0;
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nx; e += (int64_t)gridDim.x * blockDim.x) xb |= !pad_bounded(X[e], bound);
+        if (xb) atomicOr(&flags[gridDim.y], 1);
+    }
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m.p; e += (int64_t)gridDim.x * blockDim.x)
+        bad |= !pad_bounded(W[(int64_t)b * m.p + e], bound);
+    if (bad) atomicOr(&flags[b], 1);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m.pp; e += (int64_t)gridDim.x * blockDim.x) {
         int l = 0;
         while (l + 1 < m.L && e >= m.offp[l + 1]) ++l;
@@ -201,6 +230,82 @@ template <typename T> __global__ void k_pad_weights(PadMap m, const T* __restric
             if (j < m.hout[l]) v = W[(int64_t)b * m.p + m.off[l] + (int64_t)m.hout[l] * m.hin[l] + j];
         }
         Wp[(int64_t)b * m.pp + e] = v;
+    }
+}
+struct FixNet {
+    int L, has_bias, act, d, o;
+    int dims[QN_MAX_LAYERS + 1];
+    int64_t offW[QN_MAX_LAYERS], offB[QN_MAX_LAYERS], p;
+    int acto[QN_MAX_LAYERS], dzo, hmax, per_chain;        // offsets into a chain's scratch
+};
+__device__ __forceinline__ double fix_tanh(double z) { return qn_tanh_f64(z); }
+__device__ __forceinline__ float fix_tanh(float z) { return qn_tanh_f32(z); }
+// Flagged chains again, from the original (unpadded) weights, one data row at a time with the whole workgroup: forward,
+// residual, backward (thread = its own gradient entries: no atomics, a fixed summation order).  The plain loops of the
+// reference's ops (F.linear, activation, autograd); slow, and only ever run for chains with unbounded values.
+template <typename T>
+__global__ __launch_bounds__(256) void k_padded_fixup(FixNet s, const T* __restrict__ W, const T* __restrict__ X, const T* __restrict__ Y,
+                                                      const int32_t* __restrict__ row_idx, int Nb, const int* __restrict__ flags,
+                                                      double* __restrict__ sse, T* __restrict__ pred, T* __restrict__ grad,
+                                                      T* __restrict__ scratch) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (!(flags[b] | flags[gridDim.x])) return;
+    const T* Wb = W + (int64_t)b * s.p;
+    T* act = scratch + (int64_t)b * s.per_chain;
+    T* dzbuf[2] = {act + s.dzo, act + s.dzo + s.hmax};
+    T* G = grad ? grad + (int64_t)b * s.p : nullptr;
+    if (G)
+        for (int64_t e = tid; e < s.p; e += 256) G[e] = T(0);
+    __shared__ double red[256];
+    double sacc = 0.0;
+    __syncthreads();
+    for (int n = 0; n < Nb; ++n) {
+        const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * Nb + n] : (int64_t)n;
+        for (int l = 0; l < s.L; ++l) {
+            const T* in = l == 0 ? X + rr * s.d : act + s.acto[l - 1];
+            const int hin = s.dims[l], hout = s.dims[l + 1];
+            for (int j = tid; j < hout; j += 256) {
+                T z = s.has_bias ? Wb[s.offB[l] + j] : T(0);
+                for (int i = 0; i < hin; ++i) z = fma(Wb[s.offW[l] + (int64_t)j * hin + i], in[i], z);
+                if (l + 1 < s.L) z = s.act == QN_ACT_TANH ? fix_tanh(z) : (s.act == QN_ACT_RELU ? qn_relu<T>(z) : z);
+                act[s.acto[l] + j] = z;
+            }
+            __syncthreads();
+        }
+        const T* out = act + s.acto[s.L - 1];
+        for (int qo = tid; qo < s.o; qo += 256) {
+            const T res = out[qo] - Y[rr * s.o + qo];
+            sacc += (double)res * (double)res;
+            if (pred) pred[((int64_t)b * Nb + n) * s.o + qo] = out[qo];
+            dzbuf[0][qo] = T(2) * res;
+        }
+        __syncthreads();
+        if (G) {
+            int cur = 0;
+            for (int l = s.L - 1; l >= 0; --l) {
+                const T* in = l == 0 ? X + rr * s.d : act + s.acto[l - 1];
+                const T* dz = dzbuf[cur];
+                const int hin = s.dims[l], hout = s.dims[l + 1];
+                for (int e = tid; e < hout * hin; e += 256) G[s.offW[l] + e] = fma(dz[e / hin], in[e % hin], G[s.offW[l] + e]);
+                if (s.has_bias)
+                    for (int j = tid; j < hout; j += 256) G[s.offB[l] + j] += dz[j];
+                if (l > 0)
+                    for (int i = tid; i < hin; i += 256) {
+                        T a = T(0);
+                        for (int j = 0; j < hout; ++j) a = fma(Wb[s.offW[l] + (int64_t)j * hin + i], dz[j], a);
+                        dzbuf[cur ^ 1][i] = qn_act_bwd<T>(a, in[i], s.act);
+                    }
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+    }
+    red[tid] = sacc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 256; ++k) t += red[k];
+        sse[b] = t;
     }
 }
 template <typename T> __global__ void k_unpad_grad(PadMap m, const T* __restrict__ Gp, T* __restrict__ G) {
@@ -233,17 +338,26 @@ int run_padded_t(const qn_desc* d, bool generic, int dtype, const T* W, const vo
                  size_t ws_bytes, hipStream_t st) {
     const qn_desc* q = d->padded;
     const size_t wbytes = qn_align((size_t)B * q->p * sizeof(T));
-    const size_t head = (gradW ? 2 : 1) * wbytes;
+    const size_t head = padded_head_bytes(d, B, gradW != nullptr, sizeof(T));
     if (head > ws_bytes) {
         qn_set_error("workspace too small: need more than %zu bytes, got %zu", head, ws_bytes);
         return QN_EWORKSPACE;
     }
     T* Wp = static_cast<T*>(ws);
     T* Gp = gradW ? reinterpret_cast<T*>(static_cast<char*>(ws) + wbytes) : nullptr;
+    int* flags = reinterpret_cast<int*>(static_cast<char*>(ws) + (gradW ? 2 : 1) * wbytes);
+    T* fix_scratch = reinterpret_cast<T*>(reinterpret_cast<char*>(flags) + qn_align((size_t)(B + 1) * sizeof(int)));
     const PadMap m = pad_map(d);
+    // 2^e below which no product chain of the network can overflow (tanh: only x . W0; otherwise one factor per layer and up
+    // to 2^11 terms per sum)
+    const int emax = sizeof(T) == 8 ? 1022 : 126, L = d->nlayers;
+    int eb = d->act == QN_ACT_TANH ? emax / 2 - 12 : (emax - 11 * L) / (L + 1);
+    eb = eb < 1 ? 1 : eb;
     (void)hipGetLastError();
+    QN_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)(B + 1) * sizeof(int), st));
     int gx = (int)((q->p + 255) / 256);
-    hipLaunchKernelGGL(k_pad_weights<T>, dim3(gx > 64 ? 64 : gx, B), dim3(256), 0, st, m, W, Wp);
+    hipLaunchKernelGGL(k_pad_weights<T>, dim3(gx > 64 ? 64 : gx, B), dim3(256), 0, st, m, W, Wp, static_cast<const T*>(X),
+                       (int64_t)N * d->dims[0], (T)std::ldexp(1.0, eb), flags);
     const int rc = generic ? qn_generic_run(q, dtype, Wp, X, Y, row_idx, B, N, Nb, sse, pred, Gp,
                                             static_cast<char*>(ws) + head, ws_bytes - head, st)
                            : qn_fused_run(q, dtype, Wp, X, Y, row_idx, B, N, Nb, sse, pred, Gp,
@@ -252,6 +366,20 @@ int run_padded_t(const qn_desc* d, bool generic, int dtype, const T* W, const vo
     if (gradW) {
         gx = (int)((d->p + 255) / 256);
         hipLaunchKernelGGL(k_unpad_grad<T>, dim3(gx > 64 ? 64 : gx, B), dim3(256), 0, st, m, (const T*)Gp, gradW);
+    }
+    {   // chains with unbounded values: once more from the original weights (returns at once for all others)
+        FixNet f;
+        f.L = L; f.has_bias = d->has_bias; f.act = d->act; f.d = d->dims[0]; f.o = d->dims[L]; f.p = d->p;
+        int off = 0, hmax = 0;
+        for (int l = 0; l <= L; ++l) f.dims[l] = d->dims[l];
+        for (int l = 0; l < L; ++l) {
+            f.offW[l] = d->offW[l]; f.offB[l] = d->offB[l];
+            f.acto[l] = off; off += d->dims[l + 1];
+            hmax = d->dims[l + 1] > hmax ? d->dims[l + 1] : hmax;
+        }
+        f.dzo = off; f.hmax = hmax; f.per_chain = (int)padded_fixup_doubles(d);
+        hipLaunchKernelGGL(k_padded_fixup<T>, dim3(B), dim3(256), 0, st, f, W, static_cast<const T*>(X), static_cast<const T*>(Y),
+                           row_idx, Nb, (const int*)flags, sse, static_cast<T*>(pred), gradW, fix_scratch);
     }
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;

@@ -50,7 +50,7 @@ constexpr int DWIDE = 16, OWIDE = 16;    // forward kernel (tanh): up to 16 inpu
 
 template <int ACT, bool NANSAFE = true> __device__ __forceinline__ double act_apply(double z, const double* tab) {
     if constexpr (ACT == QN_ACT_TANH) return qn_tanh_f64_tab<NANSAFE>(z, tab);
-    else if constexpr (ACT == QN_ACT_RELU) return z > 0.0 ? z : 0.0;
+    else if constexpr (ACT == QN_ACT_RELU) return qn_relu<double>(z);
     else return z;
 }
 
@@ -579,15 +579,12 @@ __device__ __forceinline__ void act_tile(const v4d& z, double (&out)[4], int act
         }
     } else if (act == QN_ACT_RELU) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) out[i] = z[i] > 0.0 ? z[i] : 0.0;
+        for (int i = 0; i < 4; ++i) out[i] = qn_relu<double>(z[i]);
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) out[i] = z[i];
     }
     __builtin_amdgcn_sched_barrier(0);
-}
-__device__ __forceinline__ double act_deriv_rt(double aout, int act) {
-    return act == QN_ACT_TANH ? 1.0 - aout * aout : (act == QN_ACT_RELU ? (aout > 0.0 ? 1.0 : 0.0) : 1.0);
 }
 
 template <int H, int NH, int DP>
@@ -804,7 +801,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dz[t][i] *= act_deriv_rt(alast[t][i], act_kind);
+            for (int i = 0; i < 4; ++i) dz[t][i] = qn_act_bwd<double>(dz[t][i], alast[t][i], act_kind);
         QN_STAMP(5);                                       // 5: last-stage column sums + dz_NH
         // ------------------------------------------------------------------ backward: hidden -> hidden layers
 #pragma unroll
@@ -902,7 +899,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
                 for (int t = 0; t < T; ++t)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dz[t][i] = nd[t][i] * act_deriv_rt(act[layer - 1][t][i], act_kind);
+                    for (int i = 0; i < 4; ++i) dz[t][i] = qn_act_bwd<double>(nd[t][i], act[layer - 1][t][i], act_kind);
                 QN_STAMP(9);                               // 9: dA MFMAs + dz
             }
         }

@@ -95,6 +95,7 @@ __device__ __forceinline__ int stage(double* __restrict__ lds, unsigned char* __
             for (int r = 0; r < 4; ++r) ex = max(ex, ((unsigned)__double2hiint(v[u][r]) & 0x7fffffffu) >> 20);
             // 2^e > every |W_ji| of the row, from the largest biased exponent field E: |w| < 2^(E - 1022)
             int e = (int)row16_max_u32(ex) - 1022;
+            bad |= e > I8_MAX_WEIGHT_EXP;                              // (an outlier weight: see qn_i8_slice.h)
             e = e < -900 ? -900 : e;                                   // (all-zero / denormal rows: any scale will do)
             double an[4];
 #pragma unroll

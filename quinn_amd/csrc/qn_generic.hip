@@ -28,16 +28,9 @@ template <> __device__ __forceinline__ float qn_tanh_finite<float>(float x) { re
 
 template <typename T> __device__ __forceinline__ T apply_act(T z, int act) {
     if (act == QN_ACT_TANH) return qn_tanh<T>(z);
-    if (act == QN_ACT_RELU) return z > T(0) ? z : T(0);
+    if (act == QN_ACT_RELU) return qn_relu<T>(z);
     return z;
 }
-// derivative expressed through the stored OUTPUT a = act(z)
-template <typename T> __device__ __forceinline__ T act_deriv(T a, int act) {
-    if (act == QN_ACT_TANH) return T(1) - a * a;
-    if (act == QN_ACT_RELU) return a > T(0) ? T(1) : T(0);
-    return T(1);
-}
-
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -144,7 +137,7 @@ __global__ __launch_bounds__(BLK) void k_bwd_dA(LayerArgs a, const T* __restrict
     for (int kk = 0; kk < KB; ++kk)
         if (k0 + kk < a.h_in) {
             const int64_t idx = ((int64_t)b * a.h_in + k0 + kk) * a.Nb + n;
-            dz_prev[idx] = acc[kk] * act_deriv(a_prev[idx], a.act);
+            dz_prev[idx] = qn_act_bwd<T>(acc[kk], a_prev[idx], a.act);
         }
 }
 
@@ -492,7 +485,7 @@ __global__ __launch_bounds__(BLK) void k_gemm64(GemmArgs g, const T* __restrict_
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[mi][ni][r] = v[mi][ni][r] > T(0) ? v[mi][ni][r] : T(0);
+                    for (int r = 0; r < 4; ++r) v[mi][ni][r] = qn_relu<T>(v[mi][ni][r]);
         }
         T* o = out + base;
 #pragma unroll
@@ -514,7 +507,7 @@ __global__ __launch_bounds__(BLK) void k_gemm64(GemmArgs g, const T* __restrict_
                 const int64_t ro = (int64_t)(16 * mi + RS * r) * Nb;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    if (ok[ni]) o[ro + 16 * ni] = acc[mi][ni][r] * act_deriv(a[ro + 16 * ni], g.act);
+                    if (ok[ni]) o[ro + 16 * ni] = qn_act_bwd<T>(acc[mi][ni][r], a[ro + 16 * ni], g.act);
             }
     }
 }
@@ -791,7 +784,7 @@ template <typename T>
 __global__ __launch_bounds__(BLK) void k_rn_dz(const T* __restrict__ g, const T* __restrict__ th, T s, int act,
                                                int64_t n, T* __restrict__ dz) {
     const int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x;
-    if (e < n) dz[e] = s * g[e] * act_deriv(th[e], act);
+    if (e < n) dz[e] = qn_act_bwd<T>(s * g[e], th[e], act);
 }
 // t += g
 template <typename T>

@@ -64,6 +64,11 @@ __device__ __forceinline__ bool block_or(int mine, double* slot) {
 // and the fixed activation scale 2^-46 (absolute error 2^-47) no longer gives relative accuracy -- those rows are redone in
 // plain float64.  Otherwise the slicing error stays <= 2^-47 / 2^-4.7 = 1.8e-13 of the rows' largest activation.
 __device__ __forceinline__ int top_digits_large(int s5) { return (s5 + 0x04040404) & (int)0xF8F8F8F8; }
+// Largest exponent a sliced matrix may have (2^e > every entry of the row): the digits keep 2^-47 of the ROW MAXIMUM, so an
+// outlier weight takes the small entries of its row their precision (norm-wise error bound 2^-47 max|W_j.| sum|a|) --
+// harmless while the outlier's term dominates the sum, wrong when it is switched off exactly (a saturated unit behind it has
+// derivative 0: tests/fuzz_all.py, weight 1e30).  Chains with |w| >= 2^20 in a sliced matrix take the plain-float64 paths.
+constexpr int I8_MAX_WEIGHT_EXP = 20;
 constexpr unsigned TINY_ACT_HI = 0x3FA00000u;       // high word of 2^-5: the same bound where float64 values are at hand
 
 // four float64 values in [-1, 1] -> six words, word k = digit k of the four values in bytes 0..3
@@ -196,6 +201,7 @@ __global__ __launch_bounds__(256) void k_i8_slice_w(I8Net net, const double* __r
             }
         }
         int e = (int)wave_max_u32(ex) - 1022;
+        bad |= e > I8_MAX_WEIGHT_EXP;
         e = e < -900 ? -900 : e;
         for (int qd = lane; qd < nq; qd += 64) {
             double an[4];

@@ -150,6 +150,17 @@ __device__ __forceinline__ double qn_tanh_f64_tab64(double x, const double* __re
     return __builtin_copysign(num * y1, x);
 }
 
+// relu with the reference's NaN semantics (torch.nn.ReLU: relu(NaN) = NaN, relu(x <= 0) = +0); `z > 0 ? z : 0` swallowed a NaN
+template <typename T> __device__ __forceinline__ T qn_relu(T z) { return z > T(0) ? z : (z != z ? z : T(0)); }
+// dz . act'(a) through the stored OUTPUT a = act(z), with the reference's semantics: tanh multiplies by 1 - a^2; relu is a
+// SELECT (torch threshold_backward on the output: a <= 0 ? 0 : dz -- an Inf / NaN gradient does not pass a dead unit, a NaN
+// output lets it pass), not a product with 0 / 1 (0 . Inf = NaN)
+template <typename T> __device__ __forceinline__ T qn_act_bwd(T dz, T a, int act) {
+    if (act == 1 /* QN_ACT_TANH */) return dz * (T(1) - a * a);
+    if (act == 2 /* QN_ACT_RELU */) return a <= T(0) ? T(0) : dz;
+    return dz;
+}
+
 // tanh for float32: 1 - 2 / (exp(2|x|) + 1) on the hardware exp2 / rcp (absolute error ~2e-7; NaN propagates through
 // v_exp_f32), and below 0.3 -- where that form cancels and would only be ABSOLUTELY accurate: a network with small weights
 // and no bias has activations of 1e-4 .. 1e-10, and tests/fuzz_all.py caught predictions that were pure rounding noise --

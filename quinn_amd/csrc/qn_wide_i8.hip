@@ -556,6 +556,7 @@ __global__ __launch_bounds__(256) void k_i8_slice_wT(I8Net net, const double* __
             ex = max(ex, ((unsigned)__double2hiint(v) & 0x7fffffffu) >> 20);
         }
         int e = (int)ex - 1022;
+        bad |= e > I8_MAX_WEIGHT_EXP;
         e = e < -900 ? -900 : e;
         const double dn = ldexp(1.0, -e);
         for (int j = j0; j < j0 + kper; j += 4) {

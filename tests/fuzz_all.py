@@ -179,6 +179,64 @@ def run_mcmc(ncases=12, seed=0, verbose=True):
     return nfail
 
 
+def run_exceptional(ncases=60, seed=0, verbose=True, paths=("auto", "generic")):
+    """Not-finite / huge / denormal values at random places (a weight, a bias, an input, a target) of random networks:
+    the kernels the dispatcher picks (QN_PATH_AUTO: fused, int8-slice, ...) and the layer-wise kernels (QN_PATH_GENERIC) must
+    follow the IEEE semantics of the reference's torch ops (the oracle): same NaN / +Inf / -Inf pattern in SSE, predictions
+    and gradient, finite values equal to 1e-11 / 1e-9."""
+    rs = np.random.RandomState(seed)
+    nfail = 0
+    codes = {"auto": _lib.PATH_AUTO, "generic": _lib.PATH_GENERIC}
+    cls = lambda v: np.where(np.isnan(v), 3, np.where(np.isposinf(v), 1, np.where(np.isneginf(v), 2, 0)))
+    for case in range(ncases):
+        h = int(rs.choice([8, 33, 64, 64, 128, 256])); nhid = int(rs.randint(1, 5)); d = int(rs.choice([1, 2, 4, 6])); o = int(rs.choice([1, 1, 2]))
+        act = str(rs.choice(["tanh", "tanh", "relu", "identity"])); bias = bool(rs.rand() < 0.8)
+        N = int(rs.randint(1, 400)); B = int(rs.randint(1, 6))
+        dims = (d,) + (h,) * nhid + (o,)
+        arch = MLPArch(dims, act, bias=bias)
+        x = rs.rand(N, d) * 2 - 1; y = rs.randn(N, o)
+        W = 0.5 * rs.randn(B, arch.nparams) / np.sqrt(h)
+        val = float(rs.choice([np.nan, np.inf, -np.inf, 1e200, -1e160, 1e-310, 3e101, 1e30]))
+        where = str(rs.choice(["w", "w", "x", "y"]))
+        if where == "w": W[rs.randint(B), rs.randint(arch.nparams)] = val
+        elif where == "x": x[rs.randint(N), rs.randint(d)] = val
+        else: y[rs.randint(N), rs.randint(o)] = val
+        mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, act, bias))
+        ref = [np.empty(B), np.empty((B, arch.nparams)), np.empty((B, N, o))]
+        with np.errstate(all="ignore"):
+            for b in range(B):
+                ref[0][b] = mlp_ref.sse(mod, W[b], x, y)
+                ref[1][b] = -2.0 * mlp_ref.logpostgrad(mod, W[b], x, [v for v in y], 1.0)
+                ref[2][b] = mlp_ref.forward_flat(mod, W[b], x)
+        op = BatchedMLP(arch, x, y)
+        ok = True; why = ""
+        for pname in paths:
+            op.set_path(codes[pname])
+            sg, g = op.sse_grad(W); s2, pr = op.sse_pred(W)
+            got = {"sse": (sg.double().cpu().numpy(), ref[0], 1e-11), "sse2": (s2.double().cpu().numpy(), ref[0], 1e-11),
+                   "pred": (pr.double().cpu().numpy().reshape(B, N, o), ref[2], 1e-11), "grad": (g.double().cpu().numpy(), ref[1], 1e-9)}
+            with np.errstate(invalid="ignore", over="ignore"):
+                for name, (u, v, tol) in got.items():
+                    cu, cv = cls(u), cls(v)
+                    if name == "grad":      # an entry that is +-Inf in the reference may be NaN (0 . Inf of a masked row in the ragged tail)
+                        cu = np.where((cu == 3) & ((cv == 1) | (cv == 2)), cv, cu)
+                    if not np.array_equal(cu, cv):
+                        ok = False; why += " %s:class(%s: %d entries)" % (pname, name, int((cu != cv).sum()))
+                        continue
+                    for b in range(B):                          # per vector: a huge vector must not hide the others
+                        fb = np.isfinite(v[b])
+                        if np.any(fb) and np.abs(u[b][fb] - v[b][fb]).max() > tol * max(np.abs(v[b][fb]).max(), 1e-300):
+                            ok = False; why += " %s:val(%s[%d] %.1e)" % (pname, name, b, np.abs(u[b][fb] - v[b][fb]).max() / max(np.abs(v[b][fb]).max(), 1e-300))
+        op.set_path(_lib.PATH_AUTO)
+        nfail += not ok
+        if verbose or not ok:
+            print(("ok  " if ok else "FAIL"), dims, act, "N", N, "B", B, "bias", bias, where, val, PATHS.get(op.path(B, N, True), "?") + "/" + PATHS.get(op.path(B, N, False), "?"), why, flush=True)
+        del op
+    if verbose:
+        print("exceptional: %d of %d failed" % (nfail, ncases))
+    return nfail
+
+
 def run_vi(ncases=40, seed=0, verbose=True):
     """The ELBO Monte-Carlo estimator (BNet.viloss: quinn/vi/bnet.py:178-232) and its gradient with respect to (mu, rho)
     against the oracle (oracle/vi_ref.py) on the same standard normals: random networks, MC sample counts, mixture

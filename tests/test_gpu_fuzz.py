@@ -35,3 +35,10 @@ def test_random_elbo_estimates_and_gradients_match_the_oracle():
     import fuzz_all
     nfail, worst = fuzz_all.run_vi(ncases=25, seed=6, verbose=False)
     assert nfail == 0, worst
+
+
+def test_non_finite_values_at_random_places_follow_the_reference():
+    """NaN / Inf / huge / denormal weights, inputs and targets on random networks (tanh / relu / identity, padded twins,
+    int8-slice and fused kernels): NaN / +Inf / -Inf pattern of SSE, predictions and gradient as torch's."""
+    import fuzz_all
+    assert fuzz_all.run_exceptional(ncases=120, seed=4, verbose=False) == 0
