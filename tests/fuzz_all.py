@@ -65,30 +65,36 @@ def run(ncases=100, seed=0, verbose=True):
     return nfail, worst
 
 
+def _random_rnet(rs):
+    """A random residual network of the reference's family: (oracle spec, operator architecture)."""
+    from oracle.rnet_ref import RNetSpec
+    from quinn_amd.nns import rnet as R
+    r = int(rs.choice([1, 2, 3, 3, 4, 5, 8, 9, 20, 33, 64, 70])); nl = int(rs.choice([0, 1, 2, 3, 5, 7, 15]))
+    kind = str(rs.choice(["const", "lin", "quad", "cubic", "poly", "nonpar"]))
+    arg = int(rs.randint(0, 4)) if kind == "poly" else (int(rs.choice([0, rs.randint(1, nl + 2)])) if kind == "nonpar" else 0)
+    pre, post = bool(rs.rand() < 0.6), bool(rs.rand() < 0.6)
+    spec = RNetSpec(r, nl, kind, arg, int(rs.randint(1, 6)) if pre else 0, int(rs.randint(1, 5)) if post else 0,
+                    bias=bool(rs.rand() < 0.8), nonlin=bool(rs.rand() < 0.8), mlp=bool(rs.rand() < 0.25), layer_pre=pre, layer_post=post)
+    wp = {"const": R.Const, "lin": R.Lin, "quad": R.Quad, "cubic": R.Cubic}.get(spec.wp_kind)
+    wp = wp() if wp else R.Poly(spec.wp_arg) if spec.wp_kind == "poly" else (R.NonPar(spec.wp_arg) if spec.wp_arg else None)
+    net = R.RNet(spec.rdim, spec.nlayers, wp_function=wp, indim=spec.indim or None, outdim=spec.outdim or None, biasorno=spec.bias,
+                 nonlin=spec.nonlin, mlp=spec.mlp, layer_pre=spec.layer_pre, layer_post=spec.layer_post)
+    arch = MLPArch.from_module(net)
+    assert arch.nparams == spec.nparams
+    return spec, arch
+
+
 def run_rnet(ncases=60, seed=0, verbose=True):
     """The residual networks of the reference (quinn/nns/rnet.py) the same way: random width, depth, weight
     parameterisation, pre / post layers, bias, plain-layer mode."""
-    from oracle.rnet_ref import RNetSpec
-    from quinn_amd.nns import rnet as R
     rs = np.random.RandomState(seed)
     old_dt = torch.get_default_dtype()
     torch.set_default_dtype(torch.double)
     worst = [0.0, 0.0, 0.0]; nfail = 0
     try:
         for case in range(ncases):
-            r = int(rs.choice([1, 2, 3, 3, 4, 5, 8, 9, 20, 33, 64, 70])); nl = int(rs.choice([0, 1, 2, 3, 5, 7, 15]))
-            kind = str(rs.choice(["const", "lin", "quad", "cubic", "poly", "nonpar"]))
-            arg = int(rs.randint(0, 4)) if kind == "poly" else (int(rs.choice([0, rs.randint(1, nl + 2)])) if kind == "nonpar" else 0)
-            pre, post = bool(rs.rand() < 0.6), bool(rs.rand() < 0.6)
-            spec = RNetSpec(r, nl, kind, arg, int(rs.randint(1, 6)) if pre else 0, int(rs.randint(1, 5)) if post else 0,
-                            bias=bool(rs.rand() < 0.8), nonlin=bool(rs.rand() < 0.8), mlp=bool(rs.rand() < 0.25), layer_pre=pre, layer_post=post)
+            spec, arch = _random_rnet(rs)
             N = int(rs.choice([rs.randint(1, 40), rs.randint(40, 600)])); B = int(rs.choice([1, 2, rs.randint(3, 40)]))
-            wp = {"const": R.Const, "lin": R.Lin, "quad": R.Quad, "cubic": R.Cubic}.get(spec.wp_kind)
-            wp = wp() if wp else R.Poly(spec.wp_arg) if spec.wp_kind == "poly" else (R.NonPar(spec.wp_arg) if spec.wp_arg else None)
-            net = R.RNet(spec.rdim, spec.nlayers, wp_function=wp, indim=spec.indim or None, outdim=spec.outdim or None, biasorno=spec.bias,
-                         nonlin=spec.nonlin, mlp=spec.mlp, layer_pre=spec.layer_pre, layer_post=spec.layer_post)
-            arch = MLPArch.from_module(net)
-            assert arch.nparams == spec.nparams
             x = rs.uniform(-2, 2, (N, spec.d)); y = rs.randn(N, spec.o)
             W = float(rs.choice([0.05, 0.4, 1.0])) * rs.randn(B, spec.nparams)
             idx = rs.randint(0, N, size=(B, int(rs.randint(1, N + 1)))) if rs.rand() < 0.3 else None
@@ -179,7 +185,7 @@ def run_mcmc(ncases=12, seed=0, verbose=True):
     return nfail
 
 
-def run_exceptional(ncases=60, seed=0, verbose=True, paths=("auto", "generic")):
+def _run_exceptional(ncases, seed, verbose, paths):
     """Not-finite / huge / denormal values at random places (a weight, a bias, an input, a target) of random networks:
     the kernels the dispatcher picks (QN_PATH_AUTO: fused, int8-slice, ...) and the layer-wise kernels (QN_PATH_GENERIC) must
     follow the IEEE semantics of the reference's torch ops (the oracle): same NaN / +Inf / -Inf pattern in SSE, predictions
@@ -189,11 +195,16 @@ def run_exceptional(ncases=60, seed=0, verbose=True, paths=("auto", "generic")):
     codes = {"auto": _lib.PATH_AUTO, "generic": _lib.PATH_GENERIC}
     cls = lambda v: np.where(np.isnan(v), 3, np.where(np.isposinf(v), 1, np.where(np.isneginf(v), 2, 0)))
     for case in range(ncases):
-        h = int(rs.choice([8, 33, 64, 64, 128, 256])); nhid = int(rs.randint(1, 5)); d = int(rs.choice([1, 2, 4, 6])); o = int(rs.choice([1, 1, 2]))
-        act = str(rs.choice(["tanh", "tanh", "relu", "identity"])); bias = bool(rs.rand() < 0.8)
         N = int(rs.randint(1, 400)); B = int(rs.randint(1, 6))
-        dims = (d,) + (h,) * nhid + (o,)
-        arch = MLPArch(dims, act, bias=bias)
+        if rs.rand() < 0.25:
+            spec, arch = _random_rnet(rs)
+            dims, act, bias, d, o, h = spec, spec.activ, spec.bias, spec.d, spec.o, spec.rdim
+        else:
+            h = int(rs.choice([8, 33, 64, 64, 128, 256])); nhid = int(rs.randint(1, 5)); d = int(rs.choice([1, 2, 4, 6])); o = int(rs.choice([1, 1, 2]))
+            act = str(rs.choice(["tanh", "tanh", "relu", "identity"])); bias = bool(rs.rand() < 0.8)
+            dims = (d,) + (h,) * nhid + (o,)
+            arch = MLPArch(dims, act, bias=bias)
+            spec = mlp_ref.MLPSpec(dims, act, bias)
         x = rs.rand(N, d) * 2 - 1; y = rs.randn(N, o)
         W = 0.5 * rs.randn(B, arch.nparams) / np.sqrt(h)
         val = float(rs.choice([np.nan, np.inf, -np.inf, 1e200, -1e160, 1e-310, 3e101, 1e30]))
@@ -201,7 +212,7 @@ def run_exceptional(ncases=60, seed=0, verbose=True, paths=("auto", "generic")):
         if where == "w": W[rs.randint(B), rs.randint(arch.nparams)] = val
         elif where == "x": x[rs.randint(N), rs.randint(d)] = val
         else: y[rs.randint(N), rs.randint(o)] = val
-        mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, act, bias))
+        mod = mlp_ref.build_module(spec)
         ref = [np.empty(B), np.empty((B, arch.nparams)), np.empty((B, N, o))]
         with np.errstate(all="ignore"):
             for b in range(B):
@@ -235,6 +246,15 @@ def run_exceptional(ncases=60, seed=0, verbose=True, paths=("auto", "generic")):
     if verbose:
         print("exceptional: %d of %d failed" % (nfail, ncases))
     return nfail
+
+
+def run_exceptional(ncases=60, seed=0, verbose=True, paths=("auto", "generic")):
+    old_dt = torch.get_default_dtype()
+    torch.set_default_dtype(torch.double)
+    try:
+        return _run_exceptional(ncases, seed, verbose, paths)
+    finally:
+        torch.set_default_dtype(old_dt)
 
 
 def run_vi(ncases=40, seed=0, verbose=True):
