@@ -257,6 +257,51 @@ def run_exceptional(ncases=60, seed=0, verbose=True, paths=("auto", "generic")):
         torch.set_default_dtype(old_dt)
 
 
+def run_fit(ncases=30, seed=0, verbose=True):
+    """The training loop of ensemble members (nnfit: quinn/nns/nnfit.py:125-166 -- epochs, minibatches from torch.randperm,
+    Adam / SGD with weight decay, best-on-validation snapshot) against the oracle's loop (oracle/fit_ref.py) from the same
+    initial weights and generator state: random networks, data sizes, batch sizes (ragged last batch), learning rates."""
+    from oracle import fit_ref
+    from quinn_amd.nns.mlp import MLP
+    from quinn_amd.nns.nnfit import load_flat_into, nnfit
+    rs = np.random.RandomState(seed)
+    old_dt = torch.get_default_dtype()
+    torch.set_default_dtype(torch.double)
+    nfail = 0
+    try:
+        for case in range(ncases):
+            d = int(rs.randint(1, 4)); o = int(rs.choice([1, 1, 2])); hid = tuple(int(v) for v in rs.choice([3, 8, 11, 32, 64, 70, 128], size=rs.randint(1, 4)))
+            act = str(rs.choice(["tanh", "tanh", "relu"])); N = int(rs.randint(2, 200)); Nv = int(rs.randint(1, 60))
+            bs = None if rs.rand() < 0.3 else int(rs.randint(1, N + 5)); opt = str(rs.choice(["adam", "adam", "sgd"]))
+            lr = float(rs.choice([1e-3, 1e-2, 5e-2])); wd = float(rs.choice([0.0, 1e-3, 0.1])); nep = int(rs.randint(1, 9))
+            dims = (d,) + hid + (o,)
+            spec = mlp_ref.MLPSpec(dims, act)
+            x = rs.rand(N, d) * 2 - 1; y = np.sin(3 * x.sum(axis=1, keepdims=True)) * np.ones((1, o)) + 0.1 * rs.randn(N, o)
+            xv = rs.rand(Nv, d) * 2 - 1; yv = np.sin(3 * xv.sum(axis=1, keepdims=True)) * np.ones((1, o))
+            w0 = rs.randn(spec.nparams) * 0.3
+            gs = int(rs.randint(0, 10000))
+            gen = torch.Generator(); gen.manual_seed(gs)
+            ref = fit_ref.fit_member_mse(spec, w0, x, y, xv, yv, nep, bs, lr, gen, wd=wd, optimizer=opt)
+            net = MLP(d, o, hid, activ=act)
+            load_flat_into(net, w0)
+            torch.manual_seed(gs)
+            info = nnfit(net, x, y, val=[xv, yv], lrate=lr, batch_size=bs, nepochs=nep, wd=wd, optimizer=opt, freq_out=100000)
+            hist = np.array(info["history"])
+            fin = np.concatenate([q.detach().flatten().cpu().numpy() for q in net.parameters()])
+            best = np.concatenate([q.detach().flatten().cpu().numpy() for q in info["best_nnmodel"].parameters()])
+            ok = hist.shape == ref["history"].shape and np.allclose(hist, ref["history"], rtol=1e-8, atol=1e-12) and info["best_epoch"] == ref["best_epoch"] \
+                and np.allclose(fin, ref["final"], rtol=1e-8, atol=1e-10) and np.allclose(best, ref["best"], rtol=1e-8, atol=1e-10)
+            nfail += not ok
+            if verbose or not ok:
+                print(("ok  " if ok else "FAIL"), dims, act, "N", N, "Nval", Nv, "batch", bs, opt, "lr", lr, "wd", wd, "epochs", nep,
+                      "| max |dw| %.1e" % np.abs(fin - ref["final"]).max(), flush=True)
+    finally:
+        torch.set_default_dtype(old_dt)
+    if verbose:
+        print("fit: %d of %d failed" % (nfail, ncases))
+    return nfail
+
+
 def run_vi(ncases=40, seed=0, verbose=True):
     """The ELBO Monte-Carlo estimator (BNet.viloss: quinn/vi/bnet.py:178-232) and its gradient with respect to (mu, rho)
     against the oracle (oracle/vi_ref.py) on the same standard normals: random networks, MC sample counts, mixture
@@ -308,5 +353,6 @@ if __name__ == "__main__":
     nf, _ = run(nc, sd)
     nf2, _ = run_rnet(max(10, nc // 2), sd)
     nf4, _ = run_vi(max(10, nc // 4), sd)
+    nf4 += run_exceptional(nc, sd) + run_fit(max(10, nc // 5), sd)
     nf3 = run_mcmc(max(6, nc // 10), sd)
     sys.exit(1 if nf + nf2 + nf3 + nf4 else 0)

@@ -42,3 +42,8 @@ def test_non_finite_values_at_random_places_follow_the_reference():
     int8-slice and fused kernels): NaN / +Inf / -Inf pattern of SSE, predictions and gradient as torch's."""
     import fuzz_all
     assert fuzz_all.run_exceptional(ncases=120, seed=4, verbose=False) == 0
+
+
+def test_random_training_loops_match_the_oracle():
+    import fuzz_all
+    assert fuzz_all.run_fit(ncases=12, seed=8, verbose=False) == 0
