@@ -73,3 +73,22 @@ def test_device_engine_two_ranks_equal_one_process(sampler, gather):
         assert outs[1]["chains"][0] == 3
         for k in keys:
             assert outs[1][k] == pytest.approx(ref[k][3:], rel=1e-6, abs=1e-4), k
+
+
+@pytest.mark.parametrize("kind", ["ens", "rms"])
+def test_ensemble_members_shard_over_two_ranks(kind):
+    """NN_Ens / NN_RMS: members block-partitioned over the ranks, one all_gather -- every rank ends up with every member's
+    weights, histories and predictions, equal to the single-process run."""
+    _no_gpu_yet()
+    tool = os.path.join(ROOT, "tools", "check_ens_2rank.py")
+    one = subprocess.run([sys.executable, tool, kind], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    ref = _json_lines(one.stdout)[-1]
+    rc, so, se = launch_ranks(tool, [kind], 2, timeout=900, capture=True)
+    assert rc == 0, se[-3000:]
+    outs = {d["rank"]: d for d in _json_lines(so)}
+    assert set(outs) == {0, 1}
+    for r in (0, 1):
+        assert outs[r]["members"] == ref["members"] == 5
+        for k in ("best_w_checksum", "final_w_checksum", "best_loss", "pred_checksum"):
+            assert outs[r][k] == pytest.approx(ref[k], rel=1e-7, abs=1e-7), (r, k)
