@@ -70,7 +70,14 @@ int qn_mlp_path(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
  * (same results to ~1e-14 relative; kept selectable as the second implementation the tests compare it with).  Under
  * QN_PATH_AUTO the float64 tanh networks with hidden widths all 128 or all 256 (one output, <= 4 inputs) take the layer-wise
  * family with their hidden layers -- forward, activation gradient, weight gradient -- as sliced exact int8 products
- * (~1e-13 relative); QN_PATH_GENERIC is the all-float64 reference of that family as well. */
+ * (~1e-13 relative); QN_PATH_GENERIC is the all-float64 reference of that family as well.
+ * Accuracy of the int8-slice kernels: operands are rounded to 2^-47 of (1 x the weight row's maximum), the products are
+ * exact -- a norm-wise bound, 47-bit against float64's 53; rows whose activations are all below ~2^-5 and chains with a
+ * hidden-matrix weight >= 2^20 (or not finite) are computed in plain float64 instead.
+ * Not-finite values, every family: SSE, predictions and gradient carry the NaN / +Inf / -Inf pattern of the reference's
+ * torch ops on the same inputs (relu(NaN) = NaN, relu backward is a select, tanh saturates an infinite input); a gradient
+ * entry that is +-Inf there may be NaN here.  Chains of a zero-padded twin with an unbounded weight or input are recomputed
+ * from the original weights (slow). */
 int qn_mlp_desc_set_path(qn_desc* desc, int path);
 
 /* sse_out[b] = sum_{n,o} (Y[r(b,n),o] - f_{W[b]}(X[r(b,n),:])[o])^2 for b < B.
