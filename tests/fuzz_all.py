@@ -37,6 +37,8 @@ def run(ncases=100, seed=0, verbose=True):
         idx = rs.randint(0, N, size=(B, int(rs.randint(1, N + 1)))) if rs.rand() < 0.3 else None
         dtype = "float32" if rs.rand() < 0.25 else "float64"
         op = BatchedMLP(arch, x, y, dtype=dtype)
+        if B > 2 and rs.rand() < 0.25:              # a workspace cap that forces the call into chunks of weight vectors
+            op.max_ws = op.workspace_bytes(max(1, B // 3), N if idx is None else idx.shape[1], True)
         s, g = op.sse_grad(W, row_idx=idx); s2, pr = op.sse_pred(W, row_idx=idx)
         s, g, s2, pr = (t.double().cpu().numpy() for t in (s, g, s2, pr))
         Nb = N if idx is None else idx.shape[1]
