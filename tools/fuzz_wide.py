@@ -3,17 +3,21 @@
 activation-gradient and weight-gradient kernels, the layer-wise int8 forward for d > 4) against the float64 kernels
 (QN_PATH_GENERIC): random widths, depths, input counts, row counts,
 vector counts, bias on / off, row subsets, weight scales from 1e-3 (tiny activations) to 4 (saturated, chaotic).
-usage: tools/fuzz_wide.py [ncases] [seed]"""
+usage: tools/fuzz_wide.py [ncases] [seed] [big]"""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quinn_amd import _lib
 from quinn_amd.ops import MLPArch, BatchedMLP
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 worst = [0.0, 0.0, 0.0]
 for case in range(ncases):
     h = int(rs.choice([64, 128, 256])); nhid = int(rs.randint(2, 6 if h <= 128 else 5)); d = int(rs.choice([1, 2, 3, 4, 4, 6]))
     N = int(rs.choice([rs.randint(1, 70), rs.randint(70, 700), rs.randint(700, 3000)])); B = int(rs.choice([1, 2, rs.randint(3, 40)]))
+    if big:                                         # many rows / many vectors: other row splits, grids beyond one wave of workgroups
+        N = int(rs.randint(3000, 40000)); B = int(rs.randint(1, max(2, 1500000 // N)))
+        if rs.rand() < 0.3: N, B = int(rs.randint(1, 300)), int(rs.randint(300, 3000))
     bias = bool(rs.rand() < 0.8); wscale = float(rs.choice([1e-3, 0.1, 1.0, 4.0])) / np.sqrt(h)
     dims = (d,) + (h,) * nhid + (1,)
     arch = MLPArch(dims, "tanh", bias=bias)
