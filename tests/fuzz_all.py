@@ -262,7 +262,9 @@ def run_exceptional(ncases=60, seed=0, verbose=True, paths=("auto", "generic")):
 def run_fit(ncases=30, seed=0, verbose=True):
     """The training loop of ensemble members (nnfit: quinn/nns/nnfit.py:125-166 -- epochs, minibatches from torch.randperm,
     Adam / SGD with weight decay, best-on-validation snapshot) against the oracle's loop (oracle/fit_ref.py) from the same
-    initial weights and generator state: random networks, data sizes, batch sizes (ragged last batch), learning rates."""
+    initial weights and generator state: random networks, data sizes, batch sizes (ragged last batch), learning rates; in
+    three forms: MSE loss, negative log-posterior with an anchored Gaussian prior (NN_RMS members, nnfit.py:64-66), MSE with
+    ReduceLROnPlateau (nnfit.py:91-92, 170-172)."""
     from oracle import fit_ref
     from quinn_amd.nns.mlp import MLP
     from quinn_amd.nns.nnfit import load_flat_into, nnfit
@@ -270,12 +272,14 @@ def run_fit(ncases=30, seed=0, verbose=True):
     old_dt = torch.get_default_dtype()
     torch.set_default_dtype(torch.double)
     nfail = 0
+    flat = lambda m: np.concatenate([q.detach().flatten().cpu().numpy() for q in m.parameters()])
     try:
         for case in range(ncases):
             d = int(rs.randint(1, 4)); o = int(rs.choice([1, 1, 2])); hid = tuple(int(v) for v in rs.choice([3, 8, 11, 32, 64, 70, 128], size=rs.randint(1, 4)))
             act = str(rs.choice(["tanh", "tanh", "relu"])); N = int(rs.randint(2, 200)); Nv = int(rs.randint(1, 60))
             bs = None if rs.rand() < 0.3 else int(rs.randint(1, N + 5)); opt = str(rs.choice(["adam", "adam", "sgd"]))
             lr = float(rs.choice([1e-3, 1e-2, 5e-2])); wd = float(rs.choice([0.0, 1e-3, 0.1])); nep = int(rs.randint(1, 9))
+            mode = str(rs.choice(["mse", "mse", "logpost", "plateau"]))
             dims = (d,) + hid + (o,)
             spec = mlp_ref.MLPSpec(dims, act)
             x = rs.rand(N, d) * 2 - 1; y = np.sin(3 * x.sum(axis=1, keepdims=True)) * np.ones((1, o)) + 0.1 * rs.randn(N, o)
@@ -283,19 +287,35 @@ def run_fit(ncases=30, seed=0, verbose=True):
             w0 = rs.randn(spec.nparams) * 0.3
             gs = int(rs.randint(0, 10000))
             gen = torch.Generator(); gen.manual_seed(gs)
-            ref = fit_ref.fit_member_mse(spec, w0, x, y, xv, yv, nep, bs, lr, gen, wd=wd, optimizer=opt)
             net = MLP(d, o, hid, activ=act)
             load_flat_into(net, w0)
-            torch.manual_seed(gs)
-            info = nnfit(net, x, y, val=[xv, yv], lrate=lr, batch_size=bs, nepochs=nep, wd=wd, optimizer=opt, freq_out=100000)
-            hist = np.array(info["history"])
-            fin = np.concatenate([q.detach().flatten().cpu().numpy() for q in net.parameters()])
-            best = np.concatenate([q.detach().flatten().cpu().numpy() for q in info["best_nnmodel"].parameters()])
-            ok = hist.shape == ref["history"].shape and np.allclose(hist, ref["history"], rtol=1e-8, atol=1e-12) and info["best_epoch"] == ref["best_epoch"] \
-                and np.allclose(fin, ref["final"], rtol=1e-8, atol=1e-10) and np.allclose(best, ref["best"], rtol=1e-8, atol=1e-10)
+            if mode == "mse":
+                ref = fit_ref.fit_member_mse(spec, w0, x, y, xv, yv, nep, bs, lr, gen, wd=wd, optimizer=opt)
+                torch.manual_seed(gs)                       # (after the oracle built its module: that draws from the global generator)
+                info = nnfit(net, x, y, val=[xv, yv], lrate=lr, batch_size=bs, nepochs=nep, wd=wd, optimizer=opt, freq_out=100000)
+                hist, rh = np.array(info["history"]), ref["history"]
+            elif mode == "logpost":
+                sig, ps = float(rs.choice([0.1, 0.5])), float(rs.choice([0.5, 2.0]))
+                anchor = rs.randn(spec.nparams) * 0.5 if rs.rand() < 0.7 else None
+                ref = fit_ref.fit_member_logpost(spec, w0, x, y, xv, yv, nep, bs, lr, gen, sig, anchor=anchor, prior_sigma=ps if anchor is not None else None)
+                pp = None if anchor is None else {'sigma': ps, 'anchor': torch.as_tensor(anchor)}
+                torch.manual_seed(gs)                       # (after the oracle built its module: that draws from the global generator)
+                info = nnfit(net, x, y, val=[xv, yv], loss_fn='logpost', datanoise=sig, priorparams=pp, lrate=lr, batch_size=bs, nepochs=nep, freq_out=100000)
+                hist, rh = np.array(info["history"]), ref["history"]
+            else:
+                nep = int(rs.randint(15, 40)); cd, fac = int(rs.randint(0, 4)), float(rs.choice([0.5, 0.1]))
+                ref = fit_ref.fit_member_plateau(spec, w0, x, y, xv, yv, nep, bs, lr, gen, cooldown=cd, factor=fac)
+                torch.manual_seed(gs)                       # (after the oracle built its module: that draws from the global generator)
+                info = nnfit(net, x, y, val=[xv, yv], lrate=lr, batch_size=bs, nepochs=nep, scheduler_lr="ReduceLROnPlateau", cooldown=cd, factor=fac, freq_out=100000)
+                hist, rh = np.array(info["history"])[:, [1, 3]], ref["history"]
+            fin = flat(net)
+            at = 1e-8 if mode == "plateau" else 1e-10         # (hundreds of Adam steps: rounding differences grow)
+            ok = hist.shape == rh.shape and np.allclose(hist, rh, rtol=1e-8, atol=at) and np.allclose(fin, ref["final"], rtol=1e-8, atol=at)
+            if mode != "plateau":
+                ok = ok and info["best_epoch"] == ref["best_epoch"] and np.allclose(flat(info["best_nnmodel"]), ref["best"], rtol=1e-8, atol=1e-10)
             nfail += not ok
             if verbose or not ok:
-                print(("ok  " if ok else "FAIL"), dims, act, "N", N, "Nval", Nv, "batch", bs, opt, "lr", lr, "wd", wd, "epochs", nep,
+                print(("ok  " if ok else "FAIL"), mode, dims, act, "N", N, "Nval", Nv, "batch", bs, opt, "lr", lr, "wd", wd, "epochs", nep,
                       "| max |dw| %.1e" % np.abs(fin - ref["final"]).max(), flush=True)
     finally:
         torch.set_default_dtype(old_dt)
@@ -304,52 +324,49 @@ def run_fit(ncases=30, seed=0, verbose=True):
     return nfail
 
 
-def run_device(ncases=20, seed=0, verbose=True):
-    """The device-resident samplers (engine='device': adaptive Metropolis and HMC without host synchronisation) on random
-    networks / data / settings.  Their random numbers are the kernels' own (Philox), so chains are checked structurally and
-    against the oracle's log-posterior at stored states: start state kept, state and log-posterior move together, acceptance
-    rate = fraction of moves, stored log-posteriors = oracle's at the stored states (1e-9), MAP bookkeeping, everything finite."""
+def run_vifit(ncases=10, seed=0, verbose=True):
+    """NN_VI.fit (nnfit with the ELBO loss: every loss evaluation draws fresh standard normals from the generator) against
+    the oracle's loop (oracle/fit_ref.py: fit_vi) from the same (mu, rho) and generator state."""
+    from oracle import fit_ref
     from quinn_amd.nns.mlp import MLP
-    from quinn_amd.solvers.nn_mcmc import NN_MCMC
+    from quinn_amd.solvers.nn_vi import NN_VI
     rs = np.random.RandomState(seed)
     old_dt = torch.get_default_dtype()
     torch.set_default_dtype(torch.double)
     nfail = 0
     try:
         for case in range(ncases):
-            d = int(rs.randint(1, 4)); o = int(rs.choice([1, 1, 2])); hid = tuple(int(v) for v in rs.choice([4, 8, 11, 16, 33, 64, 64, 100, 128], size=rs.randint(1, 4)))
-            act = str(rs.choice(["tanh", "tanh", "relu"])); N = int(rs.randint(3, 500)); sigma = float(rs.choice([0.1, 0.3, 1.0]))
-            sampler = str(rs.choice(["amcmc", "hmc"])); C = int(rs.choice([1, 3, 8, 20])); nmcmc = int(rs.randint(30, 120))
-            x = rs.rand(N, d) * 4 - 2; y = np.sin(x.sum(axis=1, keepdims=True)) * np.ones((1, o)) + sigma * rs.randn(N, o)
+            d = int(rs.randint(1, 3)); o = 1; hid = tuple(int(v) for v in rs.choice([3, 8, 16, 33, 64], size=rs.randint(1, 3)))
+            act = str(rs.choice(["tanh", "relu"])); N = int(rs.randint(4, 120)); Nv = int(rs.randint(2, 40))
+            bs = None if rs.rand() < 0.3 else int(rs.randint(2, N + 3)); lr = float(rs.choice([1e-3, 1e-2])); nep = int(rs.randint(1, 6))
+            S = int(rs.choice([1, 3, 8])); sig = float(rs.choice([0.1, 0.5]))
             dims = (d,) + hid + (o,)
             spec = mlp_ref.MLPSpec(dims, act)
-            sp = {'gamma': 0.1, 't0': int(rs.randint(5, 25)), 'tadapt': int(rs.randint(5, 25))} if sampler == "amcmc" else \
-                 {'epsilon': float(rs.choice([5e-3, 3e-2, 0.1]) * sigma / np.sqrt(N)), 'L': int(rs.randint(1, 5))}
-            solver = NN_MCMC(MLP(d, o, hid, activ=act), verbose=False)
-            ini = 0.3 * rs.randn(C, spec.nparams)
-            solver.fit(x, y, zflag=False, datanoise=sigma, nmcmc=nmcmc, param_ini=ini, sampler=sampler, sampler_params=dict(sp),
-                       seeds=[int(v) for v in rs.randint(0, 10000, size=C)], engine='device')
-            r = solver.mcmc_results
-            chain, lps = np.asarray(r['chain']).reshape(C, nmcmc + 1, -1), np.asarray(r['logpost']).reshape(C, nmcmc + 1)
-            moved = (chain[:, 1:] != chain[:, :-1]).any(axis=2)
-            why = ""
-            if not np.array_equal(chain[:, 0], ini): why += " start"
-            if not (np.isfinite(chain).all() and np.isfinite(lps).all()): why += " finite"
-            if not np.array_equal(moved, lps[:, 1:] != lps[:, :-1]): why += " moves"
-            if not np.allclose(moved.mean(axis=1), np.asarray(r['accrate']).reshape(-1), atol=1e-12): why += " accrate"
-            if not np.all(np.asarray(r['maxpost']).reshape(-1) >= lps.max(axis=1) - 1e-9 * np.abs(lps.max(axis=1))): why += " maxpost"
-            mod = mlp_ref.build_module(spec)
-            yd = [v for v in y]
-            for c, i in [(0, 0), (C - 1, nmcmc // 2), (C // 2, nmcmc)]:
-                ref = mlp_ref.logpost(mod, chain[c, i], x, yd, sigma)
-                if abs(lps[c, i] - ref) > 1e-9 * abs(ref): why += " logpost(%d,%d: %.1e)" % (c, i, abs(lps[c, i] / ref - 1))
-            nfail += bool(why)
-            if verbose or why:
-                print(("FAIL" if why else "ok  "), dims, act, "N", N, "sigma", sigma, sampler, sp, "chains", C, "steps", nmcmc, "| accept %.2f" % moved.mean(), why, flush=True)
+            p = spec.nparams
+            x = rs.rand(N, d) * 2 - 1; y = np.sin(3 * x.sum(axis=1, keepdims=True)) + 0.1 * rs.randn(N, 1)
+            xv = rs.rand(Nv, d) * 2 - 1; yv = np.sin(3 * xv.sum(axis=1, keepdims=True))
+            mu0 = rs.uniform(-0.3, 0.3, p); rho0 = rs.uniform(-5.0, -3.0, p)
+            gs = int(rs.randint(0, 10000))
+            gen = torch.Generator(); gen.manual_seed(gs)
+            ref = fit_ref.fit_vi(spec, mu0, rho0, x, y, xv, yv, nep, bs, lr, S, sig, gen)
+            vi = NN_VI(MLP(d, o, hid, activ=act), verbose=False)
+            with torch.no_grad():
+                vi.bmodel.theta.copy_(torch.as_tensor(np.concatenate([mu0, rho0]), device=vi.bmodel.theta.device))
+            torch.manual_seed(gs)
+            vi.fit(x, y, val=[xv, yv], datanoise=sig, lrate=lr, batch_size=bs, nsam=S, nepochs=nep, freq_out=100000)
+            hist = np.array(vi.fit_info["history"])
+            th = vi.bmodel.theta.detach().cpu().numpy()
+            ok = hist.shape == ref["history"].shape and np.allclose(hist, ref["history"], rtol=1e-8, atol=1e-9) and \
+                np.allclose(th[:p], ref["final"][0], rtol=1e-8, atol=1e-10) and np.allclose(th[p:], ref["final"][1], rtol=1e-8, atol=1e-10) and \
+                vi.fit_info["best_epoch"] == ref["best_epoch"]
+            nfail += not ok
+            if verbose or not ok:
+                print(("ok  " if ok else "FAIL"), "vi fit", dims, act, "N", N, "batch", bs, "S", S, "lr", lr, "epochs", nep,
+                      "| max |dmu| %.1e" % np.abs(th[:p] - ref["final"][0]).max(), flush=True)
     finally:
         torch.set_default_dtype(old_dt)
     if verbose:
-        print("device engines: %d of %d failed" % (nfail, ncases))
+        print("vi fit: %d of %d failed" % (nfail, ncases))
     return nfail
 
 
@@ -404,6 +421,6 @@ if __name__ == "__main__":
     nf, _ = run(nc, sd)
     nf2, _ = run_rnet(max(10, nc // 2), sd)
     nf4, _ = run_vi(max(10, nc // 4), sd)
-    nf4 += run_exceptional(nc, sd) + run_fit(max(10, nc // 5), sd) + run_device(max(10, nc // 5), sd)
+    nf4 += run_exceptional(nc, sd) + run_fit(max(10, nc // 5), sd) + run_device(max(10, nc // 5), sd) + run_vifit(max(6, nc // 10), sd)
     nf3 = run_mcmc(max(6, nc // 10), sd)
     sys.exit(1 if nf + nf2 + nf3 + nf4 else 0)

@@ -52,3 +52,8 @@ def test_random_training_loops_match_the_oracle():
 def test_device_resident_samplers_on_random_networks():
     import fuzz_all
     assert fuzz_all.run_device(ncases=12, seed=3, verbose=False) == 0
+
+
+def test_random_vi_fits_match_the_oracle_loop():
+    import fuzz_all
+    assert fuzz_all.run_vifit(ncases=5, seed=2, verbose=False) == 0
