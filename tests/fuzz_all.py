@@ -324,6 +324,65 @@ def run_fit(ncases=30, seed=0, verbose=True):
     return nfail
 
 
+def run_ens(ncases=12, seed=0, verbose=True):
+    """The batched ensemble trainers (NN_Ens.fit, NN_RMS.fit: every member's forward / backward in ONE call per optimiser
+    step) against the oracle's member-after-member loops (oracle/fit_ref.py: fit_ensemble / fit_rms = nn_ens.py:36-69,
+    nn_rms.py:41-57): random networks, member counts, data fractions (ragged member subsets), batch sizes, with and without a
+    validation set.  Histories, best and final weights of every member."""
+    from oracle import fit_ref
+    from quinn_amd.nns.mlp import MLP
+    from quinn_amd.nns.nnfit import load_flat_into
+    from quinn_amd.solvers.nn_ens import NN_Ens
+    from quinn_amd.solvers.nn_rms import NN_RMS
+    rs = np.random.RandomState(seed)
+    old_dt = torch.get_default_dtype()
+    torch.set_default_dtype(torch.double)
+    nfail = 0
+    try:
+        for case in range(ncases):
+            d = int(rs.randint(1, 4)); o = int(rs.choice([1, 1, 2])); hid = tuple(int(v) for v in rs.choice([3, 8, 11, 32, 64, 70, 128], size=rs.randint(1, 4)))
+            act = str(rs.choice(["tanh", "tanh", "relu"])); N = int(rs.randint(4, 150)); Nv = int(rs.randint(1, 40))
+            M = int(rs.randint(1, 7)); dfrac = float(rs.choice([1.0, 0.8, 0.5])); kind = str(rs.choice(["ens", "ens", "rms"]))
+            bs = None if rs.rand() < 0.3 else int(rs.randint(1, N + 5)); lr = float(rs.choice([1e-3, 1e-2, 5e-2])); nep = int(rs.randint(1, 7))
+            noval = bool(rs.rand() < 0.3)
+            dims = (d,) + hid + (o,)
+            spec = mlp_ref.MLPSpec(dims, act)
+            x = rs.rand(N, d) * 2 - 1; y = np.sin(3 * x.sum(axis=1, keepdims=True)) * np.ones((1, o)) + 0.1 * rs.randn(N, o)
+            xv = rs.rand(Nv, d) * 2 - 1; yv = np.sin(3 * xv.sum(axis=1, keepdims=True)) * np.ones((1, o))
+            w0 = rs.randn(spec.nparams) * 0.3
+            ns, ts = int(rs.randint(0, 10000)), int(rs.randint(0, 10000))
+            gen = torch.Generator(); gen.manual_seed(ts)
+            vx, vy = (None, None) if noval else (xv, yv)
+            net = MLP(d, o, hid, activ=act)
+            load_flat_into(net, w0)
+            if kind == "ens":
+                ref = fit_ref.fit_ensemble(spec, w0, x, y, vx, vy, M, dfrac, nep, bs, lr, np.random.RandomState(ns), gen)
+                uq = NN_Ens(net, nens=M, dfrac=dfrac, verbose=False)
+            else:
+                sig, ps = float(rs.choice([0.1, 0.5])), float(rs.choice([0.5, 2.0]))
+                ref = fit_ref.fit_rms(spec, w0, x, y, vx, vy, M, dfrac, nep, bs, lr, np.random.RandomState(ns), gen, sig, ps)
+                uq = NN_RMS(net, nens=M, dfrac=dfrac, verbose=False, datanoise=sig, priorsigma=ps)
+            np.random.seed(ns)
+            torch.manual_seed(ts)
+            kw = {} if noval else {"val": [xv, yv]}
+            uq.fit(x, y, lrate=lr, batch_size=bs, nepochs=nep, freq_out=100000, **kw)
+            ok = True
+            for j in range(M):
+                h = np.array(uq.learners[j].history)
+                ok = ok and h.shape == ref[j]["history"].shape and np.allclose(h, ref[j]["history"], rtol=1e-8, atol=1e-10) \
+                    and np.allclose(uq.fit_results["best_w"][j], ref[j]["best"], rtol=1e-8, atol=1e-10) \
+                    and np.allclose(uq.fit_results["final_w"][j], ref[j]["final"], rtol=1e-8, atol=1e-10)
+            nfail += not ok
+            if verbose or not ok:
+                print(("ok  " if ok else "FAIL"), kind, dims, act, "N", N, "members", M, "dfrac", dfrac, "batch", bs, "lr", lr, "epochs", nep, "noval" if noval else "val",
+                      "| max |dw| %.1e" % max(np.abs(uq.fit_results["final_w"][j] - ref[j]["final"]).max() for j in range(M)), flush=True)
+    finally:
+        torch.set_default_dtype(old_dt)
+    if verbose:
+        print("ensembles: %d of %d failed" % (nfail, ncases))
+    return nfail
+
+
 def run_vifit(ncases=10, seed=0, verbose=True):
     """NN_VI.fit (nnfit with the ELBO loss: every loss evaluation draws fresh standard normals from the generator) against
     the oracle's loop (oracle/fit_ref.py: fit_vi) from the same (mu, rho) and generator state."""
@@ -421,6 +480,6 @@ if __name__ == "__main__":
     nf, _ = run(nc, sd)
     nf2, _ = run_rnet(max(10, nc // 2), sd)
     nf4, _ = run_vi(max(10, nc // 4), sd)
-    nf4 += run_exceptional(nc, sd) + run_fit(max(10, nc // 5), sd) + run_device(max(10, nc // 5), sd) + run_vifit(max(6, nc // 10), sd)
+    nf4 += run_exceptional(nc, sd) + run_fit(max(10, nc // 5), sd) + run_device(max(10, nc // 5), sd) + run_vifit(max(6, nc // 10), sd) + run_ens(max(6, nc // 10), sd)
     nf3 = run_mcmc(max(6, nc // 10), sd)
     sys.exit(1 if nf + nf2 + nf3 + nf4 else 0)

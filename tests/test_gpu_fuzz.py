@@ -57,3 +57,8 @@ def test_device_resident_samplers_on_random_networks():
 def test_random_vi_fits_match_the_oracle_loop():
     import fuzz_all
     assert fuzz_all.run_vifit(ncases=5, seed=2, verbose=False) == 0
+
+
+def test_random_batched_ensemble_fits_match_member_after_member_oracle_loops():
+    import fuzz_all
+    assert fuzz_all.run_ens(ncases=10, seed=5, verbose=False) == 0
