@@ -384,3 +384,24 @@ def test_user_supplied_initial_covariance():
     assert np.abs(emp - cov).max() < 0.25 * np.abs(cov).max()
     long = DeviceAMCMC(op, 0.2, gamma=0.1, t0=50, tadapt=100, seed=5, cov_ini=cov).run(400, ini)
     assert torch.isfinite(long['logpost']).all() and (long['accrate'] > 0).all()
+
+
+@pytest.mark.parametrize("bad", ["y_nan", "y_inf"])
+@pytest.mark.parametrize("engine", ["host", "device"])
+@pytest.mark.parametrize("sampler,sp", [("amcmc", {'gamma': 0.1, 't0': 10, 'tadapt': 10}), ("hmc", {'epsilon': 0.01, 'L': 3})])
+def test_a_log_posterior_that_is_not_finite_rejects_every_step(bad, engine, sampler, sp):
+    """mcmc.py:68-75: the MH ratio exp(NaN) / exp(inf - inf) is NaN and `u < NaN` is False -- the chain stays at its start,
+    acceptance rate 0, on both engines."""
+    x, y = _problem()
+    y = y.copy()
+    y[3, 0] = np.nan if bad == "y_nan" else np.inf
+    torch.manual_seed(0)
+    solver = NN_MCMC(MLP(1, 1, (8, 8), activ='tanh'), verbose=False)
+    with np.errstate(all="ignore"):
+        solver.fit(x, y, zflag=False, datanoise=0.1, nmcmc=30, sampler=sampler, sampler_params=dict(sp), seeds=[1, 2, 3], engine=engine)
+    r = solver.mcmc_results
+    chain = np.asarray(r['chain']).reshape(3, 31, -1)
+    assert np.isfinite(chain).all() and (chain == chain[:, :1]).all()
+    assert (np.asarray(r['accrate']) == 0).all()
+    lp = np.asarray(r['logpost']).reshape(3, -1)
+    assert np.isnan(lp).all() if bad == "y_nan" else np.isneginf(lp).all()
