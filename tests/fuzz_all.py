@@ -429,6 +429,55 @@ def run_vifit(ncases=10, seed=0, verbose=True):
     return nfail
 
 
+def run_device(ncases=20, seed=0, verbose=True):
+    """The device-resident samplers (engine='device': adaptive Metropolis and HMC without host synchronisation) on random
+    networks / data / settings.  Their random numbers are the kernels' own (Philox), so chains are checked structurally and
+    against the oracle's log-posterior at stored states: start state kept, state and log-posterior move together, acceptance
+    rate = fraction of moves, stored log-posteriors = oracle's at the stored states (1e-9), MAP bookkeeping, everything finite."""
+    from quinn_amd.nns.mlp import MLP
+    from quinn_amd.solvers.nn_mcmc import NN_MCMC
+    rs = np.random.RandomState(seed)
+    old_dt = torch.get_default_dtype()
+    torch.set_default_dtype(torch.double)
+    nfail = 0
+    try:
+        for case in range(ncases):
+            d = int(rs.randint(1, 4)); o = int(rs.choice([1, 1, 2])); hid = tuple(int(v) for v in rs.choice([4, 8, 11, 16, 33, 64, 64, 100, 128], size=rs.randint(1, 4)))
+            act = str(rs.choice(["tanh", "tanh", "relu"])); N = int(rs.randint(3, 500)); sigma = float(rs.choice([0.1, 0.3, 1.0]))
+            sampler = str(rs.choice(["amcmc", "hmc"])); C = int(rs.choice([1, 3, 8, 20])); nmcmc = int(rs.randint(30, 120))
+            x = rs.rand(N, d) * 4 - 2; y = np.sin(x.sum(axis=1, keepdims=True)) * np.ones((1, o)) + sigma * rs.randn(N, o)
+            dims = (d,) + hid + (o,)
+            spec = mlp_ref.MLPSpec(dims, act)
+            sp = {'gamma': 0.1, 't0': int(rs.randint(5, 25)), 'tadapt': int(rs.randint(5, 25))} if sampler == "amcmc" else \
+                 {'epsilon': float(rs.choice([5e-3, 3e-2, 0.1]) * sigma / np.sqrt(N)), 'L': int(rs.randint(1, 5))}
+            solver = NN_MCMC(MLP(d, o, hid, activ=act), verbose=False)
+            ini = 0.3 * rs.randn(C, spec.nparams)
+            solver.fit(x, y, zflag=False, datanoise=sigma, nmcmc=nmcmc, param_ini=ini, sampler=sampler, sampler_params=dict(sp),
+                       seeds=[int(v) for v in rs.randint(0, 10000, size=C)], engine='device')
+            r = solver.mcmc_results
+            chain, lps = np.asarray(r['chain']).reshape(C, nmcmc + 1, -1), np.asarray(r['logpost']).reshape(C, nmcmc + 1)
+            moved = (chain[:, 1:] != chain[:, :-1]).any(axis=2)
+            why = ""
+            if not np.array_equal(chain[:, 0], ini): why += " start"
+            if not (np.isfinite(chain).all() and np.isfinite(lps).all()): why += " finite"
+            if not np.array_equal(moved, lps[:, 1:] != lps[:, :-1]): why += " moves"
+            if not np.allclose(moved.mean(axis=1), np.asarray(r['accrate']).reshape(-1), atol=1e-12): why += " accrate"
+            if not np.all(np.asarray(r['maxpost']).reshape(-1) >= lps.max(axis=1) - 1e-9 * np.abs(lps.max(axis=1))): why += " maxpost"
+            mod = mlp_ref.build_module(spec)
+            yd = [v for v in y]
+            for c, i in [(0, 0), (C - 1, nmcmc // 2), (C // 2, nmcmc)]:
+                ref = mlp_ref.logpost(mod, chain[c, i], x, yd, sigma)
+                if abs(lps[c, i] - ref) > 1e-9 * abs(ref): why += " logpost(%d,%d: %.1e)" % (c, i, abs(lps[c, i] / ref - 1))
+            nfail += bool(why)
+            if verbose or why:
+                print(("FAIL" if why else "ok  "), dims, act, "N", N, "sigma", sigma, sampler, sp, "chains", C, "steps", nmcmc, "| accept %.2f" % moved.mean(), why, flush=True)
+    finally:
+        torch.set_default_dtype(old_dt)
+    if verbose:
+        print("device engines: %d of %d failed" % (nfail, ncases))
+    return nfail
+
+
 def run_vi(ncases=40, seed=0, verbose=True):
     """The ELBO Monte-Carlo estimator (BNet.viloss: quinn/vi/bnet.py:178-232) and its gradient with respect to (mu, rho)
     against the oracle (oracle/vi_ref.py) on the same standard normals: random networks, MC sample counts, mixture
