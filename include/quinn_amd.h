@@ -52,6 +52,12 @@ int qn_mlp_desc_create(const int* dims, int ndims, int act, int has_bias, qn_des
  * The descriptor is used with the same qn_mlp_* entry points as an MLP's. */
 int qn_rnet_desc_create(int indim, int rdim, int outdim, int nsteps, int npar, const double* coef, int act,
                         int has_bias, int layer_pre, int layer_post, int mlp, qn_desc** out);
+/* uses[i*npar+k] = 0: parameter tensor k does not enter step i at all (NonPar, rnet.py:349-377, picks ONE tensor per step:
+ * `pars[int(t * npar)]`); such a tensor is skipped -- its value, even Inf or NaN, has no effect on the step and its
+ * gradient receives nothing from it -- where a tensor with uses = 1 and coefficient 0 (the t^k of Lin / Quad / Cubic / Poly at
+ * t = 0, which the reference multiplies out) contributes 0 * value.  Default: every entry 1.  n = nsteps * npar; an entry
+ * marked unused must have coefficient 0. */
+int qn_rnet_desc_set_uses(qn_desc* desc, const unsigned char* uses, int n);
 int qn_mlp_desc_destroy(qn_desc* desc);
 /* p = number of entries of one flat weight vector. */
 int64_t qn_mlp_num_params(const qn_desc* desc);

@@ -18,7 +18,7 @@ ACT_CODES = {"identity": 0, "tanh": 1, "relu": 2}
 PATH_AUTO, PATH_GENERIC, PATH_FUSED, PATH_FUSED_DP = 0, 1, 2, 3
 
 # every symbol include/quinn_amd.h declares (tests check the .so exports all of them)
-SYMBOLS = ["qn_mlp_desc_create", "qn_rnet_desc_create", "qn_mlp_desc_destroy", "qn_mlp_num_params", "qn_workspace_bytes",
+SYMBOLS = ["qn_mlp_desc_create", "qn_rnet_desc_create", "qn_rnet_desc_set_uses", "qn_mlp_desc_destroy", "qn_mlp_num_params", "qn_workspace_bytes",
            "qn_mlp_path", "qn_mlp_desc_set_path", "qn_mlp_sse_fwd", "qn_mlp_sse_parts", "qn_mlp_sse_fwd_parts", "qn_mlp_sse_fwdbwd", "qn_vi_sample_kl",
            "qn_vi_grad", "qn_adam_batched", "qn_mcmc_propose", "qn_mcmc_propose_hist", "qn_mcmc_hist_block_steps", "qn_mcmc_propose_hist_block",
            "qn_mcmc_apply_delta", "qn_mcmc_accept", "qn_mcmc_accept_propose", "qn_hmc_parts", "qn_hmc_begin", "qn_hmc_leap", "qn_hmc_accept", "qn_pred_moments", "qn_debug_tanh", "qn_debug_tanh_finite", "qn_debug_tanh_table", "qn_last_error",
@@ -72,6 +72,8 @@ def lib():
     L.qn_rnet_desc_create.argtypes = [i32, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_double), i32, i32, i32, i32,
                                       i32, ctypes.POINTER(vp)]
     L.qn_rnet_desc_create.restype = i32
+    L.qn_rnet_desc_set_uses.argtypes = [vp, ctypes.POINTER(ctypes.c_ubyte), i32]
+    L.qn_rnet_desc_set_uses.restype = i32
     L.qn_mlp_desc_destroy.argtypes = [vp]
     L.qn_mlp_desc_destroy.restype = i32
     L.qn_mlp_num_params.argtypes = [vp]

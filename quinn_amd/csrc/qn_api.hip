@@ -121,6 +121,7 @@ extern "C" int qn_rnet_desc_create(int indim, int rdim, int outdim, int nsteps, 
     d->rn_r = rdim; d->rn_steps = nsteps; d->rn_npar = npar;
     d->rn_pre = layer_pre ? 1 : 0; d->rn_post = layer_post ? 1 : 0; d->rn_mlp = mlp ? 1 : 0;
     for (int i = 0; i < nsteps * npar; ++i) d->rn_coef[i] = coef[i];
+    for (int i = 0; i < QN_MAX_LAYERS * QN_MAX_LAYERS; ++i) d->rn_uses[i] = 1;
     // parameters() order of the module: weight_pre, bias_pre, weight_post, bias_post, ww_*, bb_*  (rnet.py:90-120)
     int64_t off = 0;
     d->rn_offWpre = off; if (layer_pre) off += (int64_t)rdim * indim;
@@ -132,6 +133,21 @@ extern "C" int qn_rnet_desc_create(int indim, int rdim, int outdim, int nsteps, 
     d->p = off;
     d->padded = nullptr;
     *out = d;
+    return QN_OK;
+}
+
+extern "C" int qn_rnet_desc_set_uses(qn_desc* d, const unsigned char* uses, int n) {
+    if (!d || !uses || d->kind != QN_KIND_RNET || n != d->rn_steps * d->rn_npar) {
+        qn_set_error("qn_rnet_desc_set_uses: need a residual-network descriptor and nsteps * npar entries");
+        return QN_EINVAL;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!uses[i] && d->rn_coef[i] != 0.0) {
+            qn_set_error("qn_rnet_desc_set_uses: entry %d is marked unused but has coefficient %g", i, d->rn_coef[i]);
+            return QN_EINVAL;
+        }
+        d->rn_uses[i] = uses[i] ? 1 : 0;
+    }
     return QN_OK;
 }
 

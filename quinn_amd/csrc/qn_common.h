@@ -21,6 +21,8 @@ struct qn_desc {
     // ---- residual network (quinn/nns/rnet.py:16-170); kind == QN_KIND_RNET.  dims[] = {d, r, o}.
     int kind;
     int rn_r, rn_steps, rn_npar, rn_pre, rn_post, rn_mlp;
+    unsigned char rn_uses[QN_MAX_LAYERS * QN_MAX_LAYERS];   // [steps][npar]: tensor k enters step i at all (qn_rnet_desc_set_uses); a
+                                    // tensor that does not is SKIPPED, not multiplied by its zero coefficient (0 . Inf = NaN)
     int64_t rn_offWpre, rn_offBpre, rn_offWpost, rn_offBpost, rn_offWW, rn_offBB;
     double rn_coef[QN_MAX_LAYERS * QN_MAX_LAYERS];   // [steps][npar]: W_i = sum_k coef[i][k] * ww_k
     // ---- MLP whose hidden widths are <= 64 but not all equal to 16 / 32 / 64: the same network with every hidden

@@ -668,6 +668,14 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
             xbad |= !qn_bounded(xk[k]);
         }
         const bool nan_possible = w_unbounded || __any(xbad);
+        // relu / identity activations are unbounded: the masked rows of a ragged tail (they re-run row 0 with a zero
+        // residual) must contribute 0 . 0, not 0 . Inf = NaN, so their inputs, activations and dz are zeroed outright
+        // (tanh: activations are bounded and the zero residual is enough)
+        const bool maskrow = act_kind != QN_ACT_TANH && !valid;
+        if (maskrow) {
+#pragma unroll
+            for (int k = 0; k < DP; ++k) xk[k] = 0.0;
+        }
         QN_STAMP(0);                                       // 0: loop top + x load
         // ------------------------------------------------------------------ forward
         double act[NH][T][4];
@@ -682,6 +690,10 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
                 for (int k = 0; k < DP; ++k) z[i] = fma(lds[offW0 + j * DP + k], xk[k], z[i]);
             }
             act_tile(z, act[0][t], act_kind, nan_possible, tanh_tab);
+            if (maskrow) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) act[0][t][i] = 0.0;
+            }
         }
 #pragma unroll
         for (int layer = 1; layer < NH; ++layer) {
@@ -711,7 +723,13 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int t = 0; t < T; ++t) act_tile(acc[t], act[layer][t], act_kind, nan_possible, tanh_tab);
+                for (int t = 0; t < T; ++t) {
+                    act_tile(acc[t], act[layer][t], act_kind, nan_possible, tanh_tab);
+                    if (maskrow) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) act[layer][t][i] = 0.0;
+                    }
+                }
             }
         }
         double (&alast)[T][4] = act[NH - 1];
@@ -801,7 +819,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dz[t][i] = qn_act_bwd<double>(dz[t][i], alast[t][i], act_kind);
+            for (int i = 0; i < 4; ++i) dz[t][i] = maskrow ? 0.0 : qn_act_bwd<double>(dz[t][i], alast[t][i], act_kind);
         QN_STAMP(5);                                       // 5: last-stage column sums + dz_NH
         // ------------------------------------------------------------------ backward: hidden -> hidden layers
 #pragma unroll
@@ -899,7 +917,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
                 for (int t = 0; t < T; ++t)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dz[t][i] = qn_act_bwd<double>(nd[t][i], act[layer - 1][t][i], act_kind);
+                    for (int i = 0; i < 4; ++i) dz[t][i] = maskrow ? 0.0 : qn_act_bwd<double>(nd[t][i], act[layer - 1][t][i], act_kind);
                 QN_STAMP(9);                               // 9: dA MFMAs + dz
             }
         }

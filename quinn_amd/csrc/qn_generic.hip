@@ -40,6 +40,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 struct LayerArgs {
     int64_t p, offW, offB;
     int has_bias, h_in, h_out, act, Nb, first, d, o;
+    int eye;        // the layer is the identity map (a residual network without pre / post layer): COPY the input -- a product
+                    // with an identity matrix turns an infinite input into NaN (0 . Inf) where the reference passes it on
 };
 
 // ---- hidden layer forward: out[b][j][n] = act(b_j + sum_k W[j][k] * in[b][k][n])
@@ -58,11 +60,17 @@ __global__ __launch_bounds__(BLK) void k_fwd_hidden(LayerArgs a, const T* __rest
         acc[jj] = (a.has_bias && j0 + jj < a.h_out) ? W[(int64_t)b * a.p + a.offB + j0 + jj] : T(0);
     int64_t row = n;
     if (a.first && row_idx) row = row_idx[(int64_t)b * a.Nb + n];
-    for (int k = 0; k < a.h_in; ++k) {
-        const T v = a.first ? X[row * a.d + k] : in[((int64_t)b * a.h_in + k) * a.Nb + n];
+    if (a.eye) {
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj)
-            if (j0 + jj < a.h_out) acc[jj] = fma(Wl[(int64_t)(j0 + jj) * a.h_in + k], v, acc[jj]);
+            if (j0 + jj < a.h_out) acc[jj] = a.first ? X[row * a.d + j0 + jj] : in[((int64_t)b * a.h_in + j0 + jj) * a.Nb + n];
+    } else {
+        for (int k = 0; k < a.h_in; ++k) {
+            const T v = a.first ? X[row * a.d + k] : in[((int64_t)b * a.h_in + k) * a.Nb + n];
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj)
+                if (j0 + jj < a.h_out) acc[jj] = fma(Wl[(int64_t)(j0 + jj) * a.h_in + k], v, acc[jj]);
+        }
     }
 #pragma unroll
     for (int jj = 0; jj < JB; ++jj)
@@ -86,9 +94,13 @@ __global__ __launch_bounds__(BLK) void k_fwd_last(LayerArgs a, const T* __restri
         if (row_idx) row = row_idx[(int64_t)b * a.Nb + n];
         for (int j = 0; j < a.h_out; ++j) {
             T acc = a.has_bias ? W[(int64_t)b * a.p + a.offB + j] : T(0);
-            for (int k = 0; k < a.h_in; ++k) {
-                const T v = a.first ? X[row * a.d + k] : in[((int64_t)b * a.h_in + k) * a.Nb + n];
-                acc = fma(Wl[(int64_t)j * a.h_in + k], v, acc);
+            if (a.eye) {
+                acc = a.first ? X[row * a.d + j] : in[((int64_t)b * a.h_in + j) * a.Nb + n];
+            } else {
+                for (int k = 0; k < a.h_in; ++k) {
+                    const T v = a.first ? X[row * a.d + k] : in[((int64_t)b * a.h_in + k) * a.Nb + n];
+                    acc = fma(Wl[(int64_t)j * a.h_in + k], v, acc);
+                }
             }
             const T r = acc - Y[row * a.o + j];
             if (pred) pred[((int64_t)b * a.Nb + n) * a.o + j] = acc;
@@ -607,7 +619,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         LayerArgs a;
         a.p = d->p; a.offW = d->offW[l]; a.offB = d->offB[l]; a.has_bias = d->has_bias;
         a.h_in = d->dims[l]; a.h_out = d->dims[l + 1]; a.act = d->act; a.Nb = Nb; a.first = (l == 0);
-        a.d = d->dims[0]; a.o = d->dims[L];
+        a.d = d->dims[0]; a.o = d->dims[L]; a.eye = 0;
         return a;
     };
     auto gargs = [&](int l) {
@@ -729,7 +741,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
 // LayerArgs), and the step gradients are contracted back with the same coefficients.
 //   OUT_0 = act(Wpre x + bpre) | x ;  TH_i = act(Weff_i OUT_i + beff_i) ;
 //   OUT_{i+1} = mlp ? TH_i : OUT_i + h * TH_i ;  pred = Wpost OUT_S + bpost | OUT_S.
-struct RnCoef { double c[QN_MAX_LAYERS * QN_MAX_LAYERS]; };
+struct RnCoef { double c[QN_MAX_LAYERS * QN_MAX_LAYERS]; unsigned char use[QN_MAX_LAYERS * QN_MAX_LAYERS]; };
 
 template <typename T>
 __global__ __launch_bounds__(BLK) void k_rn_expand(RnCoef cf, const T* __restrict__ W, int64_t p, int64_t offWW,
@@ -742,9 +754,11 @@ __global__ __launch_bounds__(BLK) void k_rn_expand(RnCoef cf, const T* __restric
         const int i = e / per, q = e % per;
         T s = T(0);
         if (q < rr) {
-            for (int k = 0; k < npar; ++k) s = fma((T)cf.c[i * npar + k], Wb[offWW + (int64_t)k * rr + q], s);
+            for (int k = 0; k < npar; ++k)
+                if (cf.use[i * npar + k]) s = fma((T)cf.c[i * npar + k], Wb[offWW + (int64_t)k * rr + q], s);
         } else if (has_bias) {
-            for (int k = 0; k < npar; ++k) s = fma((T)cf.c[i * npar + k], Wb[offBB + (int64_t)k * r + q - rr], s);
+            for (int k = 0; k < npar; ++k)
+                if (cf.use[i * npar + k]) s = fma((T)cf.c[i * npar + k], Wb[offBB + (int64_t)k * r + q - rr], s);
         }
         Weff[(int64_t)b * tot + e] = s;
     }
@@ -761,7 +775,7 @@ __global__ __launch_bounds__(BLK) void k_rn_contract(RnCoef cf, const T* __restr
         if (q >= rr && !has_bias) continue;
         double s = 0.0;
         for (int i = 0; i < steps; ++i)
-            s = fma(cf.c[i * npar + k], (double)dWeff[((int64_t)b * steps + i) * per + q], s);
+            if (cf.use[i * npar + k]) s = fma(cf.c[i * npar + k], (double)dWeff[((int64_t)b * steps + i) * per + q], s);
         if (q < rr) gradW[(int64_t)b * p + offWW + (int64_t)k * rr + q] = (T)s;
         else gradW[(int64_t)b * p + offBB + (int64_t)k * r + q - rr] = (T)s;
     }
@@ -825,24 +839,25 @@ int run_rnet(const qn_desc* d, const T* W, const T* X, const T* Y, const int32_t
     }
     RnCoef cf;
     for (int i = 0; i < S * d->rn_npar; ++i) cf.c[i] = d->rn_coef[i];
+    for (int i = 0; i < S * d->rn_npar; ++i) cf.use[i] = d->rn_uses[i];
     constexpr int JB = 8, TJ = 8, TK = 8, KB = 8;
     const int egrid = (int)((nact + BLK - 1) / BLK);
     auto base = [&]() {
         LayerArgs a;
         a.p = d->p; a.offW = 0; a.offB = 0; a.has_bias = d->has_bias; a.h_in = r; a.h_out = r; a.act = d->act;
-        a.Nb = Nb; a.first = 0; a.d = din; a.o = o;
+        a.Nb = Nb; a.first = 0; a.d = din; a.o = o; a.eye = 0;
         return a;
     };
     LayerArgs apre = base();     // x -> OUT_0
     apre.first = 1; apre.h_in = din;
     const T* Wpre = W;
     if (d->rn_pre) { apre.offW = d->rn_offWpre; apre.offB = d->rn_offBpre; apre.has_bias = 1; }
-    else { Wpre = eye; apre.p = 0; apre.has_bias = 0; apre.act = QN_ACT_IDENTITY; }
+    else { Wpre = eye; apre.p = 0; apre.has_bias = 0; apre.act = QN_ACT_IDENTITY; apre.eye = 1; }
     LayerArgs apost = base();    // OUT_S -> pred
     apost.h_out = o;
     const T* Wpost = W;
     if (d->rn_post) { apost.offW = d->rn_offWpost; apost.offB = d->rn_offBpost; apost.has_bias = 1; }
-    else { Wpost = eye; apost.p = 0; apost.has_bias = 0; }
+    else { Wpost = eye; apost.p = 0; apost.has_bias = 0; apost.eye = 1; }
     auto astep = [&](int i) {    // OUT_i -> TH_i on the expanded weights
         LayerArgs a = base();
         a.p = (int64_t)S * per; a.offW = (int64_t)i * per; a.offB = a.offW + r * r;

@@ -28,6 +28,7 @@ struct RnFusedArgs {
     int T;                          // threads per block (backward: also the stash stride)
     int nblk;                       // row blocks per chain (grid.x)
     double coef[QN_MAX_LAYERS * QN_MAX_LAYERS];
+    unsigned char use[QN_MAX_LAYERS * QN_MAX_LAYERS];   // tensor k enters step i (qn_common.h: rn_uses): others are skipped
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -61,11 +62,13 @@ __device__ __forceinline__ void stage(const RnFusedArgs& a, const double* __rest
         if (q < R * R) {
             const int j = q / R, k = q % R;
             if (j < r && k < r)
-                for (int m = 0; m < a.npar; ++m) s = fma(a.coef[i * a.npar + m], Wb[a.offWW + (int64_t)m * r * r + j * r + k], s);
+                for (int m = 0; m < a.npar; ++m)
+                    if (a.use[i * a.npar + m]) s = fma(a.coef[i * a.npar + m], Wb[a.offWW + (int64_t)m * r * r + j * r + k], s);
         } else if (a.has_bias) {
             const int j = q - R * R;
             if (j < r)
-                for (int m = 0; m < a.npar; ++m) s = fma(a.coef[i * a.npar + m], Wb[a.offBB + (int64_t)m * r + j], s);
+                for (int m = 0; m < a.npar; ++m)
+                    if (a.use[i * a.npar + m]) s = fma(a.coef[i * a.npar + m], Wb[a.offBB + (int64_t)m * r + j], s);
         }
         Weff[e] = s;
     }
@@ -381,14 +384,14 @@ __global__ __launch_bounds__(256) void k_rnet_grad_reduce(RnFusedArgs a, const d
             for (int i = 0; i < a.S; ++i) {
                 double si = 0.0;
                 for (int m = 0; m < a.nblk; ++m) si += sb[(int64_t)m * nimg + R * DOMAX + R + i * per + j * R + k];
-                s = fma(a.coef[i * a.npar + kpar], si, s);
+                if (a.use[i * a.npar + kpar]) s = fma(a.coef[i * a.npar + kpar], si, s);
             }
         } else if (a.has_bias && e >= a.offBB && e < a.offBB + (int64_t)a.npar * r) {
             const int q = (int)(e - a.offBB), kpar = q / r, j = q % r;
             for (int i = 0; i < a.S; ++i) {
                 double si = 0.0;
                 for (int m = 0; m < a.nblk; ++m) si += sb[(int64_t)m * nimg + R * DOMAX + R + i * per + R * R + j];
-                s = fma(a.coef[i * a.npar + kpar], si, s);
+                if (a.use[i * a.npar + kpar]) s = fma(a.coef[i * a.npar + kpar], si, s);
             }
         }
         gb[e] = s;
@@ -426,6 +429,7 @@ void fill_args(const qn_desc* d, int B, int N, int Nb, RnFusedArgs* a) {
     a->offWpre = d->rn_offWpre; a->offBpre = d->rn_offBpre; a->offWpost = d->rn_offWpost; a->offBpost = d->rn_offBpost;
     a->offWW = d->rn_offWW; a->offBB = d->rn_offBB;
     for (int i = 0; i < d->rn_steps * d->rn_npar; ++i) a->coef[i] = d->rn_coef[i];
+    for (int i = 0; i < d->rn_steps * d->rn_npar; ++i) a->use[i] = d->rn_uses[i];
 }
 
 int blocks_for(int B, int Nb, int T) {

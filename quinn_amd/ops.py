@@ -127,6 +127,7 @@ class RNetArch:
     layer_pre: bool = False
     layer_post: bool = False
     mlp: bool = False
+    uses: Tuple[Tuple[bool, ...], ...] = ()     # uses[i][k]: tensor k enters step i at all (default: every one does)
 
     @property
     def dims(self):
@@ -175,6 +176,9 @@ class RNetArch:
                                          _lib.ACT_CODES[self.activ], int(self.bias), int(self.layer_pre),
                                          int(self.layer_post), int(self.mlp), ctypes.byref(h)),
                    "qn_rnet_desc_create")
+        if self.uses:
+            u = [1 if v else 0 for row in self.uses for v in row]
+            _lib.check(L.qn_rnet_desc_set_uses(h, (ctypes.c_ubyte * len(u))(*u), len(u)), "qn_rnet_desc_set_uses")
         return h
 
     @staticmethod
@@ -191,10 +195,13 @@ class RNetArch:
             raise NotImplementedError("RNet final_layer is outside the MI355X hot path")
         wp = nnmodel.wp_function
         npar, nsteps = int(wp.npar), int(nnmodel.nlayers) + 1
-        coef = []
+        coef, uses = [], []
         for i in range(nsteps):
             t = nnmodel.step_size * i                                  # rnet.py:146
             row = []
+            # does tensor k enter the step at all?  A NaN there shows in the result if it does -- also through a zero
+            # coefficient (the polynomials multiply t^k out; NonPar picks one tensor and never touches the others)
+            uses.append(tuple(bool(np.isnan(float(wp([float('nan') if q == k else 0.0 for q in range(npar)], t)))) for k in range(npar)))
             for k in range(npar):
                 e = [1.0 if q == k else 0.0 for q in range(npar)]
                 c = float(wp(e, t))
@@ -209,7 +216,7 @@ class RNetArch:
             raise NotImplementedError(f"RNet activation {type(act).__name__}")
         return RNetArch(int(nnmodel.indim), int(nnmodel.rdim), int(nnmodel.outdim), nsteps, tuple(coef), activ,
                         bool(nnmodel.biasorno), bool(nnmodel.layer_pre), bool(nnmodel.layer_post),
-                        bool(nnmodel.mlp))
+                        bool(nnmodel.mlp), tuple(uses))
 
 
 def flatten_module(nnmodel):

@@ -231,8 +231,8 @@ def _run_exceptional(ncases, seed, verbose, paths):
             with np.errstate(invalid="ignore", over="ignore"):
                 for name, (u, v, tol) in got.items():
                     cu, cv = cls(u), cls(v)
-                    if name == "grad":      # an entry that is +-Inf in the reference may be NaN (0 . Inf of a masked row in the ragged tail)
-                        cu = np.where((cu == 3) & ((cv == 1) | (cv == 2)), cv, cu)
+                    if name == "grad":      # an entry that is +-Inf in the reference may be NaN here: the summation order of terms that
+                        cu = np.where((cu == 3) & ((cv == 1) | (cv == 2)), cv, cu)      # overflow is not the reference's
                     if not np.array_equal(cu, cv):
                         ok = False; why += " %s:class(%s: %d entries)" % (pname, name, int((cu != cv).sum()))
                         continue
