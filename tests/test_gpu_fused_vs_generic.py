@@ -299,3 +299,53 @@ def test_default_dispatch_equals_exact_layerwise_kernels(case):
         np.testing.assert_allclose(b[k], a[k], rtol=1e-11)
     assert np.abs(b[1] - a[1]).max() <= 1e-10 * max(np.abs(a[1]).max(), 1e-300)
     np.testing.assert_allclose(b[3], a[3], rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("dims,act,where,val", [
+    ((4, 33, 1), "tanh", "x", -np.inf),              # zero-padded twin (33 -> 64): padded units meet an infinite input
+    ((1, 8, 8, 1), "tanh", "x", np.inf),             # twin 8 -> 16
+    ((2, 100, 100, 1), "tanh", "x", np.inf),         # twin 100 -> 128 (int8-slice kernels)
+    ((3, 50, 50, 2), "relu", "w", 1e200),            # relu activations overflow on a twin
+    ((2, 64, 64, 1), "relu", "w", np.nan),           # relu(NaN) = NaN, not 0
+    ((2, 16, 16, 1), "relu", "w", np.inf),           # relu backward: a select, not a product with 0 / 1
+    ((1, 8, 8, 1), "identity", "w", -np.inf),        # ragged tail of an unbounded activation
+])
+def test_not_finite_values_on_twins_and_unbounded_activations_follow_torch(dims, act, where, val):
+    """Cases the randomised sweep (tests/fuzz_all.py: run_exceptional) found: NaN / +Inf / -Inf pattern of SSE and predictions
+    as the reference's torch ops, gradient finite in the same places (an entry that is +-Inf there may be NaN)."""
+    from oracle import mlp_ref
+    N, B = 45, 3
+    rs = np.random.RandomState(5)
+    x = rs.uniform(-1, 1, (N, dims[0])); y = rs.randn(N, dims[-1])
+    arch = MLPArch(dims, act)
+    W = 0.5 * rs.randn(B, arch.nparams) / np.sqrt(dims[1])
+    if where == "x":
+        x[7, 0] = val
+    else:
+        W[1, dims[0] * dims[1] + dims[1] + 5] = val                       # an entry of the second layer's matrix
+    op = BatchedMLP(arch, x, y)
+    mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, act))
+    cls = lambda v: np.where(np.isnan(v), 3, np.where(np.isposinf(v), 1, np.where(np.isneginf(v), 2, 0)))
+    with np.errstate(all="ignore"):
+        ref_s = np.array([mlp_ref.sse(mod, W[b], x, y) for b in range(B)])
+        ref_p = np.stack([mlp_ref.forward_flat(mod, W[b], x) for b in range(B)])
+        ref_g = np.stack([-2.0 * mlp_ref.logpostgrad(mod, W[b], x, [v for v in y], 1.0) for b in range(B)])
+    for path in (_lib.PATH_AUTO, _lib.PATH_GENERIC):
+        old = op.set_path(path)
+        try:
+            s, g = op.sse_grad(W)
+            s2, pr = op.sse_pred(W)
+        finally:
+            op.set_path(old)
+        s, g, s2, pr = (t.cpu().numpy() for t in (s, g, s2, pr))
+        assert np.array_equal(cls(s), cls(ref_s)) and np.array_equal(cls(s2), cls(ref_s))
+        assert np.array_equal(cls(pr.reshape(ref_p.shape)), cls(ref_p))
+        cg, cr = cls(g), cls(ref_g)
+        cg = np.where((cg == 3) & ((cr == 1) | (cr == 2)), cr, cg)
+        assert np.array_equal(cg, cr)
+        for b in range(B):
+            fin = np.isfinite(ref_g[b])
+            if fin.any():
+                assert np.abs(g[b][fin] - ref_g[b][fin]).max() <= 1e-9 * max(np.abs(ref_g[b][fin]).max(), 1e-300)
+            if np.isfinite(ref_s[b]):
+                np.testing.assert_allclose(s[b], ref_s[b], rtol=1e-11)

@@ -308,3 +308,55 @@ def test_device_engines_run_on_the_ex_ufit_network(sampler, sp):
     assert (np.asarray(r['accrate']) > 0.02).all()
     assert (r['logpost'][:, -100:].mean(axis=1) > r['logpost'][:, 0]).all()      # climbed from the random start
     assert solver.predict_ens(x, nens=5, nburn=100, chain=0).shape == (5, 14, 1)
+
+
+EXC = [  # spec, where the value goes, value
+    (RNetSpec(3, 0, "cubic", 0), "x", np.inf),                                           # no pre layer: out_0 = x (a copy, not I . x)
+    (RNetSpec(2, 0, "const", 0, 0, 4, layer_post=True), "x", -np.inf),
+    (RNetSpec(5, 2, "lin", 0), "x", np.inf),
+    (RNetSpec(8, 5, "nonpar", 3, mlp=True), "ww1", -np.inf),                             # NonPar: a tensor only enters its own steps
+    (RNetSpec(4, 15, "nonpar", 16, 5, 0, layer_pre=True), "ww9", np.nan),
+    (RNetSpec(4, 0, "quad", 0, 4, 0, bias=False, nonlin=False, layer_pre=True), "ww2", np.nan),   # t = 0: the reference multiplies ww_2 by 0
+    (RNetSpec(3, 2, "poly", 2, 0, 1, layer_post=True), "ww1", np.inf),
+]
+
+
+@pytest.mark.parametrize("case", EXC, ids=[f"r{c[0].rdim}L{c[0].nlayers}{c[0].wp_kind}_{c[1]}_{c[2]}" for c in EXC])
+def test_not_finite_values_follow_the_reference_ops(case):
+    """NaN / +Inf / -Inf pattern of SSE and predictions as torch's on both kernel families; gradient: finite entries in the
+    same places and equal (an entry that is +-Inf in the reference may be NaN: DESIGN 4.2).  Found by tests/fuzz_all.py."""
+    from quinn_amd import _lib
+    spec, where, val = case
+    rs = np.random.RandomState(7)
+    N, B = 37, 2
+    x = rs.uniform(-1, 1, (N, spec.d)); y = rs.randn(N, spec.o)
+    W = 0.3 * rs.randn(B, spec.nparams)
+    if where == "x":
+        x[5, 0] = val
+    else:                                                       # an entry of parameter tensor ww_k
+        k = int(where[2:])
+        off = sum(int(np.prod(s)) for s in spec.param_shapes()[:(2 if spec.layer_pre else 0) + (2 if spec.layer_post else 0) + k])
+        W[0, off + 1] = val
+    op = BatchedMLP(MLPArch.from_module(_net_from_spec(spec)), x, y)
+    mod = mlp_ref.build_module(spec)
+    cls = lambda v: np.where(np.isnan(v), 3, np.where(np.isposinf(v), 1, np.where(np.isneginf(v), 2, 0)))
+    with np.errstate(all="ignore"):
+        ref_s = np.array([mlp_ref.sse(mod, W[b], x, y) for b in range(B)])
+        ref_p = np.stack([mlp_ref.forward_flat(mod, W[b], x) for b in range(B)])
+        ref_g = np.stack([-2.0 * mlp_ref.logpostgrad(mod, W[b], x, [v for v in y], 1.0) for b in range(B)])
+    for path in (_lib.PATH_AUTO, _lib.PATH_GENERIC):
+        op.set_path(path)
+        s, g = op.sse_grad(W)
+        s2, pr = op.sse_pred(W)
+        s, g, s2, pr = (t.cpu().numpy() for t in (s, g, s2, pr))
+        assert np.array_equal(cls(s), cls(ref_s)) and np.array_equal(cls(s2), cls(ref_s))
+        assert np.array_equal(cls(pr.reshape(ref_p.shape)), cls(ref_p))
+        cg, cr = cls(g), cls(ref_g)
+        cg = np.where((cg == 3) & ((cr == 1) | (cr == 2)), cr, cg)
+        assert np.array_equal(cg, cr)
+        fin = np.isfinite(ref_g)
+        for b in range(B):
+            if fin[b].any():
+                assert np.abs(g[b][fin[b]] - ref_g[b][fin[b]]).max() <= 1e-9 * max(np.abs(ref_g[b][fin[b]]).max(), 1e-300)
+        fp = np.isfinite(ref_p)
+        np.testing.assert_allclose(pr.reshape(ref_p.shape)[fp], ref_p[fp], rtol=1e-10, atol=1e-12)
