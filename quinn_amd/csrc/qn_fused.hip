@@ -587,7 +587,9 @@ __device__ __forceinline__ void act_tile(const v4d& z, double (&out)[4], int act
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int H, int NH, int DP>
+// UNB: the activation is unbounded (relu / identity): the masked rows of a ragged tail are zeroed outright (below).  A
+// template parameter, not a test of the runtime activation: the test alone cost the tanh instance 3.8 % (tools/ab_grad_mask.sh).
+template <int H, int NH, int DP, bool UNB>
 __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const double* __restrict__ W,
                                                          const double* __restrict__ X, const double* __restrict__ Y,
                                                          const int32_t* __restrict__ row_idx,
@@ -671,8 +673,8 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
         // relu / identity activations are unbounded: the masked rows of a ragged tail (they re-run row 0 with a zero
         // residual) must contribute 0 . 0, not 0 . Inf = NaN, so their inputs, activations and dz are zeroed outright
         // (tanh: activations are bounded and the zero residual is enough)
-        const bool maskrow = act_kind != QN_ACT_TANH && !valid;
-        if (maskrow) {
+        const bool maskrow = UNB && !valid;
+        if (UNB && maskrow) {
 #pragma unroll
             for (int k = 0; k < DP; ++k) xk[k] = 0.0;
         }
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
                 for (int k = 0; k < DP; ++k) z[i] = fma(lds[offW0 + j * DP + k], xk[k], z[i]);
             }
             act_tile(z, act[0][t], act_kind, nan_possible, tanh_tab);
-            if (maskrow) {
+            if (UNB && maskrow) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) act[0][t][i] = 0.0;
             }
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     act_tile(acc[t], act[layer][t], act_kind, nan_possible, tanh_tab);
-                    if (maskrow) {
+                    if (UNB && maskrow) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) act[layer][t][i] = 0.0;
                     }
@@ -819,7 +821,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dz[t][i] = maskrow ? 0.0 : qn_act_bwd<double>(dz[t][i], alast[t][i], act_kind);
+            for (int i = 0; i < 4; ++i) dz[t][i] = (UNB && maskrow) ? 0.0 : qn_act_bwd<double>(dz[t][i], alast[t][i], act_kind);
         QN_STAMP(5);                                       // 5: last-stage column sums + dz_NH
         // ------------------------------------------------------------------ backward: hidden -> hidden layers
 #pragma unroll
@@ -917,7 +919,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
                 for (int t = 0; t < T; ++t)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dz[t][i] = maskrow ? 0.0 : qn_act_bwd<double>(nd[t][i], act[layer - 1][t][i], act_kind);
+                    for (int i = 0; i < 4; ++i) dz[t][i] = (UNB && maskrow) ? 0.0 : qn_act_bwd<double>(nd[t][i], act[layer - 1][t][i], act_kind);
                 QN_STAMP(9);                               // 9: dA MFMAs + dz
             }
         }
@@ -1176,8 +1178,8 @@ fwd_fn pick_fwd(int H, int act, int dp, int o) {
     return nullptr;
 }
 
-bwd_fn pick_bwd(int H, int nhid) {
-#define QN_PICK(HH, NN) if (H == HH && nhid == NN) return k_fused_bwd_f64<HH, NN, 4>;
+bwd_fn pick_bwd(int H, int nhid, int act = QN_ACT_TANH) {
+#define QN_PICK(HH, NN) if (H == HH && nhid == NN) return act == QN_ACT_TANH ? k_fused_bwd_f64<HH, NN, 4, false> : k_fused_bwd_f64<HH, NN, 4, true>;
     QN_PICK(16, 1) QN_PICK(16, 2) QN_PICK(16, 3) QN_PICK(16, 4)
     QN_PICK(32, 1) QN_PICK(32, 2) QN_PICK(32, 3) QN_PICK(32, 4)
     QN_PICK(64, 1) QN_PICK(64, 2) QN_PICK(64, 3)
@@ -1270,7 +1272,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
         hipLaunchKernelGGL(kern, grid, dim3(H == HS ? NTS : WG), lds_bytes, st, a, (const double*)W,
                            (const double*)X, (const double*)Y, row_idx, (double*)pred, partial);
     } else {
-        bwd_fn kern = pick_bwd(H, nhid);
+        bwd_fn kern = pick_bwd(H, nhid, d->act);
         if (!kern) {
             qn_set_error("qn_fused_run: no backward kernel instance for H=%d nhid=%d", H, nhid);
             return QN_EUNSUPPORTED;
