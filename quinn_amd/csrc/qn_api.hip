@@ -174,7 +174,7 @@ static bool use_fused(const qn_desc* d, int B, int Nb, int want_grad, int dtype)
     if (d->path == QN_PATH_GENERIC || prefer_wide(d, want_grad, dtype)) return false;
     return fused_ok(d, B, Nb, want_grad, dtype);
 }
-// head of the workspace of a run on the zero-padded twin: padded weights (+ padded gradient) | flags [B + 1] | scratch of the
+// head of the workspace of a run on the zero-padded twin: padded weights (+ padded gradient) | flags [B + 1][64] | scratch of the
 // exceptional-value fix-up (k_padded_fixup below): per chain every layer's outputs + two dz vectors
 static size_t padded_fixup_doubles(const qn_desc* d) {
     size_t sum = 0, hmax = 0;
@@ -185,7 +185,7 @@ static size_t padded_fixup_doubles(const qn_desc* d) {
     return sum + 2 * hmax;
 }
 static size_t padded_head_bytes(const qn_desc* d, int B, int want_grad, size_t el) {
-    return (want_grad ? 2 : 1) * qn_align((size_t)B * d->padded->p * el) + qn_align((size_t)(B + 1) * sizeof(int)) +
+    return (want_grad ? 2 : 1) * qn_align((size_t)B * d->padded->p * el) + qn_align((size_t)(B + 1) * 64 * sizeof(int)) +
            qn_align((size_t)B * padded_fixup_doubles(d) * el);
 }
 static size_t fused_ws(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
@@ -220,19 +220,23 @@ struct PadMap {
 // (blockIdx.y == 0) every input against 2^ebound, chosen so that below it no intermediate value can overflow; flagged chains
 // (flags[b]; flags[B] = an input: every chain) are recomputed from the ORIGINAL weights by k_padded_fixup after the twin's
 // kernels.  Found by tests/fuzz_all.py (x = -inf on a 33-wide network: the reference saturates, the twin returned NaN).
+constexpr int PAD_SLOTS = 64;           // blocks per chain of k_pad_weights at most (one flag slot each)
 template <typename T> __device__ __forceinline__ bool pad_bounded(T v, T bound) { return (v < T(0) ? -v : v) < bound; }   // (NaN: false)
 template <typename T> __global__ void k_pad_weights(PadMap m, const T* __restrict__ W, T* __restrict__ Wp, const T* __restrict__ X,
                                                     int64_t nx, T bound, int* __restrict__ flags) {
+    // every block WRITES its own slot flags[(chain or B) * PAD_SLOTS + blockIdx.x] (no atomics, no memset node ahead of the kernel)
     const int b = blockIdx.y;
     int bad = 0;
     if (b == 0) {
         int xb = 0;
         for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nx; e += (int64_t)gridDim.x * blockDim.x) xb |= !pad_bounded(X[e], bound);
-        if (xb) atomicOr(&flags[gridDim.y], 1);
+        xb = __syncthreads_or(xb);
+        if (threadIdx.x == 0) flags[(int64_t)gridDim.y * PAD_SLOTS + blockIdx.x] = xb;
     }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m.p; e += (int64_t)gridDim.x * blockDim.x)
         bad |= !pad_bounded(W[(int64_t)b * m.p + e], bound);
-    if (bad) atomicOr(&flags[b], 1);
+    bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) flags[(int64_t)b * PAD_SLOTS + blockIdx.x] = bad;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m.pp; e += (int64_t)gridDim.x * blockDim.x) {
         int l = 0;
         while (l + 1 < m.L && e >= m.offp[l + 1]) ++l;
@@ -262,10 +266,12 @@ __device__ __forceinline__ float fix_tanh(float z) { return qn_tanh_f32(z); }
 template <typename T>
 __global__ __launch_bounds__(256) void k_padded_fixup(FixNet s, const T* __restrict__ W, const T* __restrict__ X, const T* __restrict__ Y,
                                                       const int32_t* __restrict__ row_idx, int Nb, const int* __restrict__ flags,
-                                                      double* __restrict__ sse, T* __restrict__ pred, T* __restrict__ grad,
+                                                      int nslots, double* __restrict__ sse, T* __restrict__ pred, T* __restrict__ grad,
                                                       T* __restrict__ scratch) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (!(flags[b] | flags[gridDim.x])) return;
+    int any = 0;
+    if (tid < nslots) any = flags[(int64_t)b * PAD_SLOTS + tid] | flags[(int64_t)gridDim.x * PAD_SLOTS + tid];
+    if (!__syncthreads_or(any)) return;
     const T* Wb = W + (int64_t)b * s.p;
     T* act = scratch + (int64_t)b * s.per_chain;
     T* dzbuf[2] = {act + s.dzo, act + s.dzo + s.hmax};
@@ -362,7 +368,7 @@ int run_padded_t(const qn_desc* d, bool generic, int dtype, const T* W, const vo
     T* Wp = static_cast<T*>(ws);
     T* Gp = gradW ? reinterpret_cast<T*>(static_cast<char*>(ws) + wbytes) : nullptr;
     int* flags = reinterpret_cast<int*>(static_cast<char*>(ws) + (gradW ? 2 : 1) * wbytes);
-    T* fix_scratch = reinterpret_cast<T*>(reinterpret_cast<char*>(flags) + qn_align((size_t)(B + 1) * sizeof(int)));
+    T* fix_scratch = reinterpret_cast<T*>(reinterpret_cast<char*>(flags) + qn_align((size_t)(B + 1) * 64 * sizeof(int)));
     const PadMap m = pad_map(d);
     // 2^e below which no product chain of the network can overflow (tanh: only x . W0; otherwise one factor per layer and up
     // to 2^11 terms per sum)
@@ -370,9 +376,9 @@ int run_padded_t(const qn_desc* d, bool generic, int dtype, const T* W, const vo
     int eb = d->act == QN_ACT_TANH ? emax / 2 - 12 : (emax - 11 * L) / (L + 1);
     eb = eb < 1 ? 1 : eb;
     (void)hipGetLastError();
-    QN_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)(B + 1) * sizeof(int), st));
     int gx = (int)((q->p + 255) / 256);
-    hipLaunchKernelGGL(k_pad_weights<T>, dim3(gx > 64 ? 64 : gx, B), dim3(256), 0, st, m, W, Wp, static_cast<const T*>(X),
+    const int nslots = gx > PAD_SLOTS ? PAD_SLOTS : gx;
+    hipLaunchKernelGGL(k_pad_weights<T>, dim3(nslots, B), dim3(256), 0, st, m, W, Wp, static_cast<const T*>(X),
                        (int64_t)N * d->dims[0], (T)std::ldexp(1.0, eb), flags);
     const int rc = generic ? qn_generic_run(q, dtype, Wp, X, Y, row_idx, B, N, Nb, sse, pred, Gp,
                                             static_cast<char*>(ws) + head, ws_bytes - head, st)
@@ -395,7 +401,7 @@ int run_padded_t(const qn_desc* d, bool generic, int dtype, const T* W, const vo
         }
         f.dzo = off; f.hmax = hmax; f.per_chain = (int)padded_fixup_doubles(d);
         hipLaunchKernelGGL(k_padded_fixup<T>, dim3(B), dim3(256), 0, st, f, W, static_cast<const T*>(X), static_cast<const T*>(Y),
-                           row_idx, Nb, (const int*)flags, sse, static_cast<T*>(pred), gradW, fix_scratch);
+                           row_idx, Nb, (const int*)flags, nslots, sse, static_cast<T*>(pred), gradW, fix_scratch);
     }
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
