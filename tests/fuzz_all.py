@@ -11,6 +11,19 @@ from quinn_amd.ops import MLPArch, BatchedMLP
 PATHS = {_lib.PATH_GENERIC: "generic", _lib.PATH_FUSED: "fused", _lib.PATH_FUSED_DP: "fused_dp"}
 
 
+def _sensitivity(mod, w, xb, yb, rs):
+    """How much the oracle's own SSE / gradient / predictions move when every weight changes by one unit in the last place
+    (relative, max norm): the floor below which two correct float64 implementations cannot be told apart.  Deep saturated
+    networks amplify rounding by 1e6 and more; the bars of the sweeps are max(stated bar, 20 x this)."""
+    w2 = w * (1.0 + 2.0 ** -52 * rs.choice([-1.0, 1.0], size=w.shape))
+    with np.errstate(all="ignore"):
+        s0, s1 = mlp_ref.sse(mod, w, xb, yb), mlp_ref.sse(mod, w2, xb, yb)
+        p0, p1 = mlp_ref.forward_flat(mod, w, xb), mlp_ref.forward_flat(mod, w2, xb)
+        g0 = mlp_ref.logpostgrad(mod, w, xb, [v for v in yb], 1.0); g1 = mlp_ref.logpostgrad(mod, w2, xb, [v for v in yb], 1.0)
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(a).max(), 1e-300))
+    return abs(s1 / s0 - 1) if s0 else 0.0, rel(g0, g1), rel(p0, p1)
+
+
 def run(ncases=100, seed=0, verbose=True):
     """Returns (number of failed cases, worst [sse, grad, pred] errors)."""
     rs = np.random.RandomState(seed)
@@ -44,18 +57,19 @@ def run(ncases=100, seed=0, verbose=True):
         Nb = N if idx is None else idx.shape[1]
         pth = PATHS.get(op.path(B, Nb, True), "?") + "/" + PATHS.get(op.path(B, Nb, False), "?")
         mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, act, bias))
-        e = [0.0, 0.0, 0.0]
+        e = [0.0, 0.0, 0.0]; sens = [0.0, 0.0, 0.0]
         for b in range(B):
             xb, yb = (x, y) if idx is None else (x[idx[b]], y[idx[b]])
+            if b == 0: sens = _sensitivity(mod, W[b], xb, yb, rs)
             sref = mlp_ref.sse(mod, W[b], xb, yb)
             pref = mlp_ref.forward_flat(mod, W[b], xb)
             gref = -2.0 * mlp_ref.logpostgrad(mod, W[b], xb, [v for v in yb], 1.0)          # dSSE/dw
             e[0] = max(e[0], abs(s[b] / sref - 1), abs(s2[b] / sref - 1))
             e[1] = max(e[1], np.abs(g[b] - gref).max() / max(np.abs(gref).max(), 1e-300))
             e[2] = max(e[2], np.abs(pr[b].reshape(pref.shape) - pref).max() / max(np.abs(pref).max(), 1e-300))
-        f = 10.0 if wscale >= 3 else 1.0
         ts, tg = (1e-11, 1e-10) if dtype == "float64" else (2e-4, 2e-3)      # (float32: the bars of tests/test_gpu_rnet_parity.py)
-        ok = e[0] <= ts * f and e[1] <= tg * f and e[2] <= (ts if dtype == "float64" else tg) * f
+        K = 2000        # (the int8-slice kernels round operands to 47 bits: ~64 units in the last place; x 30 headroom)
+        ok = e[0] <= max(ts, K * sens[0]) and e[1] <= max(tg, K * sens[1]) and e[2] <= max(ts if dtype == "float64" else tg, K * sens[2])
         nfail += not ok
         if dtype == "float64": worst = [max(u, v) for u, v in zip(worst, e)]
         if verbose or not ok:
@@ -105,17 +119,17 @@ def run_rnet(ncases=60, seed=0, verbose=True):
             s, g = op.sse_grad(W, row_idx=idx); s2, pr = op.sse_pred(W, row_idx=idx)
             s, g, s2, pr = (t.double().cpu().numpy() for t in (s, g, s2, pr))
             mod = mlp_ref.build_module(spec)
-            e = [0.0, 0.0, 0.0]
+            e = [0.0, 0.0, 0.0]; sens = [0.0, 0.0, 0.0]
             for b in range(B):
                 xb, yb = (x, y) if idx is None else (x[idx[b]], y[idx[b]])
+                if b == 0: sens = _sensitivity(mod, W[b], xb, yb, rs)
                 sref = mlp_ref.sse(mod, W[b], xb, yb)
                 pref = mlp_ref.forward_flat(mod, W[b], xb)
                 gref = -2.0 * mlp_ref.logpostgrad(mod, W[b], xb, [v for v in yb], 1.0)
                 e[0] = max(e[0], abs(s[b] / sref - 1), abs(s2[b] / sref - 1))
                 e[1] = max(e[1], np.abs(g[b] - gref).max() / max(np.abs(gref).max(), 1e-300))
                 e[2] = max(e[2], np.abs(pr[b].reshape(pref.shape) - pref).max() / max(np.abs(pref).max(), 1e-300))
-            f = 10.0 if wscale >= 1.0 else 1.0          # (up to 16 saturated layers amplify the float64 kernels' own rounding differences)
-            ok = e[0] <= 1e-11 * f and e[1] <= 1e-10 * f and e[2] <= 1e-11 * f
+            ok = e[0] <= max(1e-11, 20 * sens[0]) and e[1] <= max(1e-10, 20 * sens[1]) and e[2] <= max(1e-11, 20 * sens[2])
             nfail += not ok
             worst = [max(u, v) for u, v in zip(worst, e)]
             Nb = N if idx is None else idx.shape[1]
