@@ -58,6 +58,15 @@ def test_residual_network_descriptor(L):
     assert L.qn_rnet_desc_create(1, 3, 1, 4, 2, coef, 1, 1, 1, 1, 0, ctypes.byref(h)) == 0
     assert L.qn_mlp_num_params(h) == 3 + 3 + 3 + 1 + 2 * 9 + 2 * 3
     assert L.qn_workspace_bytes(h, 4, 13, 1, 0) > 0
+    # which tensors enter a step: 8 entries; one marked unused must have coefficient 0 (entry 1 has, entry 3 has not)
+    ub = ctypes.c_ubyte * 8
+    assert L.qn_rnet_desc_set_uses(h, ub(1, 0, 1, 1, 1, 1, 1, 1), 8) == 0
+    assert L.qn_rnet_desc_set_uses(h, ub(1, 1, 1, 0, 1, 1, 1, 1), 8) == EINVAL
+    assert L.qn_rnet_desc_set_uses(h, ub(1, 1, 1, 1, 1, 1, 1, 1), 7) == EINVAL
+    assert L.qn_rnet_desc_set_uses(h, None, 8) == EINVAL and L.qn_rnet_desc_set_uses(None, ub(), 8) == EINVAL
+    m = _desc(L, (1, 4, 1))
+    assert L.qn_rnet_desc_set_uses(m, ub(1, 1, 1, 1, 1, 1, 1, 1), 8) == EINVAL                    # not a residual network
+    assert L.qn_mlp_desc_destroy(m) == 0
     assert L.qn_mlp_desc_destroy(h) == 0
     assert L.qn_rnet_desc_create(1, 3, 1, 0, 2, coef, 1, 1, 1, 1, 0, ctypes.byref(h)) != 0        # no steps
     assert L.qn_rnet_desc_create(2, 3, 1, 4, 2, coef, 1, 1, 0, 1, 0, ctypes.byref(h)) != 0        # no pre layer but indim != rdim
