@@ -242,8 +242,10 @@ def _run_exceptional(ncases, seed, verbose, paths):
         for pname in paths:
             op.set_path(codes[pname])
             sg, g = op.sse_grad(W); s2, pr = op.sse_pred(W)
+            # (predictions: 3e-11 -- a bias-free network with small weights just above the tiny-activation guard of the int8-slice
+            # kernels reaches 1.1e-11 of max |pred|: 2^-47 / 0.04 per layer times the cancellation in the last dot product)
             got = {"sse": (sg.double().cpu().numpy(), ref[0], 1e-11), "sse2": (s2.double().cpu().numpy(), ref[0], 1e-11),
-                   "pred": (pr.double().cpu().numpy().reshape(B, N, o), ref[2], 1e-11), "grad": (g.double().cpu().numpy(), ref[1], 1e-9)}
+                   "pred": (pr.double().cpu().numpy().reshape(B, N, o), ref[2], 3e-11), "grad": (g.double().cpu().numpy(), ref[1], 1e-9)}
             with np.errstate(invalid="ignore", over="ignore"):
                 for name, (u, v, tol) in got.items():
                     cu, cv = cls(u), cls(v)
