@@ -97,7 +97,7 @@ def _random_rnet(rs):
                  nonlin=spec.nonlin, mlp=spec.mlp, layer_pre=spec.layer_pre, layer_post=spec.layer_post)
     arch = MLPArch.from_module(net)
     assert arch.nparams == spec.nparams
-    return spec, arch
+    return spec, arch, net
 
 
 def run_rnet(ncases=60, seed=0, verbose=True):
@@ -109,7 +109,7 @@ def run_rnet(ncases=60, seed=0, verbose=True):
     worst = [0.0, 0.0, 0.0]; nfail = 0
     try:
         for case in range(ncases):
-            spec, arch = _random_rnet(rs)
+            spec, arch, _ = _random_rnet(rs)
             N = int(rs.choice([rs.randint(1, 40), rs.randint(40, 600)])); B = int(rs.choice([1, 2, rs.randint(3, 40)]))
             x = rs.uniform(-2, 2, (N, spec.d)); y = rs.randn(N, spec.o)
             wscale = float(rs.choice([0.05, 0.4, 1.0]))
@@ -166,6 +166,14 @@ def run_mcmc(ncases=12, seed=0, verbose=True):
             spec = mlp_ref.MLPSpec(dims, act)
             if spec.nparams > (500 if sampler == "amcmc" else 3000):      # (the reference's proposal is an SVD of p x p per step)
                 hid = hid[:1]; dims = (d,) + hid + (o,); spec = mlp_ref.MLPSpec(dims, act)
+            net = None
+            if rs.rand() < 0.3:                                            # a residual network (the model of examples/ex_ufit.py)
+                for _ in range(20):
+                    rspec, _, rnet_ = _random_rnet(rs)
+                    if rspec.nparams <= 400: break
+                if rspec.nparams <= 400:
+                    spec, net, d, o, dims, act = rspec, rnet_, rspec.d, rspec.o, rspec, rspec.activ
+                    x = rs.rand(N, d) * 4 - 2; y = np.sin(x.sum(axis=1, keepdims=True)) * np.ones((1, o)) + sigma * rs.randn(N, o)
             yd = [v for v in y]
             if sampler == "amcmc":
                 sp = {'gamma': float(rs.choice([0.01, 0.1, 0.5])), 't0': int(rs.randint(3, 40)), 'tadapt': int(rs.randint(2, 30))}
@@ -181,7 +189,7 @@ def run_mcmc(ncases=12, seed=0, verbose=True):
                 mods.append(mlp_ref.build_module(spec)); return mods[-1]
             ref = mcmc_ref.run_multichain(lambda: (lambda w, m=mkmod(): mlp_ref.logpost(m, w, x, yd, sigma)), mk, nmcmc, spec.nparams, seeds,
                                           make_logpostgrad=None if sampler == "amcmc" else (lambda: (lambda w, m=mkmod(): mlp_ref.logpostgrad(m, w, x, yd, sigma))))
-            solver = NN_MCMC(MLP(d, o, hid, activ=act), verbose=False)
+            solver = NN_MCMC(net if net is not None else MLP(d, o, hid, activ=act), verbose=False)
             solver.fit(x, y, zflag=False, datanoise=sigma, nmcmc=nmcmc, sampler=sampler, sampler_params=dict(sp), seeds=seeds)
             chain = np.asarray(solver.samples).reshape(C, nmcmc + 1, -1)
             acc = (chain[:, 1:] != chain[:, :-1]).any(axis=2)
@@ -215,7 +223,7 @@ def _run_exceptional(ncases, seed, verbose, paths):
     for case in range(ncases):
         N = int(rs.randint(1, 400)); B = int(rs.randint(1, 6))
         if rs.rand() < 0.25:
-            spec, arch = _random_rnet(rs)
+            spec, arch, _ = _random_rnet(rs)
             dims, act, bias, d, o, h = spec, spec.activ, spec.bias, spec.d, spec.o, spec.rdim
         else:
             h = int(rs.choice([8, 33, 64, 64, 128, 256])); nhid = int(rs.randint(1, 5)); d = int(rs.choice([1, 2, 4, 6])); o = int(rs.choice([1, 1, 2]))
