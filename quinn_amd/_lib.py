@@ -29,22 +29,41 @@ class QuinnAmdError(RuntimeError):
     pass
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, jobs=None):
     """Compile the HIP sources for gfx950 into quinn_amd/lib/libquinn_amd.so (hipcc
-    cross-compiles without a GPU)."""
+    cross-compiles without a GPU).  One object per source under quinn_amd/lib/obj/, compiled in
+    parallel and only when the source or a header is newer than its object; then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "qn_common.h"), os.path.join(CSRC, "qn_math.h"), os.path.join(CSRC, "qn_tanh_table.h"), os.path.join(CSRC, "qn_tanh_table64.h"), os.path.join(CSRC, "qn_fused_args.h"), os.path.join(CSRC, "qn_i8_slice.h"), os.path.join(_HERE, "..", "include", "quinn_amd.h")]
+    hdrs = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + \
+           [os.path.join(_HERE, "..", "include", "quinn_amd.h")]
+    hnew = max(os.path.getmtime(h) for h in hdrs)
     if not force and os.path.exists(LIBPATH):
-        if os.path.getmtime(LIBPATH) >= max(os.path.getmtime(d) for d in deps):
+        if os.path.getmtime(LIBPATH) >= max(hnew, max(os.path.getmtime(s) for s in srcs)):
             return LIBPATH
-    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has one unified register file);
     # without it hipcc copies every loop-carried accumulator VGPR<->AGPR per iteration (25 % of the GEMM loop)
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC", "-shared",
-           "-o", LIBPATH] + srcs
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC"]
+    extra = os.environ.get("QN_HIPCC_FLAGS", "").split()          # A/B builds (-DQN_...)
+
+    def one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        if not force and not extra and os.path.exists(obj) and os.path.getmtime(obj) >= max(hnew, os.path.getmtime(src)):
+            return obj
+        cmd = [hipcc] + flags + extra + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIBPATH] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return LIBPATH
 
