@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libquinn_amd.so")
-SOURCES = ["qn_api.hip", "qn_generic.hip", "qn_fused.hip", "qn_fused_i8.hip", "qn_wide_i8.hip", "qn_dw_i8.hip", "qn_mcmc.hip", "qn_rnet.hip"]
+SOURCES = ["qn_api.hip", "qn_generic.hip", "qn_fused.hip", "qn_fused_i8.hip", "qn_fused_bwd_i8.hip", "qn_wide_i8.hip", "qn_dw_i8.hip", "qn_mcmc.hip", "qn_rnet.hip"]
 
 QN_F64, QN_F32 = 0, 1
 ACT_CODES = {"identity": 0, "tanh": 1, "relu": 2}

@@ -594,7 +594,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
                                                          const double* __restrict__ X, const double* __restrict__ Y,
                                                          const int32_t* __restrict__ row_idx,
                                                          double* __restrict__ pred_out, double* __restrict__ partial,
-                                                         double* __restrict__ slab) {
+                                                         double* __restrict__ slab, const int* __restrict__ only_flagged) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     constexpr int T = H / 16;
@@ -605,6 +605,12 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
     constexpr int RPT = ROWS_IT / TPF;           // rows per such thread
     int b, split;
     if (!qn_fused_wg(a.nsplit, a.B, &b, &split)) return;
+    if (only_flagged) {
+        // second pass behind k_fused_bwd_i8 (qn_fused_bwd_i8.hip): only chains with a (chain, split) that left its fast path
+        int any = 0;
+        for (int k = 0; k < a.nsplit; ++k) any |= only_flagged[b * a.nsplit + k];
+        if (!any) return;
+    }
     const int d = a.d, o = a.o, act_kind = a.act;
     const int nb = a.has_bias ? 1 : 0;
     const int offW0 = 0, offb0 = H * DP, offHH = offb0 + H;
@@ -1069,10 +1075,17 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
     }
 }
 
-// gradW[b][e] = sum over the nsplit slabs, fixed order
+// gradW[b][e] = sum over the nsplit slabs, fixed order; block (0, b) also adds up the chain's SSE partials (left to right, as
+// k_sum_partials does: one launch fewer per gradient evaluation)
 __global__ __launch_bounds__(256) void k_grad_reduce(const double* __restrict__ slab, int nsplit, int64_t p, int B,
-                                                     double* __restrict__ gradW) {
+                                                     double* __restrict__ gradW, const double* __restrict__ partial,
+                                                     double* __restrict__ sse) {
     const int b = blockIdx.y;
+    if (partial && blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nsplit; ++i) s += partial[(int64_t)b * nsplit + i];
+        sse[b] = s;
+    }
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < p; e += (int64_t)gridDim.x * 256) {
         double sacc = 0.0;
         for (int k = 0; k < nsplit; ++k) sacc += slab[((int64_t)b * nsplit + k) * p + e];
@@ -1110,6 +1123,13 @@ bool uses_i8(const qn_desc* d, int want_grad) {
            qn_fused_i8_applies(H, nhid, d->act, d->dims[0], d->dims[d->nlayers]);
 }
 
+// the gradient of 64-wide tanh networks likewise (qn_fused_bwd_i8.hip), with the float64 kernel behind it for flagged chains
+bool uses_i8_bwd(const qn_desc* d) {
+    int H, nhid;
+    return d->path != QN_PATH_FUSED_DP && uniform_hidden(d, &H, &nhid) &&
+           qn_fused_bwd_i8_applies(H, nhid, d->act, d->dims[0], d->dims[d->nlayers]);
+}
+
 void plan(const qn_desc* d, int B, int Nb, int want_grad, FusedArgs* a) {
     // rows one workgroup covers per iteration; target workgroups per chip: 2/CU forward, 1/CU backward
     // (and streaming forward: its 128 KB matrix buffer leaves room for one workgroup per CU)
@@ -1143,7 +1163,7 @@ size_t lds_need(int H, int d, int o, int nhid, int want_grad) {
 
 using fwd_fn = qn_fwd_fn;
 using bwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*,
-                        double*);
+                        double*, const int*);
 
 // Forward geometry: 4 waves x 2 row groups per workgroup (2 workgroups / CU, 2 waves / SIMD).  The
 // alternative 8 waves x 1 row group (4 waves / SIMD, same 128 rows per iteration) measured 3.5 % slower
@@ -1223,7 +1243,7 @@ size_t qn_fused_workspace(const qn_desc* d, int B, int Nb, int want_grad, int dt
     FusedArgs a;
     plan(d, B, Nb, want_grad, &a);
     size_t tot = qn_align((size_t)B * a.nsplit * sizeof(double));
-    if (want_grad) tot += qn_align((size_t)B * a.nsplit * d->p * sizeof(double));
+    if (want_grad) tot += qn_align((size_t)B * a.nsplit * d->p * sizeof(double)) + qn_align((size_t)B * a.nsplit * sizeof(int));
     return tot + 256;
 }
 
@@ -1247,7 +1267,8 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
     a.act = d->act; a.has_bias = d->has_bias;
     plan(d, B, Nb, want_grad, &a);
     const size_t npart = qn_align((size_t)B * a.nsplit * sizeof(double));
-    const size_t need = npart + (want_grad ? qn_align((size_t)B * a.nsplit * d->p * sizeof(double)) : 0);
+    const size_t nslab = want_grad ? qn_align((size_t)B * a.nsplit * d->p * sizeof(double)) : 0;
+    const size_t need = npart + nslab + (want_grad ? qn_align((size_t)B * a.nsplit * sizeof(int)) : 0);
     if (need > ws_bytes) {
         qn_set_error("workspace too small: need %zu bytes, got %zu", need, ws_bytes);
         return QN_EWORKSPACE;
@@ -1278,13 +1299,25 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
             return QN_EUNSUPPORTED;
         }
         if (int rc = arm_lds(reinterpret_cast<const void*>(kern))) return rc;
+        const int* flagged = nullptr;
+        if (uses_i8_bwd(d)) {
+            // sliced int8 products (qn_fused_bwd_i8.hip); (chain, split)s outside its contract are flagged and their chains
+            // recomputed by the float64 kernel right behind it (which returns at once for every other chain)
+            int* flags = reinterpret_cast<int*>(static_cast<char*>(ws) + npart + nslab);
+            qn_bwd_i8_fn k8 = qn_fused_bwd_i8_kernel(nhid);
+            if (int rc = arm_lds(reinterpret_cast<const void*>(k8))) return rc;
+            hipLaunchKernelGGL(k8, grid, dim3(WG), qn_fused_bwd_i8_lds_bytes(nhid), st, a, (const double*)W, (const double*)X,
+                               (const double*)Y, row_idx, (double*)pred, partial, slab, flags);
+            flagged = flags;
+        }
         hipLaunchKernelGGL(kern, grid, dim3(WG), lds_bytes, st, a, (const double*)W, (const double*)X,
-                           (const double*)Y, row_idx, (double*)pred, partial, slab);
+                           (const double*)Y, row_idx, (double*)pred, partial, slab, flagged);
         int gx = (int)((d->p + 255) / 256);
         if (gx > 64) gx = 64;
-        hipLaunchKernelGGL(k_grad_reduce, dim3(gx, B), dim3(256), 0, st, slab, a.nsplit, d->p, B, (double*)gradW);
+        hipLaunchKernelGGL(k_grad_reduce, dim3(gx, B), dim3(256), 0, st, slab, a.nsplit, d->p, B, (double*)gradW,
+                           (const double*)partial, sse);
     }
-    if (partial != sse) hipLaunchKernelGGL(k_sum_partials, dim3((B + 63) / 64), dim3(64), 0, st, partial, a.nsplit, B, sse);
+    if (!want_grad && partial != sse) hipLaunchKernelGGL(k_sum_partials, dim3((B + 63) / 64), dim3(64), 0, st, partial, a.nsplit, B, sse);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }

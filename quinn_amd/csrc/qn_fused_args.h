@@ -33,6 +33,14 @@ bool qn_fused_i8_applies(int H, int nhid, int act, int d, int o);
 size_t qn_fused_i8_lds_bytes(int d, int nhid);
 qn_fwd_fn qn_fused_i8_kernel(int d, int o);
 
+// sliced int8-product forward + backward for 64-wide tanh networks (qn_fused_bwd_i8.hip): grid, partial-sum and gradient-slab
+// conventions of k_fused_bwd_f64<64, NH, 4>; `flags` [B][nsplit]: (chain, split)s that left the fast path (the caller
+// reruns those chains with k_fused_bwd_f64)
+using qn_bwd_i8_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*, double*, int*);
+bool qn_fused_bwd_i8_applies(int H, int nhid, int act, int d, int o);
+size_t qn_fused_bwd_i8_lds_bytes(int nhid);
+qn_bwd_i8_fn qn_fused_bwd_i8_kernel(int nhid);
+
 // layer-wise int8-slice forward for wide tanh networks (qn_fused_i8.hip); used by qn_generic.hip
 struct qn_desc;
 #include <hip/hip_runtime.h>

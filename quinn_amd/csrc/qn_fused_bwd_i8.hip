@@ -1,0 +1,477 @@
+// Fused float64 forward + BACKWARD for 64-wide tanh networks with every 64 x 64 product -- the hidden layers of the forward
+// pass, dA = W^T dZ and dW = dZ A^T -- as SLICED EXACT PRODUCTS on the int8 matrix pipe (v_mfma_i32_16x16x64_i8): the
+// gradient of BASELINE configs[1] (64 chains, 3x64, N = 4096), i.e. what logPostGrad costs an HMC / MALA proposal
+// (quinn/solvers/nn_mcmc.py:73-98 -> quinn/nns/nnwrap.py:128-150, called L + 1 times per proposal in quinn/mcmc/hmc.py:48-60).
+//
+// Why.  k_fused_bwd_f64 (qn_fused.hip) pays 384 float64 MFMAs per 16 data rows on the vector pipe (24.6 k cycles) plus the
+// activations: 0.46-0.48 of the float64 MFMA peak.  As sliced int8 products the same six GEMMs are 6 x 104 MFMAs = 10 k
+// cycles on the OTHER pipe (qn_fused_i8.hip explains the arithmetic), next to ~3.5 k vector instructions.
+//
+// Organisation: workgroup = 4 waves = one chain x 64 data rows per iteration, one wave per SIMD (launch bound 1: the
+// weight digit planes of W AND W^T, 2 x 24 KB per hidden matrix, plus two transposition stashes fill the LDS); lane
+// (q, c) of a wave holds features 16 t + 4 q + r of data row c, as in k_fused_fwd_i8.
+//   forward   a_1 on the VALU, a_2 .. a_NH by digit products (A operand: W digits from LDS, B operand: the previous
+//             layer's digits, in registers); every a_l is kept as float64 (for 1 - a^2) and a_1 .. a_{NH-1} as digits.
+//   backward, for l = NH-1 .. 1, with dZ = dZ_{l+1} in registers (float64, accumulator layout):
+//     scale   2^G > every |dZ| of the workgroup's 64 rows (wave maxima exchanged through LDS ahead of the barrier the
+//             stash needs anyway); dZ is sliced ONCE with it: digits m = round(dZ 2^(46 - G)) serve both products;
+//     dW_l    contraction over the 64 DATA ROWS, which sit on lanes: the digit words of dZ and of a_l (4 features of
+//             one row each) go through a 4 x 4 byte transposition inside lane quads (2 DPP moves + 2 v_perm per word:
+//             4 rows of one feature) into two LDS stashes [6][64 features][64 rows], the layout of a weight digit
+//             plane; wave w then owns output rows 16 w .. 16 w + 15: 4 tiles x 26 exact products, recombined into
+//             float64 accumulators once per iteration (the scale changes with the iteration);
+//     db_l    lane-local sums of dZ, reduced over lanes once at the end;
+//     dA      A operand: digit planes of W^T (sliced with one scale per COLUMN of W), B operand: the digits of dZ;
+//             dZ_l = 2^G scale_i sum . (1 - a_l^2).
+//   thin first / last layer (d <= 2 inputs, one output): lane-local accumulators as in k_fused_bwd_f64's fast path.
+// Output conventions of k_fused_bwd_f64: SSE partial per (chain, row split), gradient slab [B][nsplit][p].
+//
+// Accuracy: operands are rounded to 2^-47 of their scale (activations: 1; weights: row / column maximum; dZ: the
+// workgroup maximum of the layer) -- a norm-wise 47-bit bound like the forward kernel's; measured against the float64
+// kernels ~1e-13 of max |g| (tests: 1e-10).
+//
+// Anything outside the fast path's contract -- a weight or input that is not finite and < 2^500, a weight >= 2^20 in a
+// sliced matrix, a layer whose activations are all tiny (qn_i8_slice.h), a gradient beyond 2^500 -- FLAGS the (chain,
+// split); the caller then launches k_fused_bwd_f64 with the flags, which recomputes every split of a flagged chain in
+// plain float64 (and returns at once for all others).
+#include "qn_common.h"
+#include "qn_fused_args.h"
+#include "qn_math.h"
+#include "qn_i8_slice.h"
+
+namespace {
+
+constexpr int BWG = 256;
+
+// LDS, doubles first: W0 [64][DP] | b0 [64] | Wl [64] | bl, pad | red [8] | wave exponents [4] | {scale, bias} (NH-1) x [64][2]
+// | column scales (NH-1) x [64] | tanh table; then bytes: (NH-1) planes of W | (NH-1) planes of W^T | stash dZ | stash A
+__host__ __device__ constexpr int bwd_head_doubles(int dp, int nhid) {
+    return ((H * dp + H + H + 2 + 8 + 4 + (nhid - 1) * 3 * H + 1) & ~1) + ((TANH_TAB + 1) & ~1);
+}
+__host__ __device__ constexpr size_t bwd_lds_bytes(int dp, int nhid) {
+    return sizeof(double) * (size_t)bwd_head_doubles(dp, nhid) + (size_t)(2 * (nhid - 1) + 2) * LAYER_BYTES;
+}
+
+__device__ __forceinline__ void slice4_scaled(const double (&a)[4], double scale, int (&S)[NS]) {
+    int lo[4], hi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double x = fma(a[r], scale, kMagic);
+        lo[r] = __double2loint(x);
+        hi[r] = __double2hiint(x);
+    }
+    const int p01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400), q01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602);
+    const int p23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400), q23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602);
+    const int r01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400), r23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400);
+    S[0] = __builtin_amdgcn_perm(p23, p01, 0x05040100) ^ 0x80808080;
+    S[1] = __builtin_amdgcn_perm(p23, p01, 0x07060302) ^ 0x80808080;
+    S[2] = __builtin_amdgcn_perm(q23, q01, 0x05040100) ^ 0x80808080;
+    S[3] = __builtin_amdgcn_perm(q23, q01, 0x07060302) ^ 0x80808080;
+    S[4] = __builtin_amdgcn_perm(r23, r01, 0x05040100) ^ 0x80808080;
+    S[5] = __builtin_amdgcn_perm(r23, r01, 0x07060302);
+}
+
+// 4 x 4 byte transposition inside a lane quad: in: lane u holds bytes (features) 0..3 of its data row; out: lane u holds
+// feature u of the quad's four rows (byte v = row of lane v).  selA / selB: the lane's v_perm selectors (by lane & 1, lane & 2).
+__device__ __forceinline__ int quad_xpose(int x, int selA, int selB) {
+    const int y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);       // quad_perm [1,0,3,2]: lane u ^ 1
+    const int z = __builtin_amdgcn_perm(y, x, selA);
+    const int w = __builtin_amdgcn_update_dpp(0, z, 0x4E, 0xF, 0xF, false);       // quad_perm [2,3,0,1]: lane u ^ 2
+    return __builtin_amdgcn_perm(w, z, selB);
+}
+
+// level sums (units of 256^LMIN) -> one float64: pairs of levels are added in int32 first (K = 64: a level is < 2^23)
+template <int NLEV>
+__device__ __forceinline__ double recombine(const v4i (&acc)[NLEV], int r) {
+    double ts = (NLEV & 1) ? (double)acc[NLEV - 1][r] : (double)(acc[NLEV - 2][r] + (acc[NLEV - 1][r] << 8));
+#pragma unroll
+    for (int l = ((NLEV & 1) ? NLEV - 3 : NLEV - 4); l >= 0; l -= 2) ts = fma(ts, 65536.0, (double)(acc[l][r] + (acc[l + 1][r] << 8)));
+    return ts;
+}
+
+// Stage chain `Wb`: thin layers as float64, every hidden matrix as digit planes of W (one scale per row) and of W^T (one
+// scale per column).  Returns whether this thread saw a weight outside the fast path's contract.
+template <int NH, int DP, int LMIN>
+__device__ __forceinline__ int stage_bwd(double* __restrict__ lds, unsigned char* __restrict__ wq, unsigned char* __restrict__ wqT,
+                                         const double* __restrict__ Wb, const FusedArgs& a) {
+    int bad = 0;
+    auto chk = [&](double v) { bad |= !qn_bounded(v); return v; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = a.d, nb = a.has_bias ? 1 : 0;
+    const int64_t gb0 = (int64_t)H * d, gHH = gb0 + nb * H;
+    const int64_t gWl = gHH + (int64_t)(NH - 1) * (H * H + nb * H), gbl = gWl + H;
+    const int lb0 = H * DP, lWl = lb0 + H, lbl = lWl + H, lsb = lbl + 2 + 8 + 4, lsT = lsb + (NH - 1) * 2 * H;
+    for (int e = tid; e < H * DP; e += BWG) {
+        const int j = e / DP, k = e % DP;
+        lds[e] = k < d ? chk(Wb[j * d + k]) : 0.0;
+    }
+    for (int e = tid; e < H; e += BWG) {
+        lds[lb0 + e] = nb ? chk(Wb[gb0 + e]) : 0.0;
+        lds[lWl + e] = chk(Wb[gWl + e]);
+    }
+    if (tid == 0) lds[lbl] = nb ? chk(Wb[gbl]) : 0.0;
+    const int q16 = lane & 15, m4 = q16 >> 2, g4 = q16 & 3;                // quad (m, g): k-slots 16 m + 4 g + {0..3}
+#pragma unroll
+    for (int layer = 1; layer < NH; ++layer) {
+        const double* Wg = Wb + gHH + (int64_t)(layer - 1) * (H * H + nb * H);
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr) {                                   // 0: planes of W (row scales), 1: planes of W^T (column scales)
+            unsigned char* plane = (tr ? wqT : wq) + (layer - 1) * LAYER_BYTES;
+            double v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = 16 * u + 4 * wave + (lane >> 4);
+                if (tr == 0) {
+                    const double2* src = reinterpret_cast<const double2*>(Wg + row * H + 16 * m4 + 4 * g4);
+                    const double2 v01 = src[0], v23 = src[1];
+                    v[u][0] = chk(v01.x); v[u][1] = chk(v01.y); v[u][2] = chk(v23.x); v[u][3] = chk(v23.y);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[u][r] = Wg[(16 * m4 + 4 * g4 + r) * H + row];       // (checked in the first pass)
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = 16 * u + 4 * wave + (lane >> 4);
+                unsigned ex = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ex = max(ex, ((unsigned)__double2hiint(v[u][r]) & 0x7fffffffu) >> 20);
+                int e = (int)row16_max_u32(ex) - 1022;                     // 2^e > every |entry| of the row (of W or of W^T)
+                bad |= e > I8_MAX_WEIGHT_EXP;
+                e = e < -900 ? -900 : e;
+                double an[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) an[r] = ldexp(v[u][r], -e);
+                int S[NS];
+                slice4(an, S);
+                unsigned char* dst = plane + row * H + 16 * (g4 ^ slot_swz(row)) + 4 * m4;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(dst + k * SLICE_BYTES) = S[k];
+                if (q16 == 0) {
+                    const double sc = ldexp(1.0, e - 2 * QB + 8 * LMIN);  // integer sum (units of 256^LMIN) -> product with unit-scale digits
+                    if (tr == 0) {
+                        lds[lsb + (layer - 1) * 2 * H + 2 * row] = sc;
+                        lds[lsb + (layer - 1) * 2 * H + 2 * row + 1] = nb ? chk(Wg[H * H + row]) : 0.0;
+                    } else {
+                        lds[lsT + (layer - 1) * H + row] = sc;
+                    }
+                }
+            }
+        }
+    }
+    return bad;
+}
+
+template <int NH, int DP, int LMIN>
+__global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const double* __restrict__ W, const double* __restrict__ X,
+                                                        const double* __restrict__ Y, const int32_t* __restrict__ row_idx,
+                                                        double* __restrict__ pred_out, double* __restrict__ partial,
+                                                        double* __restrict__ slab, int* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN), NM = NH - 1;
+    double* lds = reinterpret_cast<double*>(smem);
+    int b, split;
+    if (!qn_fused_wg(a.nsplit, a.B, &b, &split)) return;
+    const int d = a.d, nb = a.has_bias ? 1 : 0;
+    constexpr int offb0 = H * DP, offWl = offb0 + H, offbl = offWl + H, offred = offbl + 2, offgx = offred + 8, offsb = offgx + 4,
+                  offsT = offsb + NM * 2 * H;
+    double* tanh_tab = lds + ((offsT + NM * H + 1) & ~1);
+    unsigned char* wq = reinterpret_cast<unsigned char*>(lds + bwd_head_doubles(DP, NH));
+    unsigned char* wqT = wq + NM * LAYER_BYTES;
+    unsigned char* SD = wqT + NM * LAYER_BYTES;
+    unsigned char* SA = SD + LAYER_BYTES;
+    double* red = lds + offred;
+    int* gx = reinterpret_cast<int*>(lds + offgx);
+    const double* Wb = W + (int64_t)b * a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c = lane & 15;
+    qn_tanh_table64_stage(tanh_tab, tid, BWG);
+    const bool w_bad = block_or(stage_bwd<NH, DP, LMIN>(lds, wq, wqT, Wb, a), red + 6);
+    if (w_bad) {                                                        // the float64 kernel recomputes the whole chain
+        if (tid == 0) {
+            flags[b * a.nsplit + split] = 1;
+            partial[(int64_t)b * a.nsplit + split] = 0.0;
+        }
+        return;
+    }
+    const int lofs = c * H + 16 * (q ^ slot_swz(c));                    // this lane's 16 bytes inside a 16-row tile of a plane
+    // stash write: this lane's transposed word = feature 16 t + 4 q + (c & 3) of rows 16 wave + 4 (c >> 2) .. + 3
+    const int wofs = (4 * q + (c & 3)) * H + 16 * (wave ^ slot_swz(4 * q)) + 4 * (c >> 2);
+    const int selA = (c & 1) ? 0x03070105 : 0x06020400, selB = (c & 2) ? 0x03020706 : 0x05040100;
+    int bad_run = 0;
+    double sse = 0.0;
+
+    double dWacc[NM][4][4];                                             // rows 16 wave + 4 q + r, columns 16 ti + c
+#pragma unroll
+    for (int l = 0; l < NM; ++l)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dWacc[l][ti][r] = 0.0;
+    double accB[NH][T][4], accWl[T][4], accW0[DP][T][4], accBl = 0.0;   // lane-local: feature 16 t + 4 q + r, summed over this lane's rows
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            accWl[t][r] = 0.0;
+#pragma unroll
+            for (int l = 0; l < NH; ++l) accB[l][t][r] = 0.0;
+#pragma unroll
+            for (int k = 0; k < DP; ++k) accW0[k][t][r] = 0.0;
+        }
+
+    auto load_frags = [&](v4i (&Af)[NS], const unsigned char* tile) {
+#pragma unroll
+        for (int wi = 0; wi < NS; ++wi) Af[wi] = *reinterpret_cast<const v4i*>(tile + wi * SLICE_BYTES);
+    };
+    auto products = [&](v4i (&acc)[NLEV], const v4i (&Af)[NS], const v4i (&Bf)[NS]) {
+#pragma unroll
+        for (int k = 0; k < NPROD; ++k) issue_product<LMIN>(k, acc, Af, Bf);
+    };
+
+    for (int it = 0; it < a.iters; ++it) {
+        const int n = split * a.rows_per_split + it * 64 + 16 * wave + c;
+        const bool valid = n < a.Nb;
+        const int nn = valid ? n : 0;
+        const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
+        double xk[DP];
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            xk[k] = k < d ? X[rr * d + k] : 0.0;
+            bad_run |= !qn_bounded(xk[k]);
+        }
+        const double yv = Y[rr];
+        // ------------------------------------------------------------------ forward
+        double act[NH][T][4];
+        v4i Bd[NM][NS];
+        {
+            int top = 0;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * t + 4 * q + r;
+                    double z = lds[offb0 + j];
+#pragma unroll
+                    for (int k = 0; k < DP; ++k) z = fma(lds[j * DP + k], xk[k], z);
+                    act[0][t][r] = qn_tanh_f64_tab64(z, tanh_tab);
+                }
+                int S[NS];
+                slice4(act[0][t], S);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) Bd[0][k][t] = S[k];
+                top |= top_digits_large(S[NS - 1]);
+            }
+            bad_run |= !__any(top != 0);                                // all activations of the wave's rows tiny: see qn_i8_slice.h
+        }
+#pragma unroll
+        for (int l = 1; l < NH; ++l) {
+            const unsigned char* plane = wq + (l - 1) * LAYER_BYTES + lofs;
+            const double* sb = lds + offsb + (l - 1) * 2 * H + 2 * 4 * q;
+            int top = 0;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                v4i Af[NS], acc[NLEV];
+                load_frags(Af, plane + t * 16 * H);
+                products(acc, Af, Bd[l - 1]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double2 sc = *reinterpret_cast<const double2*>(sb + 32 * t + 2 * r);
+                    act[l][t][r] = qn_tanh_f64_tab64(fma(recombine<NLEV>(acc, r), sc.x, sc.y), tanh_tab);
+                }
+                if (l < NM) {
+                    int S[NS];
+                    slice4(act[l][t], S);
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) Bd[l][k][t] = S[k];
+                    top |= top_digits_large(S[NS - 1]);
+                }
+            }
+            if (l < NM) bad_run |= !__any(top != 0);
+        }
+        // ------------------------------------------------------------------ last layer, residual
+        double delta;
+        {
+            double pd = 0.0;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pd = fma(lds[offWl + 16 * t + 4 * q + r], act[NH - 1][t][r], pd);
+            pd += __shfl_xor(pd, 16, 64);
+            pd += __shfl_xor(pd, 32, 64);
+            const double pr = pd + lds[offbl];
+            const double res = pr - yv;
+            delta = valid ? 2.0 * res : 0.0;
+            if (valid && q == 0) {
+                sse += res * res;
+                if (pred_out) pred_out[(int64_t)b * a.Nb + n] = pr;
+            }
+        }
+        // ------------------------------------------------------------------ backward
+        double dz[T][4];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double av = act[NH - 1][t][r];
+                accWl[t][r] = fma(delta, av, accWl[t][r]);
+                dz[t][r] = (lds[offWl + 16 * t + 4 * q + r] * delta) * fma(-av, av, 1.0);
+            }
+        if (q == 0) accBl += delta;
+#pragma unroll
+        for (int l = NH - 1; l >= 1; --l) {
+            // dz = dZ_{l+1} (gradient at the pre-activations of a_{l+1}); matrix W_l = planes l - 1; a_l = act[l - 1]
+            unsigned ex = 0;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ex = max(ex, ((unsigned)__double2hiint(dz[t][r]) & 0x7fffffffu) >> 20);
+                    accB[l][t][r] += dz[t][r];
+                }
+            ex = wave_max_u32(ex);
+            if (lane == 0) gx[wave] = (int)ex;
+            __syncthreads();                                            // exponents visible; the previous stash readers are done
+            int E = max(max(gx[0], gx[1]), max(gx[2], gx[3]));          // |dZ| < 2^(E - 1022) for the workgroup's 64 rows
+            bad_run |= E >= 1022 + 500;
+            E = E < 122 ? 122 : (E > 1600 ? 1600 : E);
+            const double sl = __hiloint2double((2091 - E) << 20, 0);    // 2^(46 - G), G = E - 1022
+            const double rs = __hiloint2double((E + 1) << 20, 0);       // 2^G
+            v4i D[NS];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                int S[NS];
+                slice4_scaled(dz[t], sl, S);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) D[k][t] = S[k];
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    *reinterpret_cast<int*>(SD + k * SLICE_BYTES + t * 16 * H + wofs) = quad_xpose(D[k][t], selA, selB);
+                    *reinterpret_cast<int*>(SA + k * SLICE_BYTES + t * 16 * H + wofs) = quad_xpose(Bd[l - 1][k][t], selA, selB);
+                }
+            __syncthreads();
+            // ---- dW_l: rows 16 wave .. + 15 (features of dZ), four column tiles (features of a_l), K = the 64 data rows
+            {
+                v4i Az[NS];
+                load_frags(Az, SD + wave * 16 * H + lofs);
+                const double sdw = rs * __hiloint2double((1023 + 8 * LMIN - 2 * QB) << 20, 0);      // digits at 2^-46 each, levels in units of 256^LMIN
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) {
+                    v4i Bf[NS], acc[NLEV];
+                    load_frags(Bf, SA + ti * 16 * H + lofs);
+                    products(acc, Az, Bf);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dWacc[l - 1][ti][r] = fma(recombine<NLEV>(acc, r), sdw, dWacc[l - 1][ti][r]);
+                }
+            }
+            // ---- dA = W_l^T dZ, then dZ_l = dA . (1 - a_l^2)
+            {
+                const unsigned char* plane = wqT + (l - 1) * LAYER_BYTES + lofs;
+                const double* sT = lds + offsT + (l - 1) * H + 4 * q;
+                double dzn[T][4];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    v4i Af[NS], acc[NLEV];
+                    load_frags(Af, plane + t * 16 * H);
+                    products(acc, Af, D);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double av = act[l - 1][t][r];
+                        dzn[t][r] = (recombine<NLEV>(acc, r) * (sT[16 * t + r] * rs)) * fma(-av, av, 1.0);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dz[t][r] = dzn[t][r];
+            }
+        }
+        // ------------------------------------------------------------------ first layer
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                accB[0][t][r] += dz[t][r];
+#pragma unroll
+                for (int k = 0; k < DP; ++k) accW0[k][t][r] = fma(dz[t][r], xk[k], accW0[k][t][r]);
+            }
+    }
+
+    // ---------------------------------------------------------------------- write the partial gradient
+    double* out = slab + ((int64_t)b * a.nsplit + split) * a.p;
+    const int64_t gb0 = (int64_t)H * d, gHH = gb0 + nb * H;
+    const int64_t gWl = gHH + (int64_t)NM * (H * H + nb * H), gbl = gWl + H;
+#pragma unroll
+    for (int l = 0; l < NM; ++l) {
+        double* og = out + gHH + (int64_t)l * (H * H + nb * H);
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) og[(int64_t)(16 * wave + 4 * q + r) * H + 16 * ti + c] = dWacc[l][ti][r];
+    }
+    // lane-local sums: over the 16 row lanes of each lane group, then over the 4 waves through LDS (the stashes are free)
+    __syncthreads();
+    constexpr int NV = NH + 1 + DP;                                     // vectors of 64: biases of the NH layers, Wl, the DP columns of W0
+    double* R = reinterpret_cast<double*>(SD);                          // [NV][4 waves][64] + [4]
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v[NV];
+#pragma unroll
+            for (int l = 0; l < NH; ++l) v[l] = accB[l][t][r];
+            v[NH] = accWl[t][r];
+#pragma unroll
+            for (int k = 0; k < DP; ++k) v[NH + 1 + k] = accW0[k][t][r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+                for (int u = 0; u < NV; ++u) v[u] += __shfl_xor(v[u], m, 64);
+            if (c == 0) {
+                const int f = 16 * t + 4 * q + r;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) R[(u * 4 + wave) * H + f] = v[u];
+            }
+        }
+    const double bl_w = wave_sum(accBl);
+    sse = wave_sum(sse);
+    if (lane == 0) {
+        R[NV * 4 * H + wave] = bl_w;
+        red[wave] = sse;
+    }
+    const int any_bad = __any(bad_run) ? 1 : 0;
+    if (lane == 0) gx[wave] = any_bad;
+    __syncthreads();
+    if (tid < H) {
+        double s[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) s[u] = ((R[(u * 4 + 0) * H + tid] + R[(u * 4 + 1) * H + tid]) + R[(u * 4 + 2) * H + tid]) + R[(u * 4 + 3) * H + tid];
+        if (nb) {
+            out[gb0 + tid] = s[0];
+#pragma unroll
+            for (int l = 1; l < NH; ++l) out[gHH + (int64_t)(l - 1) * (H * H + H) + H * H + tid] = s[l];
+        }
+        out[gWl + tid] = s[NH];
+#pragma unroll
+        for (int k = 0; k < DP; ++k)
+            if (k < d) out[(int64_t)tid * d + k] = s[NH + 1 + k];
+    }
+    if (tid == 0) {
+        if (nb) out[gbl] = ((R[NV * 4 * H] + R[NV * 4 * H + 1]) + R[NV * 4 * H + 2]) + R[NV * 4 * H + 3];
+        partial[(int64_t)b * a.nsplit + split] = (red[0] + red[1]) + (red[2] + red[3]);
+        flags[b * a.nsplit + split] = gx[0] | gx[1] | gx[2] | gx[3];
+    }
+}
+
+}  // namespace
+
+// ---- what qn_fused.hip needs to dispatch to this kernel
+bool qn_fused_bwd_i8_applies(int Hh, int nhid, int act, int d, int o) {
+    return Hh == H && act == QN_ACT_TANH && (nhid == 2 || nhid == 3) && d <= 2 && o == 1;
+}
+size_t qn_fused_bwd_i8_lds_bytes(int nhid) { return bwd_lds_bytes(2, nhid); }
+qn_bwd_i8_fn qn_fused_bwd_i8_kernel(int nhid) {
+    return nhid == 2 ? k_fused_bwd_i8<2, 2, QN_I8_LMIN> : k_fused_bwd_i8<3, 2, QN_I8_LMIN>;
+}
