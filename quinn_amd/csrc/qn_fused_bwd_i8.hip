@@ -43,6 +43,21 @@ namespace {
 
 constexpr int BWG = 256;
 
+#ifdef QN_BWD8_STAMPS
+// diagnostic build only (tools/bwd8_stamps.py): per-phase cycles of wave 0 of workgroup 0
+#define QN_STAMP(k)                                                                          \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                  \
+        const long long now_ = __builtin_amdgcn_s_memtime();                                 \
+        stamp_acc[k] += now_ - stamp_prev;                                                   \
+        stamp_prev = now_;                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#else
+#define QN_STAMP(k) do { } while (0)
+#endif
+
 // LDS, doubles first: W0 [64][DP] | b0 [64] | Wl [64] | bl, pad | red [8] | wave exponents [4] | {scale, bias} (NH-1) x [64][2]
 // | column scales (NH-1) x [64] | tanh table; then bytes: (NH-1) planes of W | (NH-1) planes of W^T | stash dZ | stash A
 __host__ __device__ constexpr int bwd_head_doubles(int dp, int nhid) {
@@ -79,6 +94,36 @@ __device__ __forceinline__ int quad_xpose(int x, int selA, int selB) {
     const int w = __builtin_amdgcn_update_dpp(0, z, 0x4E, 0xF, 0xF, false);       // quad_perm [2,3,0,1]: lane u ^ 2
     return __builtin_amdgcn_perm(w, z, selB);
 }
+
+// Scheduling request for the region that ends here (between two sched_barrier(0)): the fragment reads first, then NMFMA
+// times one MFMA followed by VPM vector instructions -- the next tile's products between the instructions of this tile's
+// epilogue (what qn_fused_i8.hip / qn_wide_i8.hip do with hand-written stages).
+#ifndef QN_BWD8_VPM_FWD
+#define QN_BWD8_VPM_FWD 5
+#endif
+#ifndef QN_BWD8_VPM_DW
+#define QN_BWD8_VPM_DW 2
+#endif
+#ifndef QN_BWD8_VPM_DA
+#define QN_BWD8_VPM_DA 3
+#endif
+template <int NMFMA, int VPM>
+__device__ __forceinline__ void interleave_hint_nolds() {
+#pragma unroll
+    for (int i = 0; i < NMFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+    }
+}
+template <int NMFMA, int VPM>
+__device__ __forceinline__ void interleave_hint() {
+    __builtin_amdgcn_sched_group_barrier(0x100, NS, 0);
+    interleave_hint_nolds<NMFMA, VPM>();
+}
+
+// The value is computed HERE (an empty volatile asm: IR-level code motion would otherwise sink an epilogue whose result
+// is not needed before the end of the iteration out of the region its MFMAs are interleaved with).
+__device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
 
 // level sums (units of 256^LMIN) -> one float64: pairs of levels are added in int32 first (K = 64: a level is < 2^23)
 template <int NLEV>
@@ -162,13 +207,14 @@ __device__ __forceinline__ int stage_bwd(double* __restrict__ lds, unsigned char
     return bad;
 }
 
-template <int NH, int DP, int LMIN>
+// DD = number of inputs (1 or 2; the LDS image of W0 is 2 columns wide either way)
+template <int NH, int DD, int LMIN>
 __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const double* __restrict__ W, const double* __restrict__ X,
                                                         const double* __restrict__ Y, const int32_t* __restrict__ row_idx,
                                                         double* __restrict__ pred_out, double* __restrict__ partial,
                                                         double* __restrict__ slab, int* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN), NM = NH - 1;
+    constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN), NM = NH - 1, DP = 2;
     double* lds = reinterpret_cast<double*>(smem);
     int b, split;
     if (!qn_fused_wg(a.nsplit, a.B, &b, &split)) return;
@@ -207,17 +253,23 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
             for (int r = 0; r < 4; ++r) dWacc[l][ti][r] = 0.0;
-    double accB[NH][T][4], accWl[T][4], accW0[DP][T][4], accBl = 0.0;   // lane-local: feature 16 t + 4 q + r, summed over this lane's rows
+    double accB0[T][4], accWl[T][4], accW0[DD][T][4], accBl = 0.0;     // lane-local: feature 16 t + 4 q + r, summed over this lane's rows
+    double dbacc[NM][4];                                                // hidden biases: rows 16 wave + 4 q + r (every lane of the group alike)
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             accWl[t][r] = 0.0;
+            accB0[t][r] = 0.0;
 #pragma unroll
-            for (int l = 0; l < NH; ++l) accB[l][t][r] = 0.0;
-#pragma unroll
-            for (int k = 0; k < DP; ++k) accW0[k][t][r] = 0.0;
+            for (int k = 0; k < DD; ++k) accW0[k][t][r] = 0.0;
         }
+#pragma unroll
+    for (int l = 0; l < NM; ++l)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dbacc[l][r] = 0.0;
+    // B operand "every feature = 1.0" (digit 5 = 64, all others 0): its products with the digits of dZ are the row sums of dZ
+    const v4i ones5 = {0x40404040, 0x40404040, 0x40404040, 0x40404040};
 
     auto load_frags = [&](v4i (&Af)[NS], const unsigned char* tile) {
 #pragma unroll
@@ -228,18 +280,42 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
         for (int k = 0; k < NPROD; ++k) issue_product<LMIN>(k, acc, Af, Bf);
     };
 
-    for (int it = 0; it < a.iters; ++it) {
-        const int n = split * a.rows_per_split + it * 64 + 16 * wave + c;
-        const bool valid = n < a.Nb;
-        const int nn = valid ? n : 0;
+#ifdef QN_BWD8_STAMPS
+    long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
+    // data of the NEXT iteration is fetched while the current one computes (an HBM / L2 round trip per iteration otherwise)
+    double xn[DD], yn;
+    int n_n;
+    bool valid_n;
+    auto fetch = [&](int it) {
+        n_n = split * a.rows_per_split + it * 64 + 16 * wave + c;
+        valid_n = n_n < a.Nb;
+        const int nn = valid_n ? n_n : 0;
         const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
-        double xk[DP];
 #pragma unroll
-        for (int k = 0; k < DP; ++k) {
-            xk[k] = k < d ? X[rr * d + k] : 0.0;
+        for (int k = 0; k < DD; ++k) xn[k] = X[rr * DD + k];
+        yn = Y[rr];
+    };
+    fetch(0);
+    // one tile's worth of matrix work: 6 fragment reads + the kept digit products into `acc`
+    auto mfma_tile = [&](v4i (&acc)[NLEV], const unsigned char* tile, const v4i (&Bop)[NS]) {
+        v4i Af[NS];
+        load_frags(Af, tile);
+        products(acc, Af, Bop);
+    };
+    for (int it = 0; it < a.iters; ++it) {
+        const int n = n_n;
+        const bool valid = valid_n;
+        double xk[DD];
+#pragma unroll
+        for (int k = 0; k < DD; ++k) {
+            xk[k] = xn[k];
             bad_run |= !qn_bounded(xk[k]);
         }
-        const double yv = Y[rr];
+        const double yv = yn;
+        if (it + 1 < a.iters) fetch(it + 1);
+        QN_STAMP(0);
         // ------------------------------------------------------------------ forward
         double act[NH][T][4];
         v4i Bd[NM][NS];
@@ -252,7 +328,7 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
                     const int j = 16 * t + 4 * q + r;
                     double z = lds[offb0 + j];
 #pragma unroll
-                    for (int k = 0; k < DP; ++k) z = fma(lds[j * DP + k], xk[k], z);
+                    for (int k = 0; k < DD; ++k) z = fma(lds[j * DP + k], xk[k], z);
                     act[0][t][r] = qn_tanh_f64_tab64(z, tanh_tab);
                 }
                 int S[NS];
@@ -263,20 +339,26 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
             }
             bad_run |= !__any(top != 0);                                // all activations of the wave's rows tiny: see qn_i8_slice.h
         }
+        QN_STAMP(1);
+        // hidden layers: the products of tile t + 1 are issued BETWEEN the vector instructions of tile t's epilogue (one wave
+        // per SIMD: a burst of MFMAs holds the wave's in-order issue, a run of vector instructions leaves the matrix pipe idle)
+        double pd = 0.0;
 #pragma unroll
         for (int l = 1; l < NH; ++l) {
             const unsigned char* plane = wq + (l - 1) * LAYER_BYTES + lofs;
             const double* sb = lds + offsb + (l - 1) * 2 * H + 2 * 4 * q;
+            v4i accs[2][NLEV];
             int top = 0;
+            mfma_tile(accs[0], plane, Bd[l - 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                v4i Af[NS], acc[NLEV];
-                load_frags(Af, plane + t * 16 * H);
-                products(acc, Af, Bd[l - 1]);
+                if (t + 1 < T) mfma_tile(accs[(t + 1) & 1], plane + (t + 1) * 16 * H, Bd[l - 1]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double2 sc = *reinterpret_cast<const double2*>(sb + 32 * t + 2 * r);
-                    act[l][t][r] = qn_tanh_f64_tab64(fma(recombine<NLEV>(acc, r), sc.x, sc.y), tanh_tab);
+                    act[l][t][r] = qn_tanh_f64_tab64(fma(recombine<NLEV>(accs[t & 1], r), sc.x, sc.y), tanh_tab);
+                    if (l == NM) pd = fma(lds[offWl + 16 * t + 4 * q + r], act[l][t][r], pd);
                 }
                 if (l < NM) {
                     int S[NS];
@@ -285,17 +367,15 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
                     for (int k = 0; k < NS; ++k) Bd[l][k][t] = S[k];
                     top |= top_digits_large(S[NS - 1]);
                 }
+                if (t + 1 < T) interleave_hint<NPROD, QN_BWD8_VPM_FWD>();
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (l < NM) bad_run |= !__any(top != 0);
         }
+        QN_STAMP(2);
         // ------------------------------------------------------------------ last layer, residual
         double delta;
         {
-            double pd = 0.0;
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pd = fma(lds[offWl + 16 * t + 4 * q + r], act[NH - 1][t][r], pd);
             pd += __shfl_xor(pd, 16, 64);
             pd += __shfl_xor(pd, 32, 64);
             const double pr = pd + lds[offbl];
@@ -317,6 +397,7 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
                 dz[t][r] = (lds[offWl + 16 * t + 4 * q + r] * delta) * fma(-av, av, 1.0);
             }
         if (q == 0) accBl += delta;
+        QN_STAMP(3);
 #pragma unroll
         for (int l = NH - 1; l >= 1; --l) {
             // dz = dZ_{l+1} (gradient at the pre-activations of a_{l+1}); matrix W_l = planes l - 1; a_l = act[l - 1]
@@ -324,81 +405,130 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ex = max(ex, ((unsigned)__double2hiint(dz[t][r]) & 0x7fffffffu) >> 20);
-                    accB[l][t][r] += dz[t][r];
-                }
+                for (int r = 0; r < 4; ++r) ex = max(ex, ((unsigned)__double2hiint(dz[t][r]) & 0x7fffffffu) >> 20);
             ex = wave_max_u32(ex);
             if (lane == 0) gx[wave] = (int)ex;
+            // the transposed digit words of a_l need nothing from the other waves: formed ahead of the barrier (where the
+            // wave would wait anyway), written behind it
+            int At[NS][T];
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int t = 0; t < T; ++t) At[k][t] = quad_xpose(Bd[l - 1][k][t], selA, selB);
             __syncthreads();                                            // exponents visible; the previous stash readers are done
+            QN_STAMP(4);
             int E = max(max(gx[0], gx[1]), max(gx[2], gx[3]));          // |dZ| < 2^(E - 1022) for the workgroup's 64 rows
             bad_run |= E >= 1022 + 500;
             E = E < 122 ? 122 : (E > 1600 ? 1600 : E);
             const double sl = __hiloint2double((2091 - E) << 20, 0);    // 2^(46 - G), G = E - 1022
             const double rs = __hiloint2double((E + 1) << 20, 0);       // 2^G
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int t = 0; t < T; ++t) *reinterpret_cast<int*>(SA + k * SLICE_BYTES + t * 16 * H + wofs) = At[k][t];
             v4i D[NS];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 int S[NS];
                 slice4_scaled(dz[t], sl, S);
 #pragma unroll
-                for (int k = 0; k < NS; ++k) D[k][t] = S[k];
-            }
-#pragma unroll
-            for (int k = 0; k < NS; ++k)
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    *reinterpret_cast<int*>(SD + k * SLICE_BYTES + t * 16 * H + wofs) = quad_xpose(D[k][t], selA, selB);
-                    *reinterpret_cast<int*>(SA + k * SLICE_BYTES + t * 16 * H + wofs) = quad_xpose(Bd[l - 1][k][t], selA, selB);
+                for (int k = 0; k < NS; ++k) {
+                    D[k][t] = S[k];
+                    *reinterpret_cast<int*>(SD + k * SLICE_BYTES + t * 16 * H + wofs) = quad_xpose(S[k], selA, selB);
                 }
+            }
+            QN_STAMP(5);
             __syncthreads();
-            // ---- dW_l: rows 16 wave .. + 15 (features of dZ), four column tiles (features of a_l), K = the 64 data rows
-            {
-                v4i Az[NS];
-                load_frags(Az, SD + wave * 16 * H + lofs);
-                const double sdw = rs * __hiloint2double((1023 + 8 * LMIN - 2 * QB) << 20, 0);      // digits at 2^-46 each, levels in units of 256^LMIN
+            QN_STAMP(6);
+            // ---- one pipeline of nine product groups: dW_l (4 column tiles: rows 16 wave .. + 15 of dZ x features of a_l, K = the
+            // 64 data rows), db_l (the six products of dZ with the constant top digit of 1.0: row sums), dA = W_l^T dZ (4 tiles);
+            // each group's products are issued between the vector instructions of the previous group's epilogue
+            const double sdw = rs * __hiloint2double((1023 + 8 * LMIN - 2 * QB) << 20, 0);      // digits at 2^-46 each, levels in units of 256^LMIN
+            const unsigned char* planeT = wqT + (l - 1) * LAYER_BYTES + lofs;
+            const double* sT = lds + offsT + (l - 1) * H + 4 * q;
+            v4i Az[NS], accs[2][NLEV], accb[NS];
+            load_frags(Az, SD + wave * 16 * H + lofs);
+            auto dw_group = [&](v4i (&acc)[NLEV], int ti) {
+                v4i Bf[NS];
+                load_frags(Bf, SA + ti * 16 * H + lofs);
+                products(acc, Az, Bf);
+            };
+            auto dw_epilogue = [&](const v4i (&acc)[NLEV], int ti) {
 #pragma unroll
-                for (int ti = 0; ti < 4; ++ti) {
-                    v4i Bf[NS], acc[NLEV];
-                    load_frags(Bf, SA + ti * 16 * H + lofs);
-                    products(acc, Az, Bf);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dWacc[l - 1][ti][r] = fma(recombine<NLEV>(acc, r), sdw, dWacc[l - 1][ti][r]);
+                for (int r = 0; r < 4; ++r) {
+                    dWacc[l - 1][ti][r] = fma(recombine<NLEV>(acc, r), sdw, dWacc[l - 1][ti][r]);
+                    pin(dWacc[l - 1][ti][r]);
                 }
-            }
-            // ---- dA = W_l^T dZ, then dZ_l = dA . (1 - a_l^2)
-            {
-                const unsigned char* plane = wqT + (l - 1) * LAYER_BYTES + lofs;
-                const double* sT = lds + offsT + (l - 1) * H + 4 * q;
-                double dzn[T][4];
+            };
+            double dzn[T][4];
+            auto da_epilogue = [&](const v4i (&acc)[NLEV], int t) {
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    v4i Af[NS], acc[NLEV];
-                    load_frags(Af, plane + t * 16 * H);
-                    products(acc, Af, D);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const double av = act[l - 1][t][r];
-                        dzn[t][r] = (recombine<NLEV>(acc, r) * (sT[16 * t + r] * rs)) * fma(-av, av, 1.0);
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const double av = act[l - 1][t][r];
+                    dzn[t][r] = (recombine<NLEV>(acc, r) * (sT[16 * t + r] * rs)) * fma(-av, av, 1.0);
+                    pin(dzn[t][r]);
                 }
+            };
+            dw_group(accs[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < T; ++t)
+            for (int ti = 0; ti < 4; ++ti) {
+                if (ti + 1 < 4) {
+                    dw_group(accs[(ti + 1) & 1], ti + 1);
+                } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dz[t][r] = dzn[t][r];
+                    for (int wi = 0; wi < NS; ++wi) accb[wi] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Az[wi], ones5, (v4i){0, 0, 0, 0}, 0, 0, 0);
+                }
+                dw_epilogue(accs[ti & 1], ti);
+                if (ti + 1 < 4) interleave_hint<NPROD, QN_BWD8_VPM_DW>();
+                else interleave_hint_nolds<NS, 8>();
+                __builtin_amdgcn_sched_barrier(0);
             }
+            {   // first tile of dA under the epilogue of db
+                mfma_tile(accs[0], planeT, D);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double ts = (double)(accb[4][r] + (accb[5][r] << 8));
+                    ts = fma(ts, 65536.0, (double)(accb[2][r] + (accb[3][r] << 8)));
+                    ts = fma(ts, 65536.0, (double)(accb[0][r] + (accb[1][r] << 8)));
+                    dbacc[l - 1][r] = fma(ts, sdw * (double)(1 << (8 * (5 - LMIN))), dbacc[l - 1][r]);
+                    pin(dbacc[l - 1][r]);
+                }
+                interleave_hint<NPROD, 2>();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            QN_STAMP(7);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                if (t + 1 < T) mfma_tile(accs[(t + 1) & 1], planeT + (t + 1) * 16 * H, D);
+                da_epilogue(accs[t & 1], t);
+                if (t + 1 < T) interleave_hint<NPROD, QN_BWD8_VPM_DA>();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dz[t][r] = dzn[t][r];
         }
         // ------------------------------------------------------------------ first layer
+        QN_STAMP(8);
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                accB[0][t][r] += dz[t][r];
+                accB0[t][r] += dz[t][r];
 #pragma unroll
-                for (int k = 0; k < DP; ++k) accW0[k][t][r] = fma(dz[t][r], xk[k], accW0[k][t][r]);
+                for (int k = 0; k < DD; ++k) accW0[k][t][r] = fma(dz[t][r], xk[k], accW0[k][t][r]);
             }
+        QN_STAMP(9);
     }
 
+#ifdef QN_BWD8_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        long long* dbg = reinterpret_cast<long long*>(partial + a.dbg_off);
+        for (int k = 0; k < 12; ++k) dbg[k] = stamp_acc[k];
+    }
+#endif
     // ---------------------------------------------------------------------- write the partial gradient
     double* out = slab + ((int64_t)b * a.nsplit + split) * a.p;
     const int64_t gb0 = (int64_t)H * d, gHH = gb0 + nb * H;
@@ -413,18 +543,17 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
     }
     // lane-local sums: over the 16 row lanes of each lane group, then over the 4 waves through LDS (the stashes are free)
     __syncthreads();
-    constexpr int NV = NH + 1 + DP;                                     // vectors of 64: biases of the NH layers, Wl, the DP columns of W0
+    constexpr int NV = 2 + DD;                                          // vectors of 64: b0, Wl, the DP columns of W0
     double* R = reinterpret_cast<double*>(SD);                          // [NV][4 waves][64] + [4]
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double v[NV];
+            v[0] = accB0[t][r];
+            v[1] = accWl[t][r];
 #pragma unroll
-            for (int l = 0; l < NH; ++l) v[l] = accB[l][t][r];
-            v[NH] = accWl[t][r];
-#pragma unroll
-            for (int k = 0; k < DP; ++k) v[NH + 1 + k] = accW0[k][t][r];
+            for (int k = 0; k < DD; ++k) v[2 + k] = accW0[k][t][r];
 #pragma unroll
             for (int m = 1; m < 16; m <<= 1)
 #pragma unroll
@@ -448,15 +577,16 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
         double s[NV];
 #pragma unroll
         for (int u = 0; u < NV; ++u) s[u] = ((R[(u * 4 + 0) * H + tid] + R[(u * 4 + 1) * H + tid]) + R[(u * 4 + 2) * H + tid]) + R[(u * 4 + 3) * H + tid];
-        if (nb) {
-            out[gb0 + tid] = s[0];
+        if (nb) out[gb0 + tid] = s[0];
+        out[gWl + tid] = s[1];
 #pragma unroll
-            for (int l = 1; l < NH; ++l) out[gHH + (int64_t)(l - 1) * (H * H + H) + H * H + tid] = s[l];
-        }
-        out[gWl + tid] = s[NH];
+        for (int k = 0; k < DD; ++k) out[(int64_t)tid * DD + k] = s[2 + k];
+    }
+    if (nb && c == 0) {
 #pragma unroll
-        for (int k = 0; k < DP; ++k)
-            if (k < d) out[(int64_t)tid * d + k] = s[NH + 1 + k];
+        for (int l = 0; l < NM; ++l)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[gHH + (int64_t)l * (H * H + H) + H * H + 16 * wave + 4 * q + r] = dbacc[l][r];
     }
     if (tid == 0) {
         if (nb) out[gbl] = ((R[NV * 4 * H] + R[NV * 4 * H + 1]) + R[NV * 4 * H + 2]) + R[NV * 4 * H + 3];
@@ -469,9 +599,10 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
 
 // ---- what qn_fused.hip needs to dispatch to this kernel
 bool qn_fused_bwd_i8_applies(int Hh, int nhid, int act, int d, int o) {
-    return Hh == H && act == QN_ACT_TANH && (nhid == 2 || nhid == 3) && d <= 2 && o == 1;
+    return Hh == H && act == QN_ACT_TANH && (nhid == 2 || nhid == 3) && d >= 1 && d <= 2 && o == 1;
 }
 size_t qn_fused_bwd_i8_lds_bytes(int nhid) { return bwd_lds_bytes(2, nhid); }
-qn_bwd_i8_fn qn_fused_bwd_i8_kernel(int nhid) {
+qn_bwd_i8_fn qn_fused_bwd_i8_kernel(int nhid, int d) {
+    if (d == 1) return nhid == 2 ? k_fused_bwd_i8<2, 1, QN_I8_LMIN> : k_fused_bwd_i8<3, 1, QN_I8_LMIN>;
     return nhid == 2 ? k_fused_bwd_i8<2, 2, QN_I8_LMIN> : k_fused_bwd_i8<3, 2, QN_I8_LMIN>;
 }
