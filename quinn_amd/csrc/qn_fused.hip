@@ -1244,7 +1244,7 @@ size_t qn_fused_workspace(const qn_desc* d, int B, int Nb, int want_grad, int dt
     plan(d, B, Nb, want_grad, &a);
     size_t tot = qn_align((size_t)B * a.nsplit * sizeof(double));
     if (want_grad) tot += qn_align((size_t)B * a.nsplit * d->p * sizeof(double)) + qn_align((size_t)B * a.nsplit * sizeof(int));
-    return tot + 256;
+    return tot + 1024;              // (+ a scratch area diagnostic builds write their stamps to)
 }
 
 int qn_fused_parts(const qn_desc* d, int B, int Nb) {

@@ -67,11 +67,14 @@ __host__ __device__ constexpr size_t bwd_lds_bytes(int dp, int nhid) {
     return sizeof(double) * (size_t)bwd_head_doubles(dp, nhid) + (size_t)(2 * (nhid - 1) + 2) * LAYER_BYTES;
 }
 
-__device__ __forceinline__ void slice4_scaled(const double (&a)[4], double scale, int (&S)[NS]) {
+// `magic`: kMagic held in a register pair the compiler cannot see through (a known constant makes it emit v_fmac_f64 behind
+// a move that re-materialises the addend: with one wave per SIMD every instruction is paid in full; tools/ubench_xpose.hip)
+__device__ __forceinline__ void slice4_scaled(const double (&a)[4], double scale, double magic, int (&S)[NS]) {
     int lo[4], hi[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const double x = fma(a[r], scale, kMagic);
+        double x;                                                   // (one v_fma_f64; see above)
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(x) : "v"(a[r]), "s"(scale), "v"(magic));
         lo[r] = __double2loint(x);
         hi[r] = __double2hiint(x);
     }
@@ -132,6 +135,67 @@ __device__ __forceinline__ double recombine(const v4i (&acc)[NLEV], int r) {
 #pragma unroll
     for (int l = ((NLEV & 1) ? NLEV - 3 : NLEV - 4); l >= 0; l -= 2) ts = fma(ts, 65536.0, (double)(acc[l][r] + (acc[l + 1][r] << 8)));
     return ts;
+}
+
+// The same for the four elements of a tile, STAGE-MAJOR: every step is written for all four elements before the next step,
+// so that a wave that is alone on its SIMD always has four independent instructions between a result and its use (written
+// element by element the compiler keeps each element's dependent chain together and the wave waits out every latency).
+template <int NLEV>
+__device__ __forceinline__ void recombine4(const v4i (&acc)[NLEV], double (&ts)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ts[r] = (NLEV & 1) ? (double)acc[NLEV - 1][r] : (double)(acc[NLEV - 2][r] + (acc[NLEV - 1][r] << 8));
+#pragma unroll
+    for (int l = ((NLEV & 1) ? NLEV - 3 : NLEV - 4); l >= 0; l -= 2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ts[r] = fma(ts[r], 65536.0, (double)(acc[l][r] + (acc[l + 1][r] << 8)));
+}
+// qn_tanh_f64_tab64 (qn_math.h) for N arguments at once, stage-major; same operations, same results
+template <int N>
+__device__ __forceinline__ void tanh_tab64_n(const double (&z)[N], double (&out)[N], const double* __restrict__ tab, double magic52, double cm13) {
+    double ax[N], zm[N], Tt[N], bb[N], b2[N], pp[N], b3[N], tb[N], num[N], den[N], y0[N], e0[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) asm("v_min_f64 %0, |%1|, %2" : "=v"(ax[r]) : "v"(z[r]), "s"(20.0));
+#pragma unroll
+    for (int r = 0; r < N; ++r) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(zm[r]) : "v"(ax[r]), "s"(64.0), "v"(magic52));      // magic52 = 1.5 * 2^52 (see slice4_scaled)
+#pragma unroll
+    for (int r = 0; r < N; ++r) Tt[r] = tab[__double2loint(zm[r])];
+#pragma unroll
+    for (int r = 0; r < N; ++r) bb[r] = fma(zm[r] - 6755399441055744.0, -0.015625, ax[r]);
+#pragma unroll
+    for (int r = 0; r < N; ++r) b2[r] = bb[r] * bb[r];
+#pragma unroll
+    for (int r = 0; r < N; ++r) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(pp[r]) : "v"(b2[r]), "s"(1.33333333333333333e-01), "v"(cm13));      // cm13 = -1/3
+#pragma unroll
+    for (int r = 0; r < N; ++r) b3[r] = bb[r] * b2[r];
+#pragma unroll
+    for (int r = 0; r < N; ++r) tb[r] = fma(b3[r], pp[r], bb[r]);
+#pragma unroll
+    for (int r = 0; r < N; ++r) num[r] = Tt[r] + tb[r];
+#pragma unroll
+    for (int r = 0; r < N; ++r) den[r] = fma(Tt[r], tb[r], 1.0);
+#pragma unroll
+    for (int r = 0; r < N; ++r) y0[r] = __builtin_amdgcn_rcp(den[r]);
+#pragma unroll
+    for (int r = 0; r < N; ++r) e0[r] = fma(-den[r], y0[r], 1.0);
+#pragma unroll
+    for (int r = 0; r < N; ++r) e0[r] = fma(e0[r], e0[r], e0[r]);
+#pragma unroll
+    for (int r = 0; r < N; ++r) y0[r] = fma(y0[r], e0[r], y0[r]);
+#pragma unroll
+    for (int r = 0; r < N; ++r) out[r] = __builtin_copysign(num[r] * y0[r], z[r]);
+}
+// quad_xpose for N words, step-major (a DPP move needs two wait states behind the instruction that wrote its source)
+template <int N>
+__device__ __forceinline__ void quad_xpose_n(const int (&x)[N], int (&out)[N], int selA, int selB) {
+    int y[N], z[N], w[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = __builtin_amdgcn_mov_dpp(x[i], 0xB1, 0xF, 0xF, true);
+#pragma unroll
+    for (int i = 0; i < N; ++i) z[i] = __builtin_amdgcn_perm(y[i], x[i], selA);
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = __builtin_amdgcn_mov_dpp(z[i], 0x4E, 0xF, 0xF, true);
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = __builtin_amdgcn_perm(w[i], z[i], selB);
 }
 
 // Stage chain `Wb`: thin layers as float64, every hidden matrix as digit planes of W (one scale per row) and of W^T (one
@@ -230,6 +294,10 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
     int* gx = reinterpret_cast<int*>(lds + offgx);
     const double* Wb = W + (int64_t)b * a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c = lane & 15;
+#ifdef QN_BWD8_STAMPS
+    long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
     qn_tanh_table64_stage(tanh_tab, tid, BWG);
     const bool w_bad = block_or(stage_bwd<NH, DP, LMIN>(lds, wq, wqT, Wb, a), red + 6);
     if (w_bad) {                                                        // the float64 kernel recomputes the whole chain
@@ -239,12 +307,15 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
         }
         return;
     }
+    QN_STAMP(10);
     const int lofs = c * H + 16 * (q ^ slot_swz(c));                    // this lane's 16 bytes inside a 16-row tile of a plane
     // stash write: this lane's transposed word = feature 16 t + 4 q + (c & 3) of rows 16 wave + 4 (c >> 2) .. + 3
     const int wofs = (4 * q + (c & 3)) * H + 16 * (wave ^ slot_swz(4 * q)) + 4 * (c >> 2);
     const int selA = (c & 1) ? 0x03070105 : 0x06020400, selB = (c & 2) ? 0x03020706 : 0x05040100;
     int bad_run = 0;
     double sse = 0.0;
+    double magic52 = 6755399441055744.0, magicS = kMagic, cm13 = -3.33333333333333333e-01;      // constants as opaque register pairs
+    asm volatile("" : "+v"(magic52), "+v"(magicS), "+v"(cm13));
 
     double dWacc[NM][4][4];                                             // rows 16 wave + 4 q + r, columns 16 ti + c
 #pragma unroll
@@ -280,10 +351,6 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
         for (int k = 0; k < NPROD; ++k) issue_product<LMIN>(k, acc, Af, Bf);
     };
 
-#ifdef QN_BWD8_STAMPS
-    long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    long long stamp_prev = __builtin_amdgcn_s_memtime();
-#endif
     // data of the NEXT iteration is fetched while the current one computes (an HBM / L2 round trip per iteration otherwise)
     double xn[DD], yn;
     int n_n;
@@ -323,16 +390,16 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
             int top = 0;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
+                double z[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = 16 * t + 4 * q + r;
-                    double z = lds[offb0 + j];
+                for (int r = 0; r < 4; ++r) z[r] = lds[offb0 + 16 * t + 4 * q + r];
 #pragma unroll
-                    for (int k = 0; k < DD; ++k) z = fma(lds[j * DP + k], xk[k], z);
-                    act[0][t][r] = qn_tanh_f64_tab64(z, tanh_tab);
-                }
+                for (int k = 0; k < DD; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z[r] = fma(lds[(16 * t + 4 * q + r) * DP + k], xk[k], z[r]);
+                tanh_tab64_n<4>(z, act[0][t], tanh_tab, magic52, cm13);
                 int S[NS];
-                slice4(act[0][t], S);
+                slice4_scaled(act[0][t], 0x1p46, magicS, S);
 #pragma unroll
                 for (int k = 0; k < NS; ++k) Bd[0][k][t] = S[k];
                 top |= top_digits_large(S[NS - 1]);
@@ -354,15 +421,23 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 if (t + 1 < T) mfma_tile(accs[(t + 1) & 1], plane + (t + 1) * 16 * H, Bd[l - 1]);
+                {
+                    double2 sc[4];
+                    double ts[4], z[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double2 sc = *reinterpret_cast<const double2*>(sb + 32 * t + 2 * r);
-                    act[l][t][r] = qn_tanh_f64_tab64(fma(recombine<NLEV>(accs[t & 1], r), sc.x, sc.y), tanh_tab);
-                    if (l == NM) pd = fma(lds[offWl + 16 * t + 4 * q + r], act[l][t][r], pd);
+                    for (int r = 0; r < 4; ++r) sc[r] = *reinterpret_cast<const double2*>(sb + 32 * t + 2 * r);
+                    recombine4<NLEV>(accs[t & 1], ts);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z[r] = fma(ts[r], sc[r].x, sc[r].y);
+                    tanh_tab64_n<4>(z, act[l][t], tanh_tab, magic52, cm13);
+                    if (l == NM) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pd = fma(lds[offWl + 16 * t + 4 * q + r], act[l][t][r], pd);
+                    }
                 }
                 if (l < NM) {
                     int S[NS];
-                    slice4(act[l][t], S);
+                    slice4_scaled(act[l][t], 0x1p46, magicS, S);
 #pragma unroll
                     for (int k = 0; k < NS; ++k) Bd[l][k][t] = S[k];
                     top |= top_digits_large(S[NS - 1]);
@@ -387,20 +462,22 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
             }
         }
         // ------------------------------------------------------------------ backward
-        double dz[T][4];
+        double dzb[2][T][4];                                            // dZ_{l+1} in dzb[(NH - 1 - l) & 1] (no copies between layers)
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double av = act[NH - 1][t][r];
                 accWl[t][r] = fma(delta, av, accWl[t][r]);
-                dz[t][r] = (lds[offWl + 16 * t + 4 * q + r] * delta) * fma(-av, av, 1.0);
+                dzb[0][t][r] = (lds[offWl + 16 * t + 4 * q + r] * delta) * fma(-av, av, 1.0);
             }
         if (q == 0) accBl += delta;
         QN_STAMP(3);
 #pragma unroll
         for (int l = NH - 1; l >= 1; --l) {
             // dz = dZ_{l+1} (gradient at the pre-activations of a_{l+1}); matrix W_l = planes l - 1; a_l = act[l - 1]
+            double (&dz)[T][4] = dzb[(NH - 1 - l) & 1];
+            double (&dzn)[T][4] = dzb[(NH - l) & 1];
             unsigned ex = 0;
 #pragma unroll
             for (int t = 0; t < T; ++t)
@@ -410,11 +487,15 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
             if (lane == 0) gx[wave] = (int)ex;
             // the transposed digit words of a_l need nothing from the other waves: formed ahead of the barrier (where the
             // wave would wait anyway), written behind it
-            int At[NS][T];
+            int At[NS * T];
+            {
+                int Ain[NS * T];
 #pragma unroll
-            for (int k = 0; k < NS; ++k)
+                for (int k = 0; k < NS; ++k)
 #pragma unroll
-                for (int t = 0; t < T; ++t) At[k][t] = quad_xpose(Bd[l - 1][k][t], selA, selB);
+                    for (int t = 0; t < T; ++t) Ain[k * T + t] = Bd[l - 1][k][t];
+                quad_xpose_n<NS * T>(Ain, At, selA, selB);
+            }
             __syncthreads();                                            // exponents visible; the previous stash readers are done
             QN_STAMP(4);
             int E = max(max(gx[0], gx[1]), max(gx[2], gx[3]));          // |dZ| < 2^(E - 1022) for the workgroup's 64 rows
@@ -425,16 +506,17 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
 #pragma unroll
             for (int k = 0; k < NS; ++k)
 #pragma unroll
-                for (int t = 0; t < T; ++t) *reinterpret_cast<int*>(SA + k * SLICE_BYTES + t * 16 * H + wofs) = At[k][t];
+                for (int t = 0; t < T; ++t) *reinterpret_cast<int*>(SA + k * SLICE_BYTES + t * 16 * H + wofs) = At[k * T + t];
             v4i D[NS];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                int S[NS];
-                slice4_scaled(dz[t], sl, S);
+                int S[NS], St[NS];
+                slice4_scaled(dz[t], sl, magicS, S);
+                quad_xpose_n<NS>(S, St, selA, selB);
 #pragma unroll
                 for (int k = 0; k < NS; ++k) {
                     D[k][t] = S[k];
-                    *reinterpret_cast<int*>(SD + k * SLICE_BYTES + t * 16 * H + wofs) = quad_xpose(S[k], selA, selB);
+                    *reinterpret_cast<int*>(SD + k * SLICE_BYTES + t * 16 * H + wofs) = St[k];
                 }
             }
             QN_STAMP(5);
@@ -454,18 +536,24 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
                 products(acc, Az, Bf);
             };
             auto dw_epilogue = [&](const v4i (&acc)[NLEV], int ti) {
+                double ts[4];
+                recombine4<NLEV>(acc, ts);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    dWacc[l - 1][ti][r] = fma(recombine<NLEV>(acc, r), sdw, dWacc[l - 1][ti][r]);
+                    dWacc[l - 1][ti][r] = fma(ts[r], sdw, dWacc[l - 1][ti][r]);
                     pin(dWacc[l - 1][ti][r]);
                 }
             };
-            double dzn[T][4];
             auto da_epilogue = [&](const v4i (&acc)[NLEV], int t) {
+                double ts[4], g[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] = sT[16 * t + r] * rs;
+                recombine4<NLEV>(acc, ts);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] *= fma(-act[l - 1][t][r], act[l - 1][t][r], 1.0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double av = act[l - 1][t][r];
-                    dzn[t][r] = (recombine<NLEV>(acc, r) * (sT[16 * t + r] * rs)) * fma(-av, av, 1.0);
+                    dzn[t][r] = ts[r] * g[r];
                     pin(dzn[t][r]);
                 }
             };
@@ -505,11 +593,8 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
                 if (t + 1 < T) interleave_hint<NPROD, QN_BWD8_VPM_DA>();
                 __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dz[t][r] = dzn[t][r];
         }
+        double (&dz)[T][4] = dzb[(NH - 1) & 1];                          // dZ_1
         // ------------------------------------------------------------------ first layer
         QN_STAMP(8);
 #pragma unroll
@@ -524,8 +609,8 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
     }
 
 #ifdef QN_BWD8_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        long long* dbg = reinterpret_cast<long long*>(partial + a.dbg_off);
+    if (lane == 0 && blockIdx.x == 0) {
+        long long* dbg = reinterpret_cast<long long*>(partial + a.dbg_off) + 12 * wave;
         for (int k = 0; k < 12; ++k) dbg[k] = stamp_acc[k];
     }
 #endif

@@ -15,11 +15,15 @@ op = BatchedMLP(arch, x, y)
 for _ in range(3):
     s, g = op.sse_grad(W)
 torch.cuda.synchronize()
-need = op.workspace_bytes(64, 4096, True) - 256
-st = op._ws[need:need + 96].cpu().numpy().view(np.int64).astype(np.float64)
+need = op.workspace_bytes(64, 4096, True) - 1024
+st4 = op._ws[need:need + 4 * 96].cpu().numpy().view(np.int64).astype(np.float64).reshape(4, 12)
+st = st4[0]
 iters = 16
 names = ["loop top + x load", "forward: first layer", "forward: hidden layers", "last layer, residual, dz_NH", "exponents + barrier A", "slice dz, transposes, stash writes",
-         "barrier B", "dW + db products", "dA products + dz", "first layer backward", "-", "-"]
+         "barrier B", "dW + db products", "dA products + dz", "first layer backward", "staging (once per workgroup; x iters here)", "-"]
 print("cycles per iteration (wave 0 of workgroup 0; s_memtime ticks = 100 MHz x ... see total); total %.0f" % (st.sum() / iters))
 for n, v in zip(names, st):
     print("  %-36s %8.0f  %5.1f%%" % (n, v / iters, 100 * v / st.sum()))
+print("per wave (cycles per iteration):")
+for k, n in enumerate(names[:11]):
+    print("  %-36s " % n + " ".join("%7.0f" % (st4[w][k] / iters) for w in range(4)))

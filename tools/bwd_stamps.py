@@ -22,7 +22,7 @@ for _ in range(3):
     s, g = op.sse_grad(W)
 torch.cuda.synchronize()
 ws = op._ws
-need = op.workspace_bytes(64, 4096, True) - 256
+need = op.workspace_bytes(64, 4096, True) - 1024
 st = ws[need:need + 96].cpu().numpy().view(np.int64).reshape(1, 12).astype(np.float64)
 iters = 16
 names = ["loop top+x load", "forward layers", "last layer+resid", "barrier A(last)", "stash+barrier B(last)", "colsum last + dz", "hidden: barriers+stash", "hidden: dW MFMA", "hidden: db colsum", "hidden: dA MFMA+dz", "first-layer stage", "-"]
