@@ -46,17 +46,19 @@ def synthetic(n, d, noise=0.02, seed=0):
     return x, y
 
 
-def cpu_baseline(arch, x, y, budget_s=16.0):
+def cpu_baseline(arch, x, y, budget_s=24.0):
     """The oracle's sequential float64 path (one eval at a time: unflatten -> Linear/tanh ->
     NegLogPost -> .item(), as the reference does) on this host's cores; bounded sample.
-    Timed with 1 thread and with this box's CPU share (<= 16 threads); the faster is `value`."""
+    Timed with 1 thread, 16 threads and os.cpu_count() threads; the fastest is `value`."""
     from oracle import mlp_ref
     mod = mlp_ref.build_module(mlp_ref.MLPSpec(arch.dims, arch.activ))
     yd = [v for v in y]
     ws = [0.1 * np.random.RandomState(1000 + c).randn(arch.nparams) for c in range(16)]
-    share = max(1, min(os.cpu_count() or 1, 16))
+    ncpu = os.cpu_count() or 1
+    counts = sorted({1, min(16, ncpu), ncpu})
     rates = {}
-    for nt in sorted({1, share}):
+    old_threads = torch.get_num_threads()
+    for nt in counts:
         torch.set_num_threads(nt)
         for i in range(10):
             mlp_ref.logpost(mod, ws[i % 16], x, yd, SIGMA)
@@ -66,16 +68,18 @@ def cpu_baseline(arch, x, y, budget_s=16.0):
             mlp_ref.logpost(mod, ws[n % 16], x, yd, SIGMA)
             n += 1
             el = time.perf_counter() - t0
-            if el > budget_s / 2 or n >= 20000:
+            if el > budget_s / len(counts) or n >= 20000:
                 break
         rates[nt] = (n / el, n, el)
+    torch.set_num_threads(old_threads)
     best = max(rates, key=lambda k: rates[k][0])
     r, n, el = rates[best]
     return {"value": r, "unit": "log-posterior evals/s", "cores": best, "kind": "port",
             "sample": f"{n} sequential float64 evals of the same workload (one chain at a time, N={x.shape[0]}, "
                       f"3x64 tanh MLP) in {el:.1f} s with {best} torch thread(s); "
                       + ", ".join(f"{k} thr: {v[0]:.1f}/s" for k, v in sorted(rates.items())),
-            "host_cpus": os.cpu_count()}
+            "by_threads": {str(k): v[0] for k, v in sorted(rates.items())},
+            "host_cpus": ncpu}
 
 
 def extras(op, arch, batches, args):
@@ -162,6 +166,9 @@ def parse_args():
                     help="kernel family (fused_dp: the float64-MFMA fused kernels, without the sliced int8-product forward)")
     ap.add_argument("--graph", type=int, default=-1, help="capture this many consecutive steps in one HIP graph and "
                     "replay it (0 = direct launches, -1 = the largest divisor of --steps up to 50)")
+    ap.add_argument("--settle-ms", type=float, default=250.0, help="untimed run of the step before the timed region until the GPU "
+                    "clock has settled (it ramps up over the first ~500 launches of a fresh process: the same kernel takes 97 us "
+                    "right after start-up and 80 us from then on, profiles/r03_clock_ramp_kernel_trace.txt); 0 = off")
     ap.add_argument("--spread", type=int, default=20, help="extra replays of the dominant kernel alone, after the timed "
                     "region, for roofline.kernel_ms_min / _median / _max")
     return ap.parse_args()
@@ -229,7 +236,9 @@ def main():
     for i in range(args.warmup):
         out = run(batches[i % NBATCH])
     if args.graph < 0:
-        args.graph = max(g for g in range(1, 51) if args.steps % g == 0)
+        # the largest divisor of --steps up to 50 that leaves at least two replays in the timed region
+        cap = min(50, max(1, args.steps // 2))
+        args.graph = max(g for g in range(1, cap + 1) if args.steps % g == 0)
         if args.graph == 1:
             args.graph = 0
 
@@ -251,6 +260,19 @@ def main():
     if args.graph:
         assert args.steps % args.graph == 0
         graph, out = capture(run, args.graph)
+    # untimed: the step itself, replayed until the clock of a freshly started GPU has settled
+    settle_steps = 0
+    if args.settle_ms > 0:
+        t_s = time.perf_counter()
+        while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
+            if args.graph:
+                graph.replay()
+                settle_steps += args.graph
+            else:
+                for i in range(10):
+                    out = run(batches[i % NBATCH])
+                settle_steps += 10
+            torch.cuda.synchronize(dev)
     barrier()
     nlaunch = args.steps // args.graph if args.graph else args.steps
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlaunch)]
@@ -314,22 +336,36 @@ def main():
         ach = nloc * flops / (kern["kernel_ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
         path = op.path(nloc, N, want_grad)
-        traffic = None
+        # which kernel the step really dispatches, and what binds it
+        fam = {1: "generic", 2: "fused"}.get(path, str(path))
+        i8 = fam == "fused" and args.dtype == "f64" and args.path != "fused_dp"
+        if fam == "fused":
+            kernel = ("k_fused_bwd_i8" if i8 else "k_fused_bwd_f64") if want_grad else ("k_fused_fwd_i8" if i8 else "k_fused_fwd_f64")
+        else:
+            kernel = "layer-wise kernels (qn_generic.hip)"
+        kpath = {"k_fused_fwd_i8": "fused_i8", "k_fused_bwd_i8": "fused_i8_bwd", "k_fused_fwd_f64": "fused_dp", "k_fused_bwd_f64": "fused_dp_bwd"}.get(kernel, fam)
+        # int8 matrix work the sliced kernels execute: 26 kept digit products per 64 x 64 product and 16 rows
+        # (v_mfma_i32_16x16x64_i8: 32768 ops in 16 cycles per SIMD -> 5.03 Pop/s dense on 256 CUs at 2.4 GHz)
+        mfmas_per_group = 4 * 26 * (6 if want_grad else 2) + (2 * 6 if want_grad else 0)   # per 16 data rows: 64 x 64 products (+ bias row sums)
+        i8_ops = nloc * (N / 16) * mfmas_per_group * 32768 if i8 else None
+        traffic = traffic_src = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        pfile = os.path.join(ROOT, "profiles", "pmc_busy.json")
         if os.path.exists(tfile) and nloc == CHAINS:
             # HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
-            # correction, + WRITE_SIZE), recorded by tools/prof_traffic.sh for this kernel / config
-            fam = {1: 'generic', 2: 'fused'}.get(path)
-            if fam == 'fused' and args.kind == 'logpost' and args.dtype == 'f64' and args.path != 'fused_dp':
-                fam = 'fused_i8'                       # the sliced int8-product forward (csrc/qn_fused_i8.hip)
-            key = f"{args.kind}_{args.dtype}_{fam}"
-            traffic = json.load(open(tfile)).get(key, {}).get("hbm_bytes_per_launch")
+            # correction, + WRITE_SIZE), recorded by tools/prof_traffic.sh for this kernel / config: NOT of this run
+            key = f"{args.kind}_{args.dtype}_{kpath}"
+            ent = json.load(open(tfile)).get(key, {})
+            traffic = ent.get("hbm_bytes_per_launch")
+            traffic_src = f"profiles/hbm_traffic.json[{key}] (separate rocprofv3 --pmc passes of this command, round {ent.get('round', '?')})" if traffic else None
+        busy = {}
+        if os.path.exists(pfile):
+            busy = json.load(open(pfile)).get(kernel, {})
         per_gpu = f"{CHAINS} AMCMC chains/GPU" if args.scaling == "weak" else f"{CHAINS} AMCMC chains in total ({nloc} on rank 0)"
         cfg = {"workload": f"configs[1]: {per_gpu}, 3x64 tanh MLP (p=8513), N=4096 1-D regression; step = batched "
                            + ("log-posterior+gradient" if want_grad else "log-posterior") + " of all chains",
                "chains_total": total, "chains_rank0": nloc, "N": N, "dims": list(DIMS),
-               "kind": args.kind, "kernel_path": {1: "generic", 2: "fused"}.get(path, str(path)) + (
-                   " (float64 MFMA kernels)" if args.path == "fused_dp" else ""),
+               "kind": args.kind, "kernel_path": kpath, "kernel": kernel, "settle_ms": args.settle_ms, "settle_steps": settle_steps,
                "launch": (f"HIP graph of {args.graph} steps, replayed {args.steps // args.graph}x" if args.graph
                           else "direct launches"),
                "parallelism": f"chains sharded x{world}, no data-path collective, one all_gather at the end"}
@@ -341,9 +377,24 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": cfg,
-            "roofline": dict({"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                              "traffic": traffic, "flops_per_eval": flops, "evals_per_launch": nloc,
-                              "step_device_ms": step_dev_ms}, **kern),
+            "roofline": dict({
+                # what binds the dispatched kernel: the int8-slice kernels are bound by vector-instruction ISSUE (float64 VALU:
+                # recombination, tanh, slicing) with the hidden GEMMs on the int8 matrix pipe beside it; the float64-MFMA
+                # kernels by the float64 pipe that MFMA and VALU share
+                "bound": "mfma", "bound_detail": "valu+i8mfma" if i8 else ("f64mfma" if fam == "fused" else "f64 valu/mfma + hbm (layer-wise)"),
+                "arith": ("47-bit operand slices (2^-47 of the row / activation scale), exact int8 products, float64 accumulation"
+                          if i8 else args.dtype),
+                # yardstick shared by every kernel of this repo: ALGORITHMIC float64 flops of the evaluation against
+                # the float64 MFMA peak -- for the int8-slice kernels a float64-EQUIVALENT rate, not work done on that pipe
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "yardstick": "algorithmic float64 flops / kernel time vs the float64 MFMA peak (float64-equivalent for the int8-slice kernels)",
+                "frac_step": nloc * flops / (t_max / args.steps) / 1e12 / peak,
+                "int8_pipe": ({"ops_per_launch": i8_ops, "achieved_pops": i8_ops / (kern["kernel_ms"] * 1e-3) / 1e15, "peak_pops": 5.03,
+                               "frac": i8_ops / (kern["kernel_ms"] * 1e-3) / 1e15 / 5.03} if i8 else None),
+                "pmc": dict(busy, source="profiles/pmc_busy.json (rocprofv3 --pmc passes of this command, committed with the profile "
+                                         "it was taken from; not of this run)") if busy else None,
+                "traffic": traffic, "traffic_source": traffic_src, "flops_per_eval": flops, "evals_per_launch": nloc,
+                "step_device_ms": step_dev_ms}, **kern),
         }
         if world == 1 and not args.no_extras:
             res["extras"] = extras(op, arch, batches, args)

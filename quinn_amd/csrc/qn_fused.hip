@@ -135,7 +135,8 @@ template <int H, int G, int ACT, int DP, int NT, int OM = OMAX>
 __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, const double* __restrict__ W,
                                                       const double* __restrict__ X, const double* __restrict__ Y,
                                                       const int32_t* __restrict__ row_idx,
-                                                      double* __restrict__ pred_out, double* __restrict__ partial) {
+                                                      double* __restrict__ pred_out, double* __restrict__ partial,
+                                                      unsigned long long* __restrict__ arrive, double* __restrict__ sse_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     constexpr int T = H / 16;
@@ -306,10 +307,10 @@ __global__ __launch_bounds__(NT, NT / 128) void k_fused_fwd_f64(FusedArgs a, con
     sse = wave_sum(sse);
     if (lane == 0) red[wave] = sse;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {                        // (the first wave, every lane with the same sum)
         double s = 0.0;
         for (int w = 0; w < NT / 64; ++w) s += red[w];
-        partial[(int64_t)b * a.nsplit + split] = s;
+        qn_sse_finish(partial, arrive, sse_out, b, split, a.nsplit, s);
     }
 }
 
@@ -347,7 +348,9 @@ __global__ __launch_bounds__(NTS, 1) void k_fused_fwd_stream_f64(FusedArgs a, co
                                                                    const double* __restrict__ Y,
                                                                    const int32_t* __restrict__ row_idx,
                                                                    double* __restrict__ pred_out,
-                                                                   double* __restrict__ partial) {
+                                                                   double* __restrict__ partial,
+                                                                   unsigned long long* __restrict__ arrive,
+                                                                   double* __restrict__ sse_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     constexpr int H = HS, T = H / 16, NT = NTS;
@@ -518,10 +521,10 @@ __global__ __launch_bounds__(NTS, 1) void k_fused_fwd_stream_f64(FusedArgs a, co
     sse = wave_sum(sse);
     if (lane == 0) red[wave] = sse;
     __syncthreads();
-    if (tid == 0) {
+    if (threadIdx.x < 64) {                        // (the first wave, every lane with the same sum)
         double s = 0.0;
         for (int w = 0; w < NT / 64; ++w) s += red[w];
-        partial[(int64_t)b * a.nsplit + split] = s;
+        qn_sse_finish(partial, arrive, sse_out, b, split, a.nsplit, s);
     }
 }
 
@@ -1242,7 +1245,7 @@ bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtyp
 size_t qn_fused_workspace(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
     FusedArgs a;
     plan(d, B, Nb, want_grad, &a);
-    size_t tot = qn_align((size_t)B * a.nsplit * sizeof(double));
+    size_t tot = qn_align((size_t)B * a.nsplit * sizeof(double)) + qn_align((size_t)B * sizeof(unsigned long long));    // partials | arrivals
     if (want_grad) tot += qn_align((size_t)B * a.nsplit * d->p * sizeof(double)) + qn_align((size_t)B * a.nsplit * sizeof(int));
     return tot + 1024;              // (+ a scratch area diagnostic builds write their stamps to)
 }
@@ -1266,7 +1269,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
     a.p = d->p; a.B = B; a.N = N; a.Nb = Nb; a.d = d->dims[0]; a.o = d->dims[d->nlayers]; a.nhid = nhid;
     a.act = d->act; a.has_bias = d->has_bias;
     plan(d, B, Nb, want_grad, &a);
-    const size_t npart = qn_align((size_t)B * a.nsplit * sizeof(double));
+    const size_t npart = qn_align((size_t)B * a.nsplit * sizeof(double)) + qn_align((size_t)B * sizeof(unsigned long long));
     const size_t nslab = want_grad ? qn_align((size_t)B * a.nsplit * d->p * sizeof(double)) : 0;
     const size_t need = npart + nslab + (want_grad ? qn_align((size_t)B * a.nsplit * sizeof(int)) : 0);
     if (need > ws_bytes) {
@@ -1278,6 +1281,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
     a.dbg_off = (int64_t)(need / sizeof(double));          // the 256 spare bytes behind the slabs
     size_t lds_bytes = lds_need(H, a.d, a.o, nhid, want_grad);
     dim3 grid(qn_fused_grid(a.nsplit, B));
+    bool summed = false;
     (void)hipGetLastError();
     if (!want_grad) {
         fwd_fn kern = pick_fwd(H, a.act, padded_d(a.d), a.o);
@@ -1290,8 +1294,15 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
             return QN_EUNSUPPORTED;
         }
         if (int rc = arm_lds(reinterpret_cast<const void*>(kern))) return rc;
+        // the chain's SSE is summed by the last of its workgroups to finish (qn_sse_finish), unless the caller wants the parts
+        unsigned long long* arrive = partial == sse ? nullptr :
+            reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + qn_align((size_t)B * a.nsplit * sizeof(double)));
+#ifdef QN_NO_ARRIVE
+        arrive = nullptr;                                   // A/B builds: the separate k_sum_partials launch
+#endif
+        summed = arrive != nullptr;
         hipLaunchKernelGGL(kern, grid, dim3(H == HS ? NTS : WG), lds_bytes, st, a, (const double*)W,
-                           (const double*)X, (const double*)Y, row_idx, (double*)pred, partial);
+                           (const double*)X, (const double*)Y, row_idx, (double*)pred, partial, arrive, sse);
     } else {
         bwd_fn kern = pick_bwd(H, nhid, d->act);
         if (!kern) {
@@ -1317,7 +1328,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
         hipLaunchKernelGGL(k_grad_reduce, dim3(gx, B), dim3(256), 0, st, slab, a.nsplit, d->p, B, (double*)gradW,
                            (const double*)partial, sse);
     }
-    if (!want_grad && partial != sse) hipLaunchKernelGGL(k_sum_partials, dim3((B + 63) / 64), dim3(64), 0, st, partial, a.nsplit, B, sse);
+    if (!want_grad && partial != sse && !summed) hipLaunchKernelGGL(k_sum_partials, dim3((B + 63) / 64), dim3(64), 0, st, partial, a.nsplit, B, sse);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }

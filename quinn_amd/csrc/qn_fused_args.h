@@ -24,7 +24,68 @@ __device__ __forceinline__ bool qn_fused_wg(int nsplit, int B, int* b, int* spli
 }
 #endif
 
-using qn_fwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*);
+// ---- the SSE of a chain from the partial sums of its row splits, inside the forward kernel ----------------------------
+// The LAST workgroup of a chain to finish adds the chain's nsplit partial sums (left to right: bit for bit what the
+// separate k_sum_partials launch wrote): one dependent launch fewer per log-posterior step (BASELINE configs[1]: ~2 us of
+// a 82 us step at a settled clock; the 14 us the round-2 bench line showed between step and kernel were mostly the GPU clock
+// still ramping up during the timed region, profiles/r03_*).
+//   arrive[b]: {QN_ARRIVE_MAGIC : 48 | arrivals of the running launch : 16}.  Anything else (a fresh workspace, bytes another
+//   call left there) counts as "no arrival yet", so the caller has nothing to initialise; the last arriver leaves
+//   {MAGIC, 0}.  (Workspace garbage that happens to equal MAGIC in its top 48 bits -- 2^-48 per chain and first use --
+//   would be taken for a count.)
+//   Memory order: partial[] and arrive[] are only touched with agent-scope atomics, which are performed at the agent's
+//   coherence point, never in a non-coherent cache; a workgroup's partial-sum store is acknowledged (s_waitcnt vmcnt(0))
+//   before its arrival is issued, and the last arriver's loads depend on the value its arrival returned.  (An agent-scope
+//   RELEASE / ACQUIRE pair on the arrival adds an L2 write-back and an invalidate per workgroup: measured 3.5 us per launch
+//   SLOWER than the separate launch, A/B in one call; this protocol: 1.5-2 us faster than the separate launch.)
+#ifdef __HIPCC__
+constexpr unsigned long long QN_ARRIVE_MAGIC = 0xFFF751A7C0DEull;           // (top 48 bits of a quiet-NaN pattern with a payload)
+// Called by ALL lanes of the workgroup's first wave (`value`: the workgroup's partial sum, the same in every lane).
+__device__ __forceinline__ void qn_sse_finish(double* __restrict__ partial, unsigned long long* __restrict__ arrive,
+                                              double* __restrict__ sse, int b, int split, int nsplit, double value) {
+    const int lane = threadIdx.x & 63;
+    if (!arrive) {                                                        // the caller sums (qn_mlp_sse_fwd_parts)
+        if (lane == 0) partial[(int64_t)b * nsplit + split] = value;
+        return;
+    }
+    unsigned count = 0;
+    if (lane == 0) {
+        __hip_atomic_store(&partial[(int64_t)b * nsplit + split], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): the store is acknowledged
+        unsigned long long old = __hip_atomic_fetch_add(&arrive[b], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old >> 16) == QN_ARRIVE_MAGIC) {
+            count = (unsigned)(old & 0xffff) + 1;
+        } else {
+            // first use of this slot (or bytes of another call): claim it; arrivals that raced with the claim retry against it
+            unsigned long long cur = __hip_atomic_load(&arrive[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                const unsigned long long next = (cur >> 16) == QN_ARRIVE_MAGIC ? cur + 1 : ((QN_ARRIVE_MAGIC << 16) | 1ull);
+                if (__hip_atomic_compare_exchange_strong(&arrive[b], &cur, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    count = (unsigned)(next & 0xffff);
+                    break;
+                }
+            }
+        }
+    }
+    count = (unsigned)__builtin_amdgcn_readfirstlane((int)count);
+    if (count != (unsigned)nsplit) return;
+    // the last workgroup of the chain: one load per lane (ONE round trip for up to 64 parts), summed left to right
+    double s = 0.0;
+    for (int base = 0; base < nsplit; base += 64) {
+        const int i = base + lane;
+        const double v = i < nsplit ? __hip_atomic_load(&partial[(int64_t)b * nsplit + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        const int n = nsplit - base < 64 ? nsplit - base : 64;
+        for (int k = 0; k < n; ++k) s += __shfl(v, k, 64);
+    }
+    if (lane == 0) {
+        sse[b] = s;
+        __hip_atomic_store(&arrive[b], QN_ARRIVE_MAGIC << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+#endif
+
+using qn_fwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*,
+                           unsigned long long*, double*);
 
 // sliced int8-product forward for 64-wide tanh networks (qn_fused_i8.hip): same grid, block and partial-sum
 // conventions as k_fused_fwd_f64<64, 2, tanh, DP, 256>

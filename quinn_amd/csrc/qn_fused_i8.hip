@@ -159,7 +159,8 @@ template <int DP, int LMIN, int OM>
 __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const double* __restrict__ W,
                                                         const double* __restrict__ X, const double* __restrict__ Y,
                                                         const int32_t* __restrict__ row_idx, double* __restrict__ pred_out,
-                                                        double* __restrict__ partial) {
+                                                        double* __restrict__ partial, unsigned long long* __restrict__ arrive,
+                                                        double* __restrict__ sse_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NLEV = 2 * (NS - 1) - LMIN + 1;       // levels LMIN .. 10
     double* lds = reinterpret_cast<double*>(smem);
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
     sse = wave_sum(sse);
     if (lane == 0) red[wave] = sse;
     __syncthreads();
-    if (threadIdx.x == 0) partial[(int64_t)b * a.nsplit + split] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x < 64) qn_sse_finish(partial, arrive, sse_out, b, split, a.nsplit, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
 }  // namespace

@@ -22,8 +22,10 @@ for kind in ("logpost", "grad"):
                 step += avg
         tot[c] = step
     kib = 2.0 * tot.get("FETCH_SIZE", 0.0) + tot.get("WRITE_SIZE", 0.0)
-    fam = "fused_i8" if any("fwd_i8" in k for k in detail) else "fused"      # (the sliced int8-product forward)
+    # key = bench.py's config.kernel_path: the sliced int8-product kernels or the float64-MFMA ones
+    fam = "fused_i8" if any("fwd_i8" in k for k in detail) else "fused_i8_bwd" if any("bwd_i8" in k for k in detail) else \
+        ("fused_dp_bwd" if kind == "grad" else "fused_dp")
     res[f"{kind}_f64_{fam}"] = {"hbm_bytes_per_launch": kib * 1024.0, "fetch_kib_raw": tot.get("FETCH_SIZE"),
-                                "write_kib": tot.get("WRITE_SIZE"), "detail_kib": detail}
+                                "write_kib": tot.get("WRITE_SIZE"), "detail_kib": detail, "round": int(os.environ.get("QN_ROUND", "3"))}
 json.dump(res, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
