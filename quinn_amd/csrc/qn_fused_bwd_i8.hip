@@ -220,47 +220,68 @@ __device__ __forceinline__ int stage_bwd(double* __restrict__ lds, unsigned char
     }
     if (tid == 0) lds[lbl] = nb ? chk(Wb[gbl]) : 0.0;
     const int q16 = lane & 15, m4 = q16 >> 2, g4 = q16 & 3;                // quad (m, g): k-slots 16 m + 4 g + {0..3}
+    // every matrix load is issued before the first one is sliced (one memory round trip instead of 2 (NH - 1))
+    double vall[NH - 1][2][4][4];
+#pragma unroll
+    for (int layer = 1; layer < NH; ++layer) {
+        const double* Wg = Wb + gHH + (int64_t)(layer - 1) * (H * H + nb * H);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = 16 * u + 4 * wave + (lane >> 4);
+            const double2* src = reinterpret_cast<const double2*>(Wg + row * H + 16 * m4 + 4 * g4);
+            const double2 v01 = src[0], v23 = src[1];
+            vall[layer - 1][0][u][0] = v01.x; vall[layer - 1][0][u][1] = v01.y; vall[layer - 1][0][u][2] = v23.x; vall[layer - 1][0][u][3] = v23.y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vall[layer - 1][1][u][r] = Wg[(16 * m4 + 4 * g4 + r) * H + row];
+        }
+    }
 #pragma unroll
     for (int layer = 1; layer < NH; ++layer) {
         const double* Wg = Wb + gHH + (int64_t)(layer - 1) * (H * H + nb * H);
 #pragma unroll
         for (int tr = 0; tr < 2; ++tr) {                                   // 0: planes of W (row scales), 1: planes of W^T (column scales)
             unsigned char* plane = (tr ? wqT : wq) + (layer - 1) * LAYER_BYTES;
-            double v[4][4];
+            double (&v)[4][4] = vall[layer - 1][tr];
+            // step-major over the thread's four items (see stage() of qn_fused_i8.hip)
+            double bias[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bias[u] = (tr == 0 && q16 == 0 && nb) ? Wg[H * H + 16 * u + 4 * wave + (lane >> 4)] : 0.0;
+            unsigned ex[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int row = 16 * u + 4 * wave + (lane >> 4);
-                if (tr == 0) {
-                    const double2* src = reinterpret_cast<const double2*>(Wg + row * H + 16 * m4 + 4 * g4);
-                    const double2 v01 = src[0], v23 = src[1];
-                    v[u][0] = chk(v01.x); v[u][1] = chk(v01.y); v[u][2] = chk(v23.x); v[u][3] = chk(v23.y);
-                } else {
+                ex[u] = 0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[u][r] = Wg[(16 * m4 + 4 * g4 + r) * H + row];       // (checked in the first pass)
+                for (int r = 0; r < 4; ++r) {
+                    if (tr == 0) chk(v[u][r]);
+                    ex[u] = max(ex[u], ((unsigned)__double2hiint(v[u][r]) & 0x7fffffffu) >> 20);
                 }
             }
+            row16_max_u32_n<4>(ex);
+            int e[4];
+            double an[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                e[u] = (int)ex[u] - 1022;                                  // 2^e > every |entry| of the row (of W or of W^T)
+                bad |= e[u] > I8_MAX_WEIGHT_EXP;
+                e[u] = e[u] < -900 ? -900 : e[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) an[u][r] = ldexp(v[u][r], -e[u]);
+            int S[4][NS];
+            slice4_n<4>(an, S);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int row = 16 * u + 4 * wave + (lane >> 4);
-                unsigned ex = 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ex = max(ex, ((unsigned)__double2hiint(v[u][r]) & 0x7fffffffu) >> 20);
-                int e = (int)row16_max_u32(ex) - 1022;                     // 2^e > every |entry| of the row (of W or of W^T)
-                bad |= e > I8_MAX_WEIGHT_EXP;
-                e = e < -900 ? -900 : e;
-                double an[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) an[r] = ldexp(v[u][r], -e);
-                int S[NS];
-                slice4(an, S);
                 unsigned char* dst = plane + row * H + 16 * (g4 ^ slot_swz(row)) + 4 * m4;
 #pragma unroll
-                for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(dst + k * SLICE_BYTES) = S[k];
+                for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(dst + k * SLICE_BYTES) = S[u][k];
                 if (q16 == 0) {
-                    const double sc = ldexp(1.0, e - 2 * QB + 8 * LMIN);  // integer sum (units of 256^LMIN) -> product with unit-scale digits
+                    const double sc = ldexp(1.0, e[u] - 2 * QB + 8 * LMIN);   // integer sum (units of 256^LMIN) -> product with unit-scale digits
                     if (tr == 0) {
                         lds[lsb + (layer - 1) * 2 * H + 2 * row] = sc;
-                        lds[lsb + (layer - 1) * 2 * H + 2 * row + 1] = nb ? chk(Wg[H * H + row]) : 0.0;
+                        lds[lsb + (layer - 1) * 2 * H + 2 * row + 1] = chk(bias[u]);
                     } else {
                         lds[lsT + (layer - 1) * H + row] = sc;
                     }
@@ -298,6 +319,21 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
     long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
+    // data of the NEXT iteration is fetched while the current one computes (an HBM / L2 round trip per iteration otherwise);
+    // the first fetch is in flight during the staging
+    double xn[DD], yn;
+    int n_n;
+    bool valid_n;
+    auto fetch = [&](int it) {
+        n_n = split * a.rows_per_split + it * 64 + 16 * wave + c;
+        valid_n = n_n < a.Nb;
+        const int nn = valid_n ? n_n : 0;
+        const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
+#pragma unroll
+        for (int k = 0; k < DD; ++k) xn[k] = X[rr * DD + k];
+        yn = Y[rr];
+    };
+    fetch(0);
     qn_tanh_table64_stage(tanh_tab, tid, BWG);
     const bool w_bad = block_or(stage_bwd<NH, DP, LMIN>(lds, wq, wqT, Wb, a), red + 6);
     if (w_bad) {                                                        // the float64 kernel recomputes the whole chain
@@ -351,20 +387,6 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
         for (int k = 0; k < NPROD; ++k) issue_product<LMIN>(k, acc, Af, Bf);
     };
 
-    // data of the NEXT iteration is fetched while the current one computes (an HBM / L2 round trip per iteration otherwise)
-    double xn[DD], yn;
-    int n_n;
-    bool valid_n;
-    auto fetch = [&](int it) {
-        n_n = split * a.rows_per_split + it * 64 + 16 * wave + c;
-        valid_n = n_n < a.Nb;
-        const int nn = valid_n ? n_n : 0;
-        const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
-#pragma unroll
-        for (int k = 0; k < DD; ++k) xn[k] = X[rr * DD + k];
-        yn = Y[rr];
-    };
-    fetch(0);
     // one tile's worth of matrix work: 6 fragment reads + the kept digit products into `acc`
     auto mfma_tile = [&](v4i (&acc)[NLEV], const unsigned char* tile, const v4i (&Bop)[NS]) {
         v4i Af[NS];

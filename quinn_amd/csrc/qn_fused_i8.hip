@@ -48,11 +48,15 @@
 
 namespace {
 
-// Stage chain `Wb`: thin layers as float64, hidden matrices as digit planes.  Returns whether this thread saw a weight
-// that is not finite and < 2^500.
+// Stage chain `Wb`: thin layers as float64, hidden matrices as digit planes, the tanh table.  Returns whether this thread saw
+// a weight that is not finite and < 2^500.
+// Every global load of the staging is issued before the first result is used, the next hidden matrix's while the current
+// one is sliced: the first version fetched the table, the thin pieces and each matrix one after the other -- five memory
+// round trips, most of the ~6.5 us a workgroup spent here (8 % of a cfg2 launch; with 8 chains per launch, where a
+// workgroup has ONE iteration of rows behind its staging, 30 %).
 template <int DP, int LMIN>
-__device__ __forceinline__ int stage(double* __restrict__ lds, unsigned char* __restrict__ wq,
-                                     const double* __restrict__ Wb, const FusedArgs& a) {
+__device__ __forceinline__ int stage(double* __restrict__ lds, unsigned char* __restrict__ wq, double* __restrict__ tanh_tab,
+                                     const double* __restrict__ Wb, const FusedArgs& a, long long* stamps = nullptr) {
     int bad = 0;
     auto chk = [&](double v) { bad |= !qn_bounded(v); return v; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,55 +64,114 @@ __device__ __forceinline__ int stage(double* __restrict__ lds, unsigned char* __
     const int64_t gb0 = (int64_t)H * d, gHH = gb0 + nb * H;
     const int64_t gWl = gHH + (int64_t)(a.nhid - 1) * (H * H + nb * H), gbl = gWl + (int64_t)o * H;
     const int lb0 = H * DP, lWl = lb0 + H, lbl = lWl + OMAX * H, lsb = thin_doubles(DP);
-    for (int e = tid; e < H * DP; e += WGT) {
-        const int j = e / DP, k = e % DP;
-        lds[e] = k < d ? chk(Wb[j * d + k]) : 0.0;
-    }
-    for (int e = tid; e < H; e += WGT) lds[lb0 + e] = nb ? chk(Wb[gb0 + e]) : 0.0;
-    for (int e = tid; e < OMAX * H; e += WGT) lds[lWl + e] = e < o * H ? chk(Wb[gWl + e]) : 0.0;
-    for (int e = tid; e < OMAX; e += WGT) lds[lbl + e] = (nb && e < o) ? chk(Wb[gbl + e]) : 0.0;
+    const int q16 = lane & 15, m4 = q16 >> 2, g4 = q16 & 3;                // quad (m, g): features 16 m + 4 g + {0..3}
     // hidden matrices: a thread takes 4 consecutive input features of one row = the 4 bytes of one dword of every digit
     // plane (k-slot map of the header), the 16 lanes of a DPP row take one matrix row: the row's largest exponent is 4
     // DPP steps, the digits come out of slice4 already packed, 6 ds_write_b32 per item (byte stores of single digits
     // were 4-way bank conflicts and, with a ds_bpermute row maximum, 19 % of the kernel)
-    const int q16 = lane & 15, m4 = q16 >> 2, g4 = q16 & 3;                // quad (m, g): features 16 m + 4 g + {0..3}
-#ifdef QN_I8_SKIP_STAGE
-    if (a.nhid > 100)             // timing-only build: what the digit staging costs
-#endif
-    for (int layer = 1; layer < a.nhid; ++layer) {
+    auto load_matrix = [&](int layer, double (&v)[4][4]) {
         const double* Wg = Wb + gHH + (int64_t)(layer - 1) * (H * H + nb * H);
-        unsigned char* plane = wq + (layer - 1) * LAYER_BYTES;
-        double* sb = lds + lsb + (layer - 1) * 2 * H;
-        double v[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = 16 * u + 4 * wave + (lane >> 4);
             const double2* src = reinterpret_cast<const double2*>(Wg + row * H + 16 * m4 + 4 * g4);
             const double2 v01 = src[0], v23 = src[1];
-            v[u][0] = chk(v01.x); v[u][1] = chk(v01.y); v[u][2] = chk(v23.x); v[u][3] = chk(v23.y);
+            v[u][0] = v01.x; v[u][1] = v01.y; v[u][2] = v23.x; v[u][3] = v23.y;
         }
+    };
+    // ---- issue: first hidden matrix, thin pieces, table
+    double vA[4][4], vB[4][4];                                            // (two named sets: a runtime-indexed array would live in scratch)
+    load_matrix(1, vA);
+    constexpr int TPT = (QN_TANH_TAB64_N + WGT - 1) / WGT;
+    double tt[TPT];
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) tt[k] = tid + k * WGT < QN_TANH_TAB64_N ? qn_tanh_table64_g[tid + k * WGT] : 0.0;
+    constexpr int W0PT = (H * DP + WGT - 1) / WGT;                         // 1
+    double w0v[W0PT], wlv, b0v = 0.0, blv = 0.0;
+#pragma unroll
+    for (int k = 0; k < W0PT; ++k) {
+        const int e = tid + k * WGT, j = e / DP, kk = e % DP;
+        w0v[k] = (e < H * DP && kk < d) ? Wb[j * d + kk] : 0.0;
+    }
+    wlv = tid < o * H ? Wb[gWl + tid] : 0.0;                               // (OMAX * H = WGT)
+    if (tid < H && nb) b0v = Wb[gb0 + tid];
+    if (tid < OMAX && tid < o && nb) blv = Wb[gbl + tid];
+#ifdef QN_FWD8_STAMPS
+    stamps[0] = __builtin_amdgcn_s_memrealtime();                        // loads issued
+#endif
+    // ---- consume
+#pragma unroll
+    for (int k = 0; k < TPT; ++k)
+        if (tid + k * WGT < QN_TANH_TAB64_N) tanh_tab[tid + k * WGT] = tt[k];
+#pragma unroll
+    for (int k = 0; k < W0PT; ++k)
+        if (tid + k * WGT < H * DP) lds[tid + k * WGT] = chk(w0v[k]);
+    lds[lWl + tid] = chk(wlv);
+    if (tid < H) lds[lb0 + tid] = chk(b0v);
+    if (tid < OMAX) lds[lbl + tid] = chk(blv);
+#ifdef QN_FWD8_STAMPS
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    stamps[1] = __builtin_amdgcn_s_memrealtime();                        // table + thin pieces have arrived
+#endif
+    // (step-major over the thread's four items: exponents, row maxima, scaling, digits, stores -- written item by item the
+    // compiler keeps each item's dependent chain together and a matrix took 2.3 us per workgroup, three times its issue time)
+    auto slice_matrix = [&](int layer, const double (&v)[4][4]) {
+        const double* Wg = Wb + gHH + (int64_t)(layer - 1) * (H * H + nb * H);
+        unsigned char* plane = wq + (layer - 1) * LAYER_BYTES;
+        double* sb = lds + lsb + (layer - 1) * 2 * H;
+        double bias[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bias[u] = (q16 == 0 && nb) ? Wg[H * H + 16 * u + 4 * wave + (lane >> 4)] : 0.0;
+        unsigned ex[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ex[u] = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                chk(v[u][r]);
+                ex[u] = max(ex[u], ((unsigned)__double2hiint(v[u][r]) & 0x7fffffffu) >> 20);
+            }
+        }
+        row16_max_u32_n<4>(ex);
+        int e[4];
+        double an[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            // 2^e > every |W_ji| of the row, from the largest biased exponent field E: |w| < 2^(E - 1022)
+            e[u] = (int)ex[u] - 1022;
+            bad |= e[u] > I8_MAX_WEIGHT_EXP;                           // (an outlier weight: see qn_i8_slice.h)
+            e[u] = e[u] < -900 ? -900 : e[u];                          // (all-zero / denormal rows: any scale will do)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) an[u][r] = ldexp(v[u][r], -e[u]);    // exact, |an| < 1
+        int S[4][NS];
+        slice4_n<4>(an, S);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = 16 * u + 4 * wave + (lane >> 4);
-            unsigned ex = 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ex = max(ex, ((unsigned)__double2hiint(v[u][r]) & 0x7fffffffu) >> 20);
-            // 2^e > every |W_ji| of the row, from the largest biased exponent field E: |w| < 2^(E - 1022)
-            int e = (int)row16_max_u32(ex) - 1022;
-            bad |= e > I8_MAX_WEIGHT_EXP;                              // (an outlier weight: see qn_i8_slice.h)
-            e = e < -900 ? -900 : e;                                   // (all-zero / denormal rows: any scale will do)
-            double an[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) an[r] = ldexp(v[u][r], -e);    // exact, |an| < 1
-            int S[NS];
-            slice4(an, S);
             unsigned char* dst = plane + row * H + 16 * (g4 ^ slot_swz(row)) + 4 * m4;
 #pragma unroll
-            for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(dst + k * SLICE_BYTES) = S[k];
+            for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(dst + k * SLICE_BYTES) = S[u][k];
             if (q16 == 0) {
-                sb[2 * row] = ldexp(1.0, e - 2 * QB + 8 * LMIN);       // integer sum (in units of 256^LMIN) -> W_j . a
-                sb[2 * row + 1] = nb ? chk(Wg[H * H + row]) : 0.0;
+                sb[2 * row] = ldexp(1.0, e[u] - 2 * QB + 8 * LMIN);    // integer sum (in units of 256^LMIN) -> W_j . a
+                sb[2 * row + 1] = chk(bias[u]);
             }
+        }
+    };
+#ifdef QN_I8_SKIP_STAGE
+    if (a.nhid > 100)             // timing-only build: what the digit staging costs
+#endif
+    for (int layer = 1; layer < a.nhid; layer += 2) {                     // the next matrix is in flight while this one is sliced
+        if (layer + 1 < a.nhid) load_matrix(layer + 1, vB);
+        slice_matrix(layer, vA);
+#ifdef QN_FWD8_STAMPS
+        stamps[2] = __builtin_amdgcn_s_memrealtime();                    // first matrix sliced
+#endif
+        if (layer + 1 < a.nhid) {
+            if (layer + 2 < a.nhid) load_matrix(layer + 2, vA);
+            slice_matrix(layer + 1, vB);
         }
     }
     return bad;
@@ -173,9 +236,6 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
     unsigned char* wq = reinterpret_cast<unsigned char*>(lds + head_doubles(DP, NH));
     double* red = lds + offred;
     const double* Wb = W + (int64_t)b * a.p;
-    qn_tanh_table64_stage(tanh_tab, threadIdx.x, WGT);
-    const bool w_bad = block_or(stage<DP, LMIN>(lds, wq, Wb, a), red + 6);
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
 #ifdef QN_I8_STAGGER
@@ -208,7 +268,20 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
             for (int qo = 0; qo < OM; ++qo) yn[g][qo] = qo < o ? Y[rr * o + qo] : 0.0;
         }
     };
-    fetch(0);
+#ifdef QN_FWD8_STAMPS
+    const long long st0 = __builtin_readcyclecounter();          // diagnostic build (tools/fwd8_stamps.py): s_memrealtime-like clock per workgroup
+    const long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    fetch(0);                                                   // (in flight during the staging)
+#ifdef QN_FWD8_STAMPS
+    long long sst[4] = {0, 0, 0, 0};
+    const int sbad = stage<DP, LMIN>(lds, wq, tanh_tab, Wb, a, sst);
+    sst[3] = __builtin_amdgcn_s_memrealtime();                           // second matrix sliced
+    const bool w_bad = block_or(sbad, red + 6);
+    const long long rt1 = __builtin_amdgcn_s_memrealtime();
+#else
+    const bool w_bad = block_or(stage<DP, LMIN>(lds, wq, tanh_tab, Wb, a), red + 6);
+#endif
     for (int it = 0; it < a.iters; ++it) {
         double xk[G][DP], yk[G][OM];
         int nrow[G];
@@ -452,9 +525,20 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
                 }
             }
     }
+#ifdef QN_FWD8_STAMPS
+    const long long rt2 = __builtin_amdgcn_s_memrealtime();
+#endif
     sse = wave_sum(sse);
     if (lane == 0) red[wave] = sse;
     __syncthreads();
+#ifdef QN_FWD8_STAMPS
+    if (threadIdx.x == 0 && pred_out) {
+        double* dbg = pred_out + (int64_t)a.B * a.Nb * a.o - 8 * (int64_t)gridDim.x + 8 * (int64_t)blockIdx.x;     // the tail of the prediction buffer
+        dbg[0] = (double)rt0; dbg[1] = (double)rt1; dbg[2] = (double)rt2; dbg[3] = (double)__builtin_amdgcn_s_memrealtime();
+        for (int k = 0; k < 4; ++k) dbg[4 + k] = (double)sst[k];
+        (void)st0;
+    }
+#endif
     if (threadIdx.x < 64) qn_sse_finish(partial, arrive, sse_out, b, split, a.nsplit, (red[0] + red[1]) + (red[2] + red[3]));
 }
 

@@ -91,6 +91,48 @@ __device__ __forceinline__ void slice4(const double (&a)[4], int (&S)[NS]) {
     S[5] = __builtin_amdgcn_perm(r23, r01, 0x07060302);                 // top digit: two's complement as it stands
 }
 
+// slice4 for N groups of four values at once, STEP-MAJOR (every step for all groups before the next step): a wave that is
+// (almost) alone on its SIMD then always has N independent instructions between a result and its use
+template <int N>
+__device__ __forceinline__ void slice4_n(const double (&a)[N][4], int (&S)[N][NS]) {
+    int lo[N][4], hi[N][4], p01[N], q01[N], p23[N], q23[N], r01[N], r23[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double x = fma(a[i][r], 0x1p46, kMagic);
+            lo[i][r] = __double2loint(x);
+            hi[i][r] = __double2hiint(x);
+        }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        p01[i] = __builtin_amdgcn_perm(lo[i][1], lo[i][0], 0x05010400); q01[i] = __builtin_amdgcn_perm(lo[i][1], lo[i][0], 0x07030602);
+        p23[i] = __builtin_amdgcn_perm(lo[i][3], lo[i][2], 0x05010400); q23[i] = __builtin_amdgcn_perm(lo[i][3], lo[i][2], 0x07030602);
+        r01[i] = __builtin_amdgcn_perm(hi[i][1], hi[i][0], 0x05010400); r23[i] = __builtin_amdgcn_perm(hi[i][3], hi[i][2], 0x05010400);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        S[i][0] = __builtin_amdgcn_perm(p23[i], p01[i], 0x05040100) ^ 0x80808080;
+        S[i][1] = __builtin_amdgcn_perm(p23[i], p01[i], 0x07060302) ^ 0x80808080;
+        S[i][2] = __builtin_amdgcn_perm(q23[i], q01[i], 0x05040100) ^ 0x80808080;
+        S[i][3] = __builtin_amdgcn_perm(q23[i], q01[i], 0x07060302) ^ 0x80808080;
+        S[i][4] = __builtin_amdgcn_perm(r23[i], r01[i], 0x05040100) ^ 0x80808080;
+        S[i][5] = __builtin_amdgcn_perm(r23[i], r01[i], 0x07060302);
+    }
+}
+// maximum over each row of 16 lanes for N values at once, step-major (a DPP operand needs two wait states behind its producer)
+template <int N>
+__device__ __forceinline__ void row16_max_u32_n(unsigned (&x)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = max(x[i], (unsigned)__builtin_amdgcn_update_dpp(0, (int)x[i], 0xB1, 0xF, 0xF, false));
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = max(x[i], (unsigned)__builtin_amdgcn_update_dpp(0, (int)x[i], 0x4E, 0xF, 0xF, false));
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = max(x[i], (unsigned)__builtin_amdgcn_update_dpp(0, (int)x[i], 0x141, 0xF, 0xF, false));
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = max(x[i], (unsigned)__builtin_amdgcn_update_dpp(0, (int)x[i], 0x140, 0xF, 0xF, false));
+}
+
 // the kept digit products of a tile in issue order (weight digit major): product k is (wi, aj) with wi + aj >= LMIN
 __host__ __device__ constexpr int nprod(int lmin) {
     int n = 0;
