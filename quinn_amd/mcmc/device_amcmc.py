@@ -183,61 +183,138 @@ class DeviceAMCMC:
             raise ValueError(f"max_rows = {self.max_rows} is too small for tadapt = {self.tadapt}: need >= {need}")
         return self.max_rows
 
-    @staticmethod
-    def _compress_history(s, room, p):
-        """Compress the stored history of every chain that has fewer than `room` free rows (host-synchronising; called
-        once per adaptation window) into 2 r + 2 rows, r = kcap / 8, that carry the SAME weighted mean and -- up to rank
+    def _compress_history(self, s, room, p, step=0, spread=True):
+        """Compress the stored history of every chain that has fewer than `room` free rows (one device->host read per call;
+        called once per adaptation window) into 2 r + 2 rows, r = kcap / 8, that carry the SAME weighted mean and -- up to rank
         r -- the same weighted scatter about it.  With the rows h_i (multiplicities w_i, n_c = sum w_i, mean m_c) of
-        everything but the current state, B = diag(sqrt w)(H - m_c), Y = B Omega (Omega: p x r Gaussian) and the
-        eigen-decomposition Y^T Y = V L V^T, Q = Y V L^-1/2 is an orthonormal basis of range(Y) and
-            R = Q^T B = L^-1/2 V^T (Y^T B)       (r x p),      R^T R ~ B^T B
-        (exactly when rank(B) <= r; the directions a single randomised range pass finds otherwise).  The pseudo-states
+        everything but the current state, B = diag(sqrt w)(H - m_c), Y = B Omega (Omega: p x r Gaussian) and an orthonormal
+        basis Q of range(Y),
+            R = Q^T B       (r x p),      R^T R ~ B^T B
+        (exactly when rank(B) <= r; the directions a single randomised range pass finds otherwise).  Q by Cholesky-QR applied
+        twice (Gram matrices and factors in float64, two batched triangular solves), or, when Y^T Y is numerically singular
+        (rank(B) < r: short chains, p < r), Q = Y V Lambda^-1/2 from its eigen-decomposition with the null directions
+        dropped -- the same projector, hence the same scatter R^T R.  The pseudo-states
             m_c + R_j / sqrt 2,  m_c - R_j / sqrt 2   (multiplicity 1 each, j < r),      m_c   (multiplicity n_c - 2 r)
         have total multiplicity n_c, mean m_c and scatter R^T R: for the accept / proposal kernels they are ordinary
         history rows (integer multiplicities adding up to the number of samples; the parallel-axis term of a later,
-        different overall mean comes out by itself).  The current state keeps a row of its own behind them.  All chains
-        that need it are compressed in ONE batch of GEMMs (zero-padded to the longest history) + one batched eigh of
-        r x r matrices."""
+        different overall mean comes out by itself).  The current state keeps a row of its own behind them.  The chains of
+        a group (<= 16: bounds the padded copy) go through ONE set of batched GEMMs / factorisations, no per-chain host work.
+        spread: besides the chains that MUST be compressed now, the fullest of those that would come due within the next
+        windows are taken as well, up to C / 8 chains per call, so that the chains of a long run do not all come due in the
+        same window."""
         kcap = s['hist'].shape[1]
         r = max(8, kcap // 8)
-        kc = s['kcur'][s['par']]
-        full = [c for c in torch.nonzero(kc + 1 + room > kcap).flatten().tolist() if int(kc[c]) > 2 * r + 1]   # (device->host read)
+        par = s['par']
+        kc_h = s['kcur'][par].cpu().numpy().astype(np.int64)                    # (the one device->host read)
+        ok = kc_h > 2 * r + 1
+        must = np.nonzero((kc_h + 1 + room > kcap) & ok)[0]
+        sel = list(must)
+        if spread:
+            # chains that would come due within the next windows (one more window even if every step were accepted) are taken early while the call has room in
+            # its budget of C / 8 chains: evens out the windows in which many chains fill up together
+            high = kcap - 2 * room
+            budget = max(len(sel), -(-len(kc_h) // 8))
+            extra = [c for c in np.argsort(-kc_h) if ok[c] and kc_h[c] > high and c not in set(sel)]
+            sel += extra[:max(0, budget - len(sel))]
         dev = s['hist'].device
-        for g0 in range(0, len(full), 16):                                      # (groups bound the padded copy: 16 x kcap x p x 4 B)
-            grp = full[g0:g0 + 16]
-            ks = [int(kc[c]) for c in grp]                                      # current row of chain c; rows 0..k-1 are compressed
-            kmax = max(ks)
-            B = torch.zeros(len(grp), kmax, p, dtype=torch.float32, device=dev)
-            mcs, ncs = [], []
-            for i, (c, k) in enumerate(zip(grp, ks)):
-                w = s['mult'][c, :k].to(torch.float32)
-                nc = int(s['mult'][c, :k].sum())
-                H = s['hist'][c, :k, :p]
-                mc = (w[:, None] * H).sum(dim=0) / nc
-                B[i, :k] = w.sqrt()[:, None] * (H - mc)
-                mcs.append(mc)
-                ncs.append(nc)
+        for g0 in range(0, len(sel), 16):
+            grp = [int(c) for c in sel[g0:g0 + 16]]
+            idx = torch.as_tensor(grp, device=dev)
+            ks = torch.as_tensor(kc_h[grp], device=dev)                        # current row of chain c; rows 0..k-1 are compressed
+            # rows taken: the group's longest history rounded up to a multiple of kcap / 4 (a few fixed shapes: the BLAS / solver
+            # kernels prepare() has loaded; rows >= a chain's k are masked)
+            kmax = min(kcap - 1, -(-int(kc_h[grp].max()) // max(1, kcap // 4)) * max(1, kcap // 4))
+            live = torch.arange(kmax, device=dev)[None, :] < ks[:, None]        # [n, kmax]
+            mult = s['mult'][idx, :kmax] * live
+            ncs = mult.sum(dim=1)                                               # [n] int64
+            w = mult.to(torch.float32)
+            B = s['hist'][idx, :kmax, :p]                                       # [n, kmax, p] (a copy: advanced indexing)
+            B.masked_fill_(~live[:, :, None], 0.0)                              # (rows beyond a chain's k are uninitialised memory)
+            mc = torch.bmm(w[:, None, :], B)[:, 0, :] / ncs[:, None].to(torch.float32)
+            B -= mc[:, None, :]
+            B *= w.sqrt()[:, :, None]                                           # (rows beyond a chain's k: weight 0)
             gen = torch.Generator(device=dev)
-            gen.manual_seed(12345 + kmax)
+            gen.manual_seed((self.seed * 1000003 + (self.chain0 + grp[0]) * 7919 + int(step)) & (2 ** 62 - 1))   # sketch keyed by (seed, chain, step)
+            # (the sketch on the bf16 matrix cores was A/B-tested: 12.4 -> 11.3 ms per 8 chains, and the low-rank test lost variance)
             Y = B @ torch.randn(p, r, dtype=torch.float32, device=dev, generator=gen)          # [n, kmax, r]
-            lam, V = torch.linalg.eigh((Y.transpose(1, 2) @ Y).double())                        # [n, r], [n, r, r]
-            keep = lam > lam[:, -1:] * 1e-10                                                    # (rank(B) < r: drop the null directions)
-            scale = torch.where(keep, lam.clamp_min(1e-300).rsqrt(), torch.zeros_like(lam))
-            T = (V * scale[:, None, :]).transpose(1, 2).float()                                 # L^-1/2 V^T
-            R = (T @ (Y.transpose(1, 2) @ B)) * (0.5 ** 0.5)                                    # [n, r, p], already / sqrt 2
-            for i, (c, k) in enumerate(zip(grp, ks)):
-                h, m = s['hist'][c], s['mult'][c]
-                cur_row, cur_mult = h[k, :p].clone(), m[k].clone()
-                h[0:2 * r:2, :p] = mcs[i] + R[i]
-                h[1:2 * r:2, :p] = mcs[i] - R[i]
-                h[2 * r, :p] = mcs[i]
-                h[2 * r + 1, :p] = cur_row
-                m.zero_()
-                m[:2 * r] = 1
-                m[2 * r] = ncs[i] - 2 * r
-                m[2 * r + 1] = cur_mult
-                s['kcur'][s['par'], c] = 2 * r + 1
-        return len(full)
+            # Q^T = (L2 L1)^-1 Y^T: Cholesky-QR applied twice (the second pass restores the orthonormality the first loses
+            # when Y is ill-conditioned: with Q orthonormal to float32 accuracy R^T R can never exceed B^T B)
+            Yt = Y.transpose(1, 2)
+            L1, info = torch.linalg.cholesky_ex(Yt.double() @ Y.double())
+            ok_chol = bool((info == 0).all())
+            if ok_chol:
+                Qt = torch.linalg.solve_triangular(L1.to(torch.float32), Yt, upper=False)       # [n, r, kmax]
+                L2, info = torch.linalg.cholesky_ex(Qt.double() @ Qt.double().transpose(1, 2))
+                ok_chol = bool((info == 0).all())
+            if ok_chol:
+                Qt = torch.linalg.solve_triangular(L2.to(torch.float32), Qt, upper=False)
+                R = Qt @ B                                                                      # [n, r, p]
+            else:
+                # (the float32 Gram matrix: its rounding noise separates the zero eigenvalues of an exactly rank-deficient Y^T Y,
+                # on which the divide-and-conquer solver does not converge)
+                lam, V = torch.linalg.eigh((Yt @ Y).double())                                   # [n, r], [n, r, r]
+                keep = lam > lam[:, -1:] * 1e-10                                                # (rank(B) < r: drop the null directions)
+                scale = torch.where(keep, lam.clamp_min(1e-300).rsqrt(), torch.zeros_like(lam))
+                R = (V * scale[:, None, :]).transpose(1, 2).float() @ (Yt @ B)                  # L^-1/2 V^T (Y^T B)
+            R *= 0.5 ** 0.5
+            cur_rows, cur_mult = s['hist'][idx, ks, :p], s['mult'][idx, ks]                     # (copies)
+            s['hist'][idx, 0:2 * r:2, :p] = mc[:, None, :] + R
+            s['hist'][idx, 1:2 * r:2, :p] = mc[:, None, :] - R
+            s['hist'][idx, 2 * r, :p] = mc
+            s['hist'][idx, 2 * r + 1, :p] = cur_rows
+            s['mult'][idx] = 0
+            s['mult'][idx, :2 * r] = 1
+            s['mult'][idx, 2 * r] = (ncs - 2 * r).to(s['mult'].dtype)
+            s['mult'][idx, 2 * r + 1] = cur_mult
+            s['kcur'][par, idx] = 2 * r + 1
+        return len(sel)
+
+    def prepare(self, nmcmc, nchains):
+        """Set-up of the adapted phase ahead of a run of `nmcmc` steps of `nchains` chains: the two work buffers of the
+        history product (kept by the engine and reused by later runs of the same shape) and the first use of every library
+        path the adaptation / compression steps take (lazily initialised solvers and kernels).  `run` calls it itself;
+        calling it beforehand keeps that one-time cost (~120 ms at the first adaptation, ~450 ms at the first compression:
+        profiles/r02_amcmc_device_50k_steps_bounded_history.json, windows at 4.7 k and 1.7 k steps/s) out of the run.
+        Returns (coef, delta)."""
+        dev, C, p = self.dev, int(nchains), self.op.p
+        kcap, TB = self._kcap(nmcmc), int(self._L.qn_mcmc_hist_block_steps())
+        key = (C, kcap, TB, p)
+        if getattr(self, '_bufs', None) is not None and self._bufs[0] == key:
+            return self._bufs[1], self._bufs[2]
+        coef = torch.empty(C * ((kcap + 3) // 4 * 4 + 1) * TB, dtype=torch.float32, device=dev)
+        delta = torch.empty(C, TB, p, dtype=torch.float64, device=dev)
+        self._bufs = (key, coef, delta)
+        k = torch.zeros(C, dtype=torch.int32, device=dev)
+        torch.argsort(k, descending=True).to(torch.int32)
+        k.cpu()
+        if kcap < nmcmc + 1:
+            # the compression's GEMMs, factorisations and solves once at their real sizes (the BLAS / solver libraries pick
+            # and load their kernels per shape on first use)
+            # the compression itself once per group size it will meet (a straggler alone / a full group of the spread) on a
+            # dummy history: the BLAS / solver libraries pick and load kernels per shape on first use, and the caching
+            # allocator gets the blocks of the temporaries
+            r = max(8, kcap // 8)
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(1)
+            pstride = (p + 3) // 4 * 4
+            for n in sorted({1, min(16, max(1, -(-C // 8)))}):
+                fake = {'hist': torch.randn(n, kcap, pstride, dtype=torch.float32, device=dev, generator=gen),
+                        'mult': torch.ones(n, kcap, dtype=torch.int32, device=dev), 'par': 0}
+                for q4 in range(1, 5):                                          # every row-count bucket a compression can meet
+                    kf = min(kcap - 2, q4 * max(1, kcap // 4) - 1)
+                    if kf <= 2 * r + 1:
+                        continue
+                    fake['kcur'] = torch.full((2, n), kf, dtype=torch.int32, device=dev)
+                    fake['mult'].fill_(1)
+                    self._compress_history(fake, kcap, p, spread=False)
+                del fake
+            lam, V = torch.linalg.eigh(torch.eye(r, dtype=torch.float64, device=dev)[None] * torch.arange(1, r + 1, device=dev)[None, :, None])
+            del lam, V
+        idx = torch.zeros(2, dtype=torch.int64, device=dev)
+        h = torch.zeros(2, 8, 8, device=dev)
+        h[idx, 0:4:2, :4] = h[idx, 0:2, :4]
+        torch.cuda.synchronize(dev)
+        return coef, delta
 
     def _run_gen(self, nmcmc, param_ini, store_chain=True, verbose=False, chain_out=None):
         """The run as a generator: yields after every block of at most TB enqueued steps (nothing is awaited)."""
@@ -281,6 +358,8 @@ class DeviceAMCMC:
         TB = int(self._L.qn_mcmc_hist_block_steps())
         G = TB                                                              # steps per captured graph
         coef = delta = None
+        if nmcmc > max(self.t0, self.tadapt):                               # the run will adapt: buffers now, not at the first adaptation
+            coef, delta = self.prepare(nmcmc, C)
 
         fuse = self.fuse_propose
 
@@ -327,7 +406,16 @@ class DeviceAMCMC:
         while i < nmcmc:
             if kcap < nmcmc + 1 and i > 0:
                 # room for every step up to the next check (each may append a row); compress the chains that lack it
-                self._compress_history(s, min(nmcmc, (i // self.tadapt + 1) * self.tadapt) - i + 1, p)
+                if os.environ.get("QN_AMCMC_TIMING"):
+                    import time as _time
+                    torch.cuda.synchronize(dev); _tc = _time.perf_counter()
+                ncomp = self._compress_history(s, min(nmcmc, (i // self.tadapt + 1) * self.tadapt) - i + 1, p, step=i)
+                if os.environ.get("QN_AMCMC_TIMING"):
+                    torch.cuda.synchronize(dev); print("[timing] step %d: compression of %d chains %.1f ms" % (i, ncomp, 1e3 * (_time.perf_counter() - _tc)), flush=True, file=__import__("sys").stderr)
+            _tm = os.environ.get("QN_AMCMC_TIMING")                          # (diagnostic: synchronising timings of the window's phases)
+            if _tm:
+                import time as _time
+                torch.cuda.synchronize(dev); _t0 = _time.perf_counter()
             if i > self.t0 and i % self.tadapt == 0:
                 # adaptation (admcmc.py:66-67) = snapshot of the history x_0..x_i: n = i + 1 samples
                 scale = self.gamma * 2.4 ** 2 / p
@@ -338,8 +426,9 @@ class DeviceAMCMC:
                                  's_iso': float(np.sqrt(scale * 1e-8))}
                 graphs = {k: g for k, g in graphs.items() if k[0] != 'adapted'}   # new snapshot tensors: recapture
                 if coef is None:
-                    coef = torch.empty(C * ((kcap + 3) // 4 * 4 + 1) * TB, dtype=torch.float32, device=dev)
-                    delta = torch.empty(C, TB, p, dtype=f64, device=dev)
+                    coef, delta = self.prepare(nmcmc, C)
+            if _tm:
+                torch.cuda.synchronize(dev); print("[timing] step %d: snapshot / allocation %.1f ms" % (i, 1e3 * (_time.perf_counter() - _t0)), flush=True, file=__import__("sys").stderr)
             nrun = min(nmcmc, (i // self.tadapt + 1) * self.tadapt) - i     # up to the next adaptation
             adapted = state['snap'] is not None
             nfull, rest = divmod(nrun, G)
@@ -360,7 +449,11 @@ class DeviceAMCMC:
                 rest = nrun
             if adapted:
                 while rest > 0:
+                    if _tm and rest == nrun:
+                        torch.cuda.synchronize(dev); _t1 = _time.perf_counter()
                     block_adapted(min(rest, TB))
+                    if _tm and rest == nrun:
+                        torch.cuda.synchronize(dev); print("[timing] step %d: first adapted block of %d steps %.1f ms" % (i, min(rest, TB), 1e3 * (_time.perf_counter() - _t1)), flush=True, file=__import__("sys").stderr)
                     rest -= min(rest, TB)
                     yield
             else:

@@ -31,6 +31,7 @@ eng.run(20, ini, store_chain=True)                      # warm-up (first launche
 _a = torch.empty(C, NMCMC + 1, arch.nparams, dtype=torch.float64, device=op.device) if STORE else None
 _b = torch.empty(C, min(NMCMC + 1, MAXROWS), (arch.nparams + 3) // 4 * 4, dtype=torch.float32, device=op.device)
 del _a, _b
+eng.prepare(NMCMC, C)                                  # adapted-phase buffers + first use of the solver paths (set-up, untimed)
 marks = []
 
 
