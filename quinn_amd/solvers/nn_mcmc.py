@@ -95,7 +95,7 @@ class NN_MCMC(QUiNNBase):
         Build-only: nchains (C independent chains in lock-step), seeds (C ints; chain c then
             equals a reference run preceded by np.random.seed(seeds[c])).  With nchains=1 and
             seeds=None the global numpy RNG is used, exactly like the reference.
-            engine='device' (samplers 'amcmc' and 'hmc'): states, proposal factors and history stay on the
+            engine='device' (samplers 'amcmc', 'hmc' and 'mala'): states, proposal factors and history stay on the
             GPU, no host synchronisation per step (`quinn_amd.mcmc.device_amcmc`); same target and
             adaptation schedule, chains equal the host engine in distribution, not bit for bit.
             gather (multi-rank runs; chains are block-partitioned over the ranks): 'all' -- every rank ends with all
@@ -152,8 +152,11 @@ class NN_MCMC(QUiNNBase):
             elif sampler == 'hmc':
                 from ..mcmc.device_hmc import DeviceHMC
                 eng = DeviceHMC(op, datanoise, seed=seed0, chain0=lo, **sampler_params)
+            elif sampler == 'mala':
+                from ..mcmc.device_mala import DeviceMALA
+                eng = DeviceMALA(op, datanoise, seed=seed0, chain0=lo, **sampler_params)
             else:
-                raise ValueError("engine='device' is implemented for sampler='amcmc' and 'hmc'")
+                raise ValueError("engine='device' is implemented for sampler='amcmc', 'hmc' and 'mala'")
             if hi > lo:
                 res = eng.run(nmcmc, ini2[lo:hi], verbose=self.verbose and rank == 0)
             else:

@@ -166,3 +166,61 @@ def test_gaussian_posterior_moments():
     np.testing.assert_allclose(np.cov(ch.T), cov, rtol=0.15, atol=0.1 * np.abs(cov).max())
     lp_map = r['maxpost'].cpu().numpy()
     assert np.all(lp_map >= r['logpost'].cpu().numpy().max(axis=1) - 1e-9)
+
+
+def test_device_mala_step_equals_the_reference_langevin_step_on_the_kernel_momenta():
+    """`DeviceMALA` (one leapfrog step of the HMC kernels) against the reference's `MALA.sampler` formulas
+    (quinn/mcmc/mala.py:42-51) and MH ratio (mcmc.py:68-75), evaluated with the ORACLE's gradient on the momenta the kernel
+    drew; two network shapes, one of them the BASELINE configs[1] shape (the int8-slice gradient kernel)."""
+    from quinn_amd.mcmc.device_mala import DeviceMALA
+    for dims, eps in (((1, 8, 8, 1), 0.01), ((1, 64, 64, 64, 1), 0.002)):
+        x, y = _problem(N=40, d=dims[0])
+        sigma, seed, C = 0.2, 4321, 4
+        arch = MLPArch(dims, "tanh")
+        op = BatchedMLP(arch, x, y)
+        ini = 0.3 * np.random.RandomState(5).randn(C, arch.nparams)
+        eng = DeviceMALA(op, sigma, epsilon=eps, seed=seed, chain0=3)
+        assert eng.L == 1
+        r = eng.run(1, ini)
+        torch.cuda.synchronize()
+        cur = torch.as_tensor(ini, device="cuda")
+        _, g0 = op.sse_grad(cur)
+        mom, q1, kcur = _begin(op, cur, g0, sigma, eps, 3, eng.seed, 0)
+        mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, "tanh"))
+        yd = [v for v in y]
+        lp = lambda w: mlp_ref.logpost(mod, w, x, yd, sigma)
+        lpg = lambda w: mlp_ref.logpostgrad(mod, w, x, yd, sigma)
+        for c in range(C):
+            g_cur = lpg(ini[c])
+            pz = mom[c] - eps * g_cur / 2                               # undo the half kick: the N(0, I) draw itself
+            prop = ini[c] + 0.5 * eps ** 2 * g_cur + eps * pz           # mala.py:45
+            g_prop = lpg(prop)
+            k0 = np.sum(np.square(pz)) / 2                              # mala.py:48
+            k1 = np.sum(np.square(pz + eps * (g_cur + g_prop) / 2)) / 2   # mala.py:50-51
+            np.testing.assert_allclose(q1[c], prop, rtol=1e-12, atol=1e-14)
+            mh = np.exp((-lp(ini[c]) + k0) - (-lp(prop) + k1))
+            np.testing.assert_allclose(r['alphas'][c, 1].item(), mh, rtol=1e-8)
+            got = r['chain'][c, 1].cpu().numpy()
+            if not np.array_equal(got, ini[c]):
+                np.testing.assert_allclose(got, prop, rtol=1e-10, atol=1e-12)
+
+
+def test_device_mala_through_the_solver_matches_the_host_sampler_in_distribution():
+    """`NN_MCMC.fit(sampler='mala', engine='device')` against the host `MALA` on a small posterior: acceptance rate and the
+    stationary level of the log-posterior agree (different random streams: in distribution, not bit for bit)."""
+    from quinn_amd.nns.mlp import MLP
+    from quinn_amd.solvers.nn_mcmc import NN_MCMC
+    x, y = _problem(seed=2, N=64)
+    res = {}
+    for engine in ("host", "device"):
+        torch.manual_seed(0)
+        nn = MLP(1, 1, (6,), activ="tanh")
+        s = NN_MCMC(nn, verbose=False)
+        np.random.seed(11)
+        s.fit(x, y, zflag=False, datanoise=0.3, nmcmc=1500, param_ini=0.1 * np.ones(s.pdim), sampler="mala",
+              sampler_params={"epsilon": 0.02}, nchains=8, seeds=list(range(50, 58)), engine=engine)
+        r = s.mcmc_results
+        res[engine] = (np.mean(r["accrate"]), np.mean(np.asarray(r["logpost"])[:, 700:]))
+    (ah, lh), (ad, ld) = res["host"], res["device"]
+    assert 0.3 < ah < 1.0 and abs(ah - ad) < 0.08, (ah, ad)
+    assert abs(lh - ld) < 1.5, (lh, ld)
