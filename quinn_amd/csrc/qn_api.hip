@@ -223,13 +223,16 @@ struct PadMap {
 constexpr int PAD_SLOTS = 64;           // blocks per chain of k_pad_weights at most (one flag slot each)
 template <typename T> __device__ __forceinline__ bool pad_bounded(T v, T bound) { return (v < T(0) ? -v : v) < bound; }   // (NaN: false)
 template <typename T> __global__ void k_pad_weights(PadMap m, const T* __restrict__ W, T* __restrict__ Wp, const T* __restrict__ X,
-                                                    int64_t nx, T bound, int* __restrict__ flags) {
+                                                    int64_t nx, const T* __restrict__ Y, int64_t ny, T bound, int* __restrict__ flags) {
     // every block WRITES its own slot flags[(chain or B) * PAD_SLOTS + blockIdx.x] (no atomics, no memset node ahead of the kernel)
     const int b = blockIdx.y;
     int bad = 0;
     if (b == 0) {
         int xb = 0;
         for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nx; e += (int64_t)gridDim.x * blockDim.x) xb |= !pad_bounded(X[e], bound);
+        // (the targets too: an infinite target makes the last layer's dz infinite, and 0 . Inf = NaN in the padded columns of the
+        // backward pass where the reference's gradient is +-Inf)
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ny; e += (int64_t)gridDim.x * blockDim.x) xb |= !pad_bounded(Y[e], bound);
         xb = __syncthreads_or(xb);
         if (threadIdx.x == 0) flags[(int64_t)gridDim.y * PAD_SLOTS + blockIdx.x] = xb;
     }
@@ -379,7 +382,7 @@ int run_padded_t(const qn_desc* d, bool generic, int dtype, const T* W, const vo
     int gx = (int)((q->p + 255) / 256);
     const int nslots = gx > PAD_SLOTS ? PAD_SLOTS : gx;
     hipLaunchKernelGGL(k_pad_weights<T>, dim3(nslots, B), dim3(256), 0, st, m, W, Wp, static_cast<const T*>(X),
-                       (int64_t)N * d->dims[0], (T)std::ldexp(1.0, eb), flags);
+                       (int64_t)N * d->dims[0], static_cast<const T*>(Y), (int64_t)N * d->dims[L], (T)std::ldexp(1.0, eb), flags);
     const int rc = generic ? qn_generic_run(q, dtype, Wp, X, Y, row_idx, B, N, Nb, sse, pred, Gp,
                                             static_cast<char*>(ws) + head, ws_bytes - head, st)
                            : qn_fused_run(q, dtype, Wp, X, Y, row_idx, B, N, Nb, sse, pred, Gp,

@@ -1214,11 +1214,14 @@ bwd_fn pick_bwd(int H, int nhid, int act = QN_ACT_TANH) {
 // function free of non-stream API calls, so it can be captured into a HIP graph)
 int arm_lds(const void* fn) {
     static std::mutex mu;
-    static std::unordered_set<const void*> armed;
+    static std::unordered_set<uint64_t> armed;              // (kernel, device): the attribute is per device
+    int dev = 0;
+    QN_HIP_CHECK(hipGetDevice(&dev));
+    const uint64_t key = (uint64_t)(uintptr_t)fn * 64u + (uint64_t)(dev & 63);
     std::lock_guard<std::mutex> lock(mu);
-    if (armed.count(fn)) return QN_OK;
+    if (armed.count(key)) return QN_OK;
     QN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    armed.insert(fn);
+    armed.insert(key);
     return QN_OK;
 }
 

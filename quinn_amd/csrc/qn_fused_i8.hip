@@ -836,12 +836,15 @@ constexpr size_t i8gemm_lds(int kc) { return (size_t)kc * NS * 64 * 64 + sizeof(
 // API calls, so it can be captured into a HIP graph)
 int i8_arm(const void* fn, size_t bytes) {
     static std::mutex mu;
-    static std::unordered_set<const void*> armed;
+    static std::unordered_set<uint64_t> armed;              // (kernel, device): the attribute is per device
     if (bytes <= 64 * 1024) return QN_OK;
+    int dev = 0;
+    QN_HIP_CHECK(hipGetDevice(&dev));
+    const uint64_t key = (uint64_t)(uintptr_t)fn * 64u + (uint64_t)(dev & 63);
     std::lock_guard<std::mutex> lock(mu);
-    if (armed.count(fn)) return QN_OK;
-    QN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    armed.insert(fn);
+    if (armed.count(key)) return QN_OK;
+    QN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    armed.insert(key);
     return QN_OK;
 }
 }  // namespace

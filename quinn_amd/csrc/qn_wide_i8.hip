@@ -894,13 +894,23 @@ void wide_plan(int B, int Nb, WideArgs* a) {
     a->iters = rps / rows_it;
 }
 
+// Raise a kernel's dynamic-LDS limit ONCE per (kernel, device) to the hardware maximum: the bytes a launch asks for grow with
+// the number of hidden layers while the kernel templates do not depend on it (arming with the first caller's size left a
+// later, deeper network above the limit), and the attribute is per device.
 int wide_arm(const void* fn, size_t bytes) {
     static std::mutex mu;
-    static std::unordered_set<const void*> armed;
+    static std::unordered_set<uint64_t> armed;
+    if (bytes > 160 * 1024) {
+        qn_set_error("int8-slice kernel needs %zu bytes of LDS (limit 160 KB)", bytes);
+        return QN_EUNSUPPORTED;
+    }
+    int dev = 0;
+    QN_HIP_CHECK(hipGetDevice(&dev));
+    const uint64_t key = (uint64_t)(uintptr_t)fn * 64u + (uint64_t)(dev & 63);
     std::lock_guard<std::mutex> lock(mu);
-    if (armed.count(fn)) return QN_OK;
-    QN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    armed.insert(fn);
+    if (armed.count(key)) return QN_OK;
+    QN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    armed.insert(key);
     return QN_OK;
 }
 

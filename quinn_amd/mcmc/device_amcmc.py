@@ -178,7 +178,7 @@ class DeviceAMCMC:
         hold a compressed history, max_rows/4 + 2 rows, plus one window of new rows between two checks)."""
         if nmcmc + 1 <= self.max_rows:
             return nmcmc + 1
-        need = (4 * (self.tadapt + 4) + 2) // 3
+        need = max(64, (4 * (self.tadapt + 4) + 2) // 3)                    # (>= 64: below that max(8, kcap // 8) breaks the room count)
         if self.max_rows < need:
             raise ValueError(f"max_rows = {self.max_rows} is too small for tadapt = {self.tadapt}: need >= {need}")
         return self.max_rows

@@ -290,6 +290,22 @@ class BatchedMLP:
         profiling); returns the previous setting.  Per descriptor: other operators are unaffected."""
         return int(self._L.qn_mlp_desc_set_path(self._desc, int(path)))
 
+    def use_exact_float64(self):
+        """Plain float64 arithmetic for THIS operator: under `PATH_AUTO` the float64 operator of 64 / 128 / 256-wide tanh
+        networks runs the sliced int8-product kernels (operands rounded to 2^-47 of their row / activation scale: a
+        norm-wise 47-bit bound, ~1e-14 .. 1e-13 on SSE / gradients of ordinary networks).  This selects the float64-MFMA
+        fused kernels where the shape allows (`PATH_FUSED_DP`), the layer-wise float64 kernels otherwise (`PATH_GENERIC`).
+        Returns the path taken."""
+        from . import _lib as L
+        self.set_path(L.PATH_FUSED_DP)
+        try:
+            ok = self.path(1, self.N, True) == L.PATH_FUSED and self.path(1, self.N, False) == L.PATH_FUSED
+        except Exception:
+            ok = False
+        if not ok:
+            self.set_path(L.PATH_GENERIC)
+        return L.PATH_FUSED_DP if ok else L.PATH_GENERIC
+
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None

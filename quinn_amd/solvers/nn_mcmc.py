@@ -27,8 +27,17 @@ class NN_MCMC(QUiNNBase):
     """Attributes: samples `(nmcmc+1, p)` (or `(C, nmcmc+1, p)` for C chains), cmode (MAP
     weights), pdim, lpinfo, verbose."""
 
-    def __init__(self, nnmodel, verbose=True, device=None, dtype="float64"):
+    def __init__(self, nnmodel, verbose=True, device=None, dtype="float64", kernels="auto"):
+        """kernels (build-only extra; the reference has no counterpart): 'auto' -- the fastest kernel family for the network's
+        shape; for 64 / 128 / 256-wide tanh networks in float64 those are the sliced int8-product kernels, whose operands are
+        rounded to 2^-47 of their row / activation scale (a norm-wise 47-bit bound: ~1e-14 .. 1e-13 on log-posteriors and
+        gradients of ordinary networks, where float64 rounding gives ~1e-16).  'float64' -- plain float64 arithmetic
+        throughout (the float64-MFMA fused kernels where they apply, the layer-wise float64 kernels otherwise): what the
+        reference's torch CPU path computes, up to summation order."""
         super().__init__(nnmodel, device=device, dtype=dtype)
+        if kernels not in ("auto", "float64"):
+            raise ValueError("kernels must be 'auto' or 'float64'")
+        self.kernels = kernels
         self.verbose = verbose
         self.pdim = sum(p.numel() for p in self.nnmodel.parameters())
         print("Number of parameters:", self.pdim)
@@ -50,6 +59,8 @@ class NN_MCMC(QUiNNBase):
             yd = np.asarray(lpinfo['yd'], dtype=np.float64)      # list of (o,) rows -> (N,o)
             self._op = BatchedMLP(self.arch, xd, yd.reshape(xd.shape[0], -1), device=self._device,
                                   dtype=self._dtype)
+            if self.kernels == "float64":
+                self._op.use_exact_float64()
             self._op_key = key
         return self._op
 
@@ -97,7 +108,11 @@ class NN_MCMC(QUiNNBase):
             seeds=None the global numpy RNG is used, exactly like the reference.
             engine='device' (samplers 'amcmc', 'hmc' and 'mala'): states, proposal factors and history stay on the
             GPU, no host synchronisation per step (`quinn_amd.mcmc.device_amcmc`); same target and
-            adaptation schedule, chains equal the host engine in distribution, not bit for bit.
+            adaptation schedule, chains equal the host engine in distribution, not bit for bit.  The device AMCMC keeps at most
+            `max_rows` (sampler_params; default 4096) distinct states per chain: on longer runs older states are compressed
+            into max_rows / 4 pseudo-states with the same multiplicity total, the same mean and the scatter's dominant
+            max_rows / 8 directions, so the adapted proposal covariance is then a low-rank APPROXIMATION of the reference's
+            full empirical covariance (exact while rank <= max_rows / 8; `DeviceAMCMC._compress_history`).
             gather (multi-rank runs; chains are block-partitioned over the ranks): 'all' -- every rank ends with all
             chains (one all_gather of the result arrays, from the device buffers in bounded pieces); 'root' -- rank 0
             does, the other ranks keep their own shard; 'none' -- no communication at all.  A gather whose result

@@ -14,7 +14,10 @@ PATHS = {_lib.PATH_GENERIC: "generic", _lib.PATH_FUSED: "fused", _lib.PATH_FUSED
 def _sensitivity(mod, w, xb, yb, rs):
     """How much the oracle's own SSE / gradient / predictions move when every weight changes by one unit in the last place
     (relative, max norm): the floor below which two correct float64 implementations cannot be told apart.  Deep saturated
-    networks amplify rounding by 1e6 and more; the bars of the sweeps are max(stated bar, 20 x this)."""
+    networks amplify rounding by 1e6 and more.  Measured PER CHAIN.  The bars of the sweeps are max(stated bar, K x this):
+    K = 20 for the residual networks (plain float64 kernels), K = K_SLICED = 512 for the MLP operator, whose default
+    (QN_PATH_AUTO) kernels for 64 / 128 / 256-wide tanh networks round operands to 2^-47 of their row / activation scale --
+    64 units in the last place of float64 (2^-47 / 2^-53) -- times 8 for the accumulation over the layers."""
     w2 = w * (1.0 + 2.0 ** -52 * rs.choice([-1.0, 1.0], size=w.shape))
     with np.errstate(all="ignore"):
         s0, s1 = mlp_ref.sse(mod, w, xb, yb), mlp_ref.sse(mod, w2, xb, yb)
@@ -22,6 +25,9 @@ def _sensitivity(mod, w, xb, yb, rs):
         g0 = mlp_ref.logpostgrad(mod, w, xb, [v for v in yb], 1.0); g1 = mlp_ref.logpostgrad(mod, w2, xb, [v for v in yb], 1.0)
     rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(a).max(), 1e-300))
     return abs(s1 / s0 - 1) if s0 else 0.0, rel(g0, g1), rel(p0, p1)
+
+
+K_SLICED = 512          # 64 ulp (47-bit operands) x 8: see _sensitivity
 
 
 def run(ncases=100, seed=0, verbose=True):
@@ -57,19 +63,21 @@ def run(ncases=100, seed=0, verbose=True):
         Nb = N if idx is None else idx.shape[1]
         pth = PATHS.get(op.path(B, Nb, True), "?") + "/" + PATHS.get(op.path(B, Nb, False), "?")
         mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, act, bias))
-        e = [0.0, 0.0, 0.0]; sens = [0.0, 0.0, 0.0]
+        e = [0.0, 0.0, 0.0]
+        ts, tg = (1e-11, 1e-10) if dtype == "float64" else (2e-4, 2e-3)      # (float32: the bars of tests/test_gpu_rnet_parity.py)
+        ok = True
         for b in range(B):
             xb, yb = (x, y) if idx is None else (x[idx[b]], y[idx[b]])
-            if b == 0: sens = _sensitivity(mod, W[b], xb, yb, rs)
             sref = mlp_ref.sse(mod, W[b], xb, yb)
             pref = mlp_ref.forward_flat(mod, W[b], xb)
             gref = -2.0 * mlp_ref.logpostgrad(mod, W[b], xb, [v for v in yb], 1.0)          # dSSE/dw
-            e[0] = max(e[0], abs(s[b] / sref - 1), abs(s2[b] / sref - 1))
-            e[1] = max(e[1], np.abs(g[b] - gref).max() / max(np.abs(gref).max(), 1e-300))
-            e[2] = max(e[2], np.abs(pr[b].reshape(pref.shape) - pref).max() / max(np.abs(pref).max(), 1e-300))
-        ts, tg = (1e-11, 1e-10) if dtype == "float64" else (2e-4, 2e-3)      # (float32: the bars of tests/test_gpu_rnet_parity.py)
-        K = 2000        # (the int8-slice kernels round operands to 47 bits: ~64 units in the last place; x 30 headroom)
-        ok = e[0] <= max(ts, K * sens[0]) and e[1] <= max(tg, K * sens[1]) and e[2] <= max(ts if dtype == "float64" else tg, K * sens[2])
+            eb = [max(abs(s[b] / sref - 1), abs(s2[b] / sref - 1)), np.abs(g[b] - gref).max() / max(np.abs(gref).max(), 1e-300),
+                  np.abs(pr[b].reshape(pref.shape) - pref).max() / max(np.abs(pref).max(), 1e-300)]
+            tp = ts if dtype == "float64" else tg
+            if not (eb[0] <= ts and eb[1] <= tg and eb[2] <= tp):            # beyond the fixed bars: this chain's own floor decides
+                sens = _sensitivity(mod, W[b], xb, yb, rs)
+                ok &= eb[0] <= max(ts, K_SLICED * sens[0]) and eb[1] <= max(tg, K_SLICED * sens[1]) and eb[2] <= max(tp, K_SLICED * sens[2])
+            e = [max(u, v) for u, v in zip(e, eb)]
         nfail += not ok
         if dtype == "float64": worst = [max(u, v) for u, v in zip(worst, e)]
         if verbose or not ok:
@@ -119,17 +127,19 @@ def run_rnet(ncases=60, seed=0, verbose=True):
             s, g = op.sse_grad(W, row_idx=idx); s2, pr = op.sse_pred(W, row_idx=idx)
             s, g, s2, pr = (t.double().cpu().numpy() for t in (s, g, s2, pr))
             mod = mlp_ref.build_module(spec)
-            e = [0.0, 0.0, 0.0]; sens = [0.0, 0.0, 0.0]
+            e = [0.0, 0.0, 0.0]
+            ok = True
             for b in range(B):
                 xb, yb = (x, y) if idx is None else (x[idx[b]], y[idx[b]])
-                if b == 0: sens = _sensitivity(mod, W[b], xb, yb, rs)
                 sref = mlp_ref.sse(mod, W[b], xb, yb)
                 pref = mlp_ref.forward_flat(mod, W[b], xb)
                 gref = -2.0 * mlp_ref.logpostgrad(mod, W[b], xb, [v for v in yb], 1.0)
-                e[0] = max(e[0], abs(s[b] / sref - 1), abs(s2[b] / sref - 1))
-                e[1] = max(e[1], np.abs(g[b] - gref).max() / max(np.abs(gref).max(), 1e-300))
-                e[2] = max(e[2], np.abs(pr[b].reshape(pref.shape) - pref).max() / max(np.abs(pref).max(), 1e-300))
-            ok = e[0] <= max(1e-11, 20 * sens[0]) and e[1] <= max(1e-10, 20 * sens[1]) and e[2] <= max(1e-11, 20 * sens[2])
+                eb = [max(abs(s[b] / sref - 1), abs(s2[b] / sref - 1)), np.abs(g[b] - gref).max() / max(np.abs(gref).max(), 1e-300),
+                      np.abs(pr[b].reshape(pref.shape) - pref).max() / max(np.abs(pref).max(), 1e-300)]
+                if not (eb[0] <= 1e-11 and eb[1] <= 1e-10 and eb[2] <= 1e-11):   # beyond the fixed bars: this chain's own floor decides
+                    sens = _sensitivity(mod, W[b], xb, yb, rs)
+                    ok &= eb[0] <= max(1e-11, 20 * sens[0]) and eb[1] <= max(1e-10, 20 * sens[1]) and eb[2] <= max(1e-11, 20 * sens[2])
+                e = [max(u, v) for u, v in zip(e, eb)]
             nfail += not ok
             worst = [max(u, v) for u, v in zip(worst, e)]
             Nb = N if idx is None else idx.shape[1]
