@@ -163,3 +163,33 @@ def test_gradient_inside_a_hip_graph_equals_direct_launches():
     gr.replay()
     torch.cuda.synchronize()
     assert torch.equal(s_out, s0) and torch.equal(g_out, g0)
+
+
+def test_exact_float64_option_selects_the_plain_float64_kernels():
+    """`BatchedMLP.use_exact_float64()` / `NN_MCMC(kernels='float64')`: bit for bit the float64-MFMA kernels (64-wide) or
+    the layer-wise float64 kernels (128-wide: no float64 fused gradient there), and closer to the oracle than the default."""
+    from quinn_amd.nns.mlp import MLP
+    from quinn_amd.solvers.nn_mcmc import NN_MCMC
+    for dims, ref_path in (((1, 64, 64, 64, 1), _lib.PATH_FUSED_DP), ((2, 128, 128, 1), _lib.PATH_GENERIC)):
+        arch = MLPArch(dims, "tanh")
+        x, y = _data(300, dims[0], seed=4)
+        W = _weights(arch, 3, 0.4, 21)
+        exact, ref = BatchedMLP(arch, x, y), BatchedMLP(arch, x, y)
+        assert exact.use_exact_float64() == ref_path
+        ref.set_path(ref_path)
+        (s0, g0), (s1, g1) = exact.sse_grad(W), ref.sse_grad(W)
+        assert torch.equal(s0, s1) and torch.equal(g0, g1)
+        assert torch.equal(exact.sse(W), ref.sse(W))
+    torch.manual_seed(0)
+    nn = MLP(1, 1, (64, 64), activ="tanh")
+    x, y = _data(200, 1, seed=6)
+    mod = mlp_ref.build_module(mlp_ref.MLPSpec((1, 64, 64, 1), "tanh"))
+    errs = {}
+    for kern in ("auto", "float64"):
+        s = NN_MCMC(nn, verbose=False, kernels=kern)
+        lpinfo = {'model': nn, 'xd': x, 'yd': [v for v in y], 'ltype': 'classical', 'lparams': {'sigma': 0.1}}
+        w = 0.3 * np.random.RandomState(1).randn(s.pdim)
+        errs[kern] = abs(s.logpost(w, lpinfo) / mlp_ref.logpost(mod, w, x, [v for v in y], 0.1) - 1)
+    assert errs["float64"] <= 1e-14 and errs["auto"] <= 1e-11, errs
+    with pytest.raises(ValueError):
+        NN_MCMC(nn, verbose=False, kernels="fast")
