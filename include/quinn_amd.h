@@ -62,7 +62,10 @@ int qn_mlp_desc_destroy(qn_desc* desc);
 /* p = number of entries of one flat weight vector. */
 int64_t qn_mlp_num_params(const qn_desc* desc);
 
-/* Bytes of scratch the two calls below need for B weight vectors x Nb rows each. */
+/* Bytes of scratch the two calls below need for B weight vectors x Nb rows each.  The workspace is the caller's: it needs
+ * no initialisation and keeps no state between calls (the fused forward kernels sum a chain's SSE by a last-arriver
+ * protocol on a tagged word of it that treats any other content as "fresh" and resets itself), but it must not be shared by
+ * calls that can run concurrently (two streams: two workspaces). */
 size_t qn_workspace_bytes(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
 
 /* Which kernel family the next call with these sizes would run (QN_PATH_GENERIC/FUSED). */
@@ -110,7 +113,8 @@ int qn_mlp_sse_fwd(const qn_desc* desc, int dtype, const void* W, const void* X,
  * (qn_mcmc_accept): sse_parts_out is [B, parts], parts = qn_mlp_sse_parts(desc, B, Nb, dtype) >= 1, and the plain
  * left-to-right sum of row b is exactly (bit for bit) what qn_mlp_sse_fwd writes to sse_out[b].  parts > 1 only where
  * the fused forward kernel runs unpadded (one partial per row split of a chain); otherwise parts = 1 and the call is
- * qn_mlp_sse_fwd without predictions.  Saves one dependent ~5 us launch per Metropolis step. */
+ * qn_mlp_sse_fwd without predictions.  (qn_mlp_sse_fwd itself sums the parts inside the forward kernel since round 3 -- the
+ * last workgroup of a chain to finish, ~1.5 us; this entry point saves that as well.) */
 int qn_mlp_sse_parts(const qn_desc* desc, int B, int Nb, int dtype);
 int qn_mlp_sse_fwd_parts(const qn_desc* desc, int dtype, const void* W, const void* X, const void* Y,
                          const int32_t* row_idx, int B, int N, int Nb, double* sse_parts_out, void* workspace,
