@@ -314,6 +314,387 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product with GROUP scales (the kernel that runs; k_i8_dw above is kept for A/B: -DQN_DW_GROUP=0).
+// In k_i8_dw the matrix waves are the critical path (94 % busy, docs/experiments.md R3.7) and a third of their vector work
+// is the recombination of every tile's int32 levels into float64 after EVERY chunk -- forced by dZ scales that change from
+// chunk to chunk.  Here a feature's dZ scale is shared by GC consecutive chunks (64 GC rows):
+//   * the slicer waves read the exponents of a group one group AHEAD (a second, early read of the same lines -- they come
+//     from L2 / MALL when the slicing read follows -- folded into a running maximum: 2 instructions per value), and fold
+//     the scale into the rounding fma (no separate scaling multiply);
+//   * the matrix waves keep ALL FOUR tiles' int32 levels in registers across the group's chunks (|level sum| <= GC * 6 * 2^20)
+//     and recombine once per group: tile 0 beside the group's last tile step, tiles 1..3 beside the first three tile steps
+//     of the next group (whose MFMAs restart those accumulators from zero one step later).  The levels are then summed in
+//     float64 (their pair sums fit int32 only for a single chunk);
+//   * the float64 accumulators live in LDS (lane-private slots, touched once per group) and the group's scales in a
+//     two-slot LDS ring: the registers they held carry the two extra tiles' levels.
+// Accuracy: a feature's digits keep 2^-47 of its largest |dZ| over 64 GC rows instead of 64 rows; the bound on the sum
+// (2^-47 max|dZ_j| sum|a|) is the one of the forward kernels' row scales.
+#ifndef QN_DW_GROUP
+#define QN_DW_GROUP 4
+#endif
+constexpr int DWG_BUF = 2 * DW_OPER;                                  // a chunk's digit planes of both operands: 48 KB
+constexpr int DWG_RING = 2 * 64 * (int)sizeof(double);                // scales of the current / previous group
+constexpr int DWG_FACC = 4 * 16 * 64 * (int)sizeof(double);           // float64 accumulators of the four matrix waves: 32 KB
+constexpr int DWG_LDS = 2 * DWG_BUF + DWG_RING + DWG_FACC + 16;
+
+template <int LMIN, int GC>
+__global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __restrict__ dz, const double* __restrict__ ap,
+                                                   double* __restrict__ out) {
+    constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN);
+    static_assert(GC >= 2 && (GC & (GC - 1)) == 0 && GC <= 64, "chunks per scale group: a power of two (int32 level sums: GC * 6 * 2^20)");
+    extern __shared__ __attribute__((aligned(16))) char smemd[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int inner_i = seq % g.inner, outer = (seq / g.inner) * 8 + xcd;
+    if (outer >= g.outer_total) return;
+    const int b = outer / g.per_b, slab = outer % g.per_b;
+    const int tiles_i = g.h_in / 64;
+    const int j0 = (inner_i / tiles_i) * 64, i0 = (inner_i % tiles_i) * 64;
+    const int Nb = g.Nb, kbeg = slab * g.kchunk, kend = kbeg + g.kchunk < Nb ? kbeg + g.kchunk : Nb;
+    const int nchunks = (kend - kbeg + 63) / 64, npad = (nchunks + GC - 1) / GC * GC;
+    const double* Z = dz + ((int64_t)b * g.h_out + j0) * Nb;
+    const double* A = ap + ((int64_t)b * g.h_in + i0) * Nb;
+    double* O = out + (int64_t)b * g.out_stride_b + (int64_t)slab * g.out_stride_k;
+    double* ring = reinterpret_cast<double*>(smemd + 2 * DWG_BUF);
+    double* faccs = reinterpret_cast<double*>(smemd + 2 * DWG_BUF + DWG_RING);
+    int* badflag = reinterpret_cast<int*>(smemd + 2 * DWG_BUF + DWG_RING + DWG_FACC);
+    if (tid == 0) *badflag = 0;
+    const bool want_rowsum = g.has_bias && i0 == 0;
+    if (nchunks <= 0) {                                               // an empty K-slab: zeros (the loops below assume a chunk)
+        for (int e = tid; e < 64 * 64; e += DWT) O[(int64_t)(j0 + (e >> 6)) * g.h_in + i0 + (e & 63)] = 0.0;
+        if (want_rowsum && tid < 64) O[(int64_t)g.h_in * g.h_out + j0 + tid] = 0.0;
+        return;
+    }
+    double magic = kMagic;                                            // (opaque register pair: see slice4_scaled, qn_fused_bwd_i8.hip)
+    asm volatile("" : "+v"(magic));
+
+    // (items and rows of a lane: as in k_i8_dw; the host sends only whole, 16-byte aligned chunks here: Nb % 64 == 0)
+    auto load_block = [&](const double* base, int ch, int q16_, int fl_, double (&v)[4][4]) {
+        const int c0 = kbeg + 64 * ch;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double2* sp = reinterpret_cast<const double2*>(base + (int64_t)(16 * u + fl_) * Nb + c0 + 2 * q16_);
+            const double2 v01 = sp[0], v23 = sp[16];
+            v[u][0] = v01.x; v[u][1] = v01.y; v[u][2] = v23.x; v[u][3] = v23.y;
+        }
+    };
+    // four values -> six digit words, x = v * scale + magic in ONE rounding (what slice4 does to v * 2^-e, exactly)
+    auto slice_item = [&](const double (&v)[4], double scale, int (&S)[NS]) {
+        int lo[4], hi[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double x;
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(x) : "v"(v[r]), "v"(scale), "v"(magic));
+            lo[r] = __double2loint(x);
+            hi[r] = __double2hiint(x);
+        }
+        const int p01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400), q01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602);
+        const int p23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400), q23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602);
+        const int r01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400), r23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400);
+        S[0] = __builtin_amdgcn_perm(p23, p01, 0x05040100) ^ 0x80808080;
+        S[1] = __builtin_amdgcn_perm(p23, p01, 0x07060302) ^ 0x80808080;
+        S[2] = __builtin_amdgcn_perm(q23, q01, 0x05040100) ^ 0x80808080;
+        S[3] = __builtin_amdgcn_perm(q23, q01, 0x07060302) ^ 0x80808080;
+        S[4] = __builtin_amdgcn_perm(r23, r01, 0x05040100) ^ 0x80808080;
+        S[5] = __builtin_amdgcn_perm(r23, r01, 0x07060302);
+    };
+    if (wave < 4) {
+        // ------------------------------------------------------------------ slicers: the dZ block
+        const int q16 = lane & 15, m4 = q16 >> 2, g4 = q16 & 3, fl = 4 * wave + (lane >> 4);
+        double rsum[4] = {0.0, 0.0, 0.0, 0.0};
+        int bad = 0;
+        unsigned pmax[4] = {0u, 0u, 0u, 0u};                             // largest |dZ| high word seen in the group being read ahead
+        double dn[4] = {0.0, 0.0, 0.0, 0.0};                             // 2^(46 - e) of the group being sliced
+        auto fold = [&](const double (&pz)[4][4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pmax[u] = max(pmax[u], (unsigned)__double2hiint(pz[u][r]) & 0x7fffffffu);
+                    // (the low words count as used until here: dead on arrival, the allocator hands them out as scratch
+                    // registers while the load is still in flight, and every such write waits for ALL outstanding loads)
+                    asm volatile("" :: "v"(__double2loint(pz[u][r])));
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(pmax[u]));     // folded HERE (sunk to its use, it waits for the loads issued meanwhile)
+        };
+        auto group_scale = [&](int grp) {
+            unsigned ex[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ex[u] = pmax[u] >> 20; pmax[u] = 0u; }
+            row16_max_u32_n<4>(ex);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                bad |= ex[u] >= 1923u;                                   // |dZ| >= 2^900 or not finite
+                int e = (int)ex[u] - 1022;                               // 2^e > every |dZ| of the feature's 64 GC rows
+                e = e < -900 ? -900 : e;
+                dn[u] = __hiloint2double((1023 + QB - e) << 20, 0);
+                if (q16 == 0) ring[(grp & 1) * 64 + 16 * u + fl] = __hiloint2double((1023 + e - 2 * QB + 8 * LMIN) << 20, 0);
+            }
+        };
+        auto slice_chunk = [&](int ch, const double (&vz)[4][4]) {
+            unsigned char* pa = reinterpret_cast<unsigned char*>(smemd + (ch & 1) * DWG_BUF);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = 16 * u + fl;
+                int S[NS];
+                slice_item(vz[u], dn[u], S);
+                const int ofs = f * 64 + 16 * (g4 ^ slot_swz(f)) + 4 * m4;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(pa + k * 4096 + ofs) = S[k];
+                if (want_rowsum) rsum[u] += (vz[u][0] + vz[u][1]) + (vz[u][2] + vz[u][3]);
+                __builtin_amdgcn_sched_barrier(0);                       // (item by item: interleaving all four costs more registers than the sets leave)
+            }
+        };
+        // the a block (tanh outputs: fixed scale 2^-46, no exponent work) of the same chunk
+        unsigned amaxa = 0;                                              // largest |a| (high word) this wave has sliced
+        auto slice_chunk_a = [&](int ch, const double (&va)[4][4]) {
+            unsigned char* pbn = reinterpret_cast<unsigned char*>(smemd + (ch & 1) * DWG_BUF) + DW_OPER;
+            const double p46 = 0x1p46;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = 16 * u + fl;
+                unsigned exa = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) exa = max(exa, (unsigned)__double2hiint(va[u][r]) & 0x7fffffffu);
+                bad |= exa >= 0x40000000u;                               // |a| >= 2 or not finite
+                amaxa = max(amaxa, exa);
+                int S[NS];
+                slice_item(va[u], p46, S);
+                const int ofs = f * 64 + 16 * (g4 ^ slot_swz(f)) + 4 * m4;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(pbn + k * 4096 + ofs) = S[k];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // A slab's last group is filled up with empty chunks (zero digits): every group is GC chunk steps, no special cases
+        // on the matrix waves.  Every load below is UNCONDITIONAL, with the chunk index clamped to the slab's last one: a load
+        // inside a branch meets the other path's registers at the join, and the compiler then waits for it on the spot.
+        double zc[4][4], a0[4][4], a1[4][4], pz[4][4];
+        const int lastc = nchunks - 1;
+        auto zero_planes = [&](int ch, int oper) {
+            unsigned char* pa = reinterpret_cast<unsigned char*>(smemd + (ch & 1) * DWG_BUF) + oper;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = 16 * u + fl, ofs = f * 64 + 16 * (g4 ^ slot_swz(f)) + 4 * m4;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(pa + k * 4096 + ofs) = 0;
+            }
+        };
+        if (q16 == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ring[64 + 16 * u + fl] = 0.0;     // (slot 1 is read beside group 0's first chunk: 0 x 0)
+        }
+#pragma unroll
+        for (int c = 0; c < GC; ++c) { load_block(Z, min(c, lastc), q16, fl, pz); fold(pz); }      // group 0's exponents
+        __builtin_amdgcn_sched_barrier(0);
+        // (in the order and number the loop leaves them outstanding at its head: the compiler's wait counts at the head are
+        // the worst case over the two ways in, and with another order there it waited for EVERYTHING in every other step)
+        load_block(A, 0, q16, fl, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_block(Z, 0, q16, fl, zc);
+        __builtin_amdgcn_sched_barrier(0);
+        load_block(A, min(1, lastc), q16, fl, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_block(Z, min(GC, lastc), q16, fl, pz);
+        __builtin_amdgcn_sched_barrier(0);
+        // an a block is requested TWO chunk steps before it is sliced (into the register set the chunk two steps back has
+        // just left: it comes from HBM for the first workgroup of an XCD that touches it, and one chunk step is shorter than
+        // that round trip); a dZ block one step before (its lines were pulled into L2 by the exponent read a group earlier:
+        // the chunk GC ahead belongs to the next group -- past the slab's end the last chunk is read again, which belongs to
+        // the last group anyway)
+#ifdef QN_DW_STAMPS
+        long long tsg_bar = 0, tsg_wz = 0, tsg_a = 0, tsg_f = 0;
+#endif
+        auto step = [&](int ch, double (&va)[4][4]) {
+            if ((ch & (GC - 1)) == 0) group_scale(ch / GC);
+#ifdef QN_DW_STAMPS
+            { const long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); tsg_wz += __builtin_amdgcn_s_memtime() - t_; }
+#endif
+            if (ch < nchunks) slice_chunk(ch, zc); else zero_planes(ch, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_block(Z, min(ch + 1, lastc), q16, fl, zc);
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef QN_DW_STAMPS
+            const long long ta_ = __builtin_amdgcn_s_memtime();
+#endif
+            if (ch < nchunks) slice_chunk_a(ch, va); else zero_planes(ch, DW_OPER);
+#ifdef QN_DW_STAMPS
+            tsg_a += __builtin_amdgcn_s_memtime() - ta_;
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            load_block(A, min(ch + 2, lastc), q16, fl, va);
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef QN_DW_STAMPS
+            { const long long t_ = __builtin_amdgcn_s_memtime(); __syncthreads(); tsg_bar += __builtin_amdgcn_s_memtime() - t_; }
+#else
+            __syncthreads();          // chunk ch is written; the matrix waves are done with chunk ch - 1 (whose buffer chunk ch + 1 overwrites)
+#endif
+#ifdef QN_DW_STAMPS
+            { const long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); tsg_f += __builtin_amdgcn_s_memtime() - t_; }
+#endif
+            fold(pz);                 // (exponents of chunk ch + GC, requested a step ago)
+            __builtin_amdgcn_sched_barrier(0);
+            load_block(Z, min(ch + 1 + GC, lastc), q16, fl, pz);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#ifdef QN_DW_STAMPS
+        const long long tsg_0 = __builtin_amdgcn_s_memtime();
+#endif
+        for (int ch = 0; ch < npad; ch += 2) {                            // (npad is even: GC is)
+            step(ch, a0);
+            step(ch + 1, a1);
+        }
+#ifdef QN_DW_STAMPS
+        if (blockIdx.x == 9 && tid == 0)
+            printf("dwg slicer: chunks %d total %lld barrier %lld wait-z %lld slice-a %lld wait-peek %lld\n", npad, (long long)(__builtin_amdgcn_s_memtime() - tsg_0), tsg_bar, tsg_wz, tsg_a, tsg_f);
+#endif
+        // the fixed scale of the a operand (absolute error 2^-47) is a relative accuracy only while the activations are not
+        // ALL tiny: a wave whose features stayed below 2^-5 over the whole slab (and are not exactly zero: padding) sends
+        // the tile through the plain float64 loop as well
+        amaxa = wave_max_u32(amaxa);
+        if (amaxa != 0 && amaxa < TINY_ACT_HI) bad = 1;
+        __syncthreads();                                                 // (matches the matrix waves' drain step)
+        if (want_rowsum) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                double s = rsum[u];
+                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+                if (q16 == 0) O[(int64_t)g.h_in * g.h_out + j0 + 16 * u + fl] = s;
+            }
+        }
+        if (bad) *badflag = 1;
+    } else {
+        // ------------------------------------------------------------------ matrix waves
+        const int m = wave - 4, q = lane >> 4, c = lane & 15;
+        const int lofs = c * 64 + 16 * (q ^ slot_swz(c));
+        double* fl_ = faccs + m * 16 * 64 + lane;                        // element (tile t, register r): fl_[(4 t + r) * 64]
+#pragma unroll
+        for (int e = 0; e < 16; ++e) fl_[e * 64] = 0.0;
+        v4i acc[4][NLEV];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int l = 0; l < NLEV; ++l) acc[t][l] = (v4i){0, 0, 0, 0};
+        // One tile step: the 26 MFMAs of tile T_ and, when TP >= 0, the recombination of tile TP's
+        // levels (a finished group) into its float64 accumulators with the scales of ring slot `par`, dealt out between them
+        // in pinned micro-steps.  The next tile's B fragments are fetched meanwhile.
+        auto tile_step = [&](auto t_tag, auto tp_tag, const v4i (&Af)[NS], v4i (&Bf)[NS], const unsigned char* pb, int par) {
+            constexpr int T_ = decltype(t_tag)::value, TP = decltype(tp_tag)::value;
+
+            // product k in B-DIGIT-MAJOR order (the kept set and its level sequence are symmetric in the two digit indices): a
+            // B digit's fragment is dead after its block of products and is refilled at once with the next tile's (one
+            // fragment set instead of two: the registers carry the extra tiles' levels)
+            auto product = [&](auto k_tag) {
+                constexpr int k = decltype(k_tag)::value, aj = prod_wi(LMIN, k), wi = prod_aj(LMIN, k), l = wi + aj - LMIN;
+                acc[T_][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Af[wi], Bf[aj], acc[T_][l], 0, 0, 0);
+                if constexpr (k == NPROD - 1 || prod_wi(LMIN, k + 1) != aj) {
+                    if constexpr (T_ < 3) Bf[aj] = *reinterpret_cast<const v4i*>(pb + aj * 4096 + (T_ + 1) * 1024 + lofs);
+                    __builtin_amdgcn_sched_barrier(0);                   // (left free, the scheduler hoists every refill to the top of the chunk: six more fragment sets alive)
+                }
+            };
+            if constexpr (TP < 0) {
+                for_each_stage(product, std::make_integer_sequence<int, NPROD>{});
+            } else {
+                constexpr int NST = NLEV + 1, NMICRO = 4 * NST;
+                double ts[4];
+                for_each_stage([&](auto id_tag) {
+                    constexpr int id = decltype(id_tag)::value, st = id >> 2, r = id & 3;
+                    constexpr int from = (id * NPROD + NMICRO - 1) / NMICRO, upto = ((id + 1) * NPROD + NMICRO - 1) / NMICRO;
+                    for_each_stage([&](auto k_tag) { product(std::integral_constant<int, from + decltype(k_tag)::value>{}); },
+                                   std::make_integer_sequence<int, upto - from>{});
+                    const v4i (&ap_)[NLEV] = acc[TP];
+                    if constexpr (st == 0) ts[r] = (double)ap_[NLEV - 1][r];
+                    else if constexpr (st < NLEV) ts[r] = fma(ts[r], 256.0, (double)ap_[NLEV - 1 - st][r]);
+                    else {
+                        fl_[(4 * TP + r) * 64] = fma(ts[r], ring[par * 64 + 16 * m + 4 * q + r], fl_[(4 * TP + r) * 64]);
+                        if constexpr (r == 3) {                          // the tile's levels restart from zero for the next group
+#pragma unroll
+                            for (int l = 0; l < NLEV; ++l) acc[TP][l] = (v4i){0, 0, 0, 0};
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }, std::make_integer_sequence<int, NMICRO>{});
+            }
+        };
+        using std::integral_constant;
+        using no_tile = integral_constant<int, -1>;
+        // (one straight-line body per group: with run-time choices between recombining and plain steps the accumulators met
+        // at every join and the register allocator spilled them)
+#ifdef QN_DW_STAMPS
+        long long tmg_bar = 0;
+        const long long tmg_0 = __builtin_amdgcn_s_memtime();
+#endif
+        for (int grp = 0; grp * GC < npad; ++grp) {
+            const int pp = (grp - 1) & 1;                                // ring slot of the previous group (group 0: zeros)
+            for_each_stage([&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value;
+#ifdef QN_DW_STAMPS
+                { const long long t_ = __builtin_amdgcn_s_memtime(); __syncthreads(); tmg_bar += __builtin_amdgcn_s_memtime() - t_; }
+#else
+                __syncthreads();                                         // chunk grp * GC + i is in LDS
+#endif
+                const unsigned char* pa = reinterpret_cast<const unsigned char*>(smemd + (i & 1) * DWG_BUF);
+                const unsigned char* pb = pa + DW_OPER;
+                v4i Af[NS], Bf[NS];
+#pragma unroll
+                for (int k = 0; k < NS; ++k) Af[k] = *reinterpret_cast<const v4i*>(pa + k * 4096 + m * 1024 + lofs);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) Bf[k] = *reinterpret_cast<const v4i*>(pb + k * 4096 + lofs);
+                if constexpr (i == 0) {                                  // beside the previous group's tiles 1..3
+                    tile_step(integral_constant<int, 0>{}, integral_constant<int, 1>{}, Af, Bf, pb, pp);
+                    tile_step(integral_constant<int, 1>{}, integral_constant<int, 2>{}, Af, Bf, pb, pp);
+                    tile_step(integral_constant<int, 2>{}, integral_constant<int, 3>{}, Af, Bf, pb, pp);
+                } else {
+                    tile_step(integral_constant<int, 0>{}, no_tile{}, Af, Bf, pb, 0);
+                    tile_step(integral_constant<int, 1>{}, no_tile{}, Af, Bf, pb, 0);
+                    tile_step(integral_constant<int, 2>{}, no_tile{}, Af, Bf, pb, 0);
+                }
+                if constexpr (i == GC - 1) tile_step(integral_constant<int, 3>{}, integral_constant<int, 0>{}, Af, Bf, pb, grp & 1);
+                else tile_step(integral_constant<int, 3>{}, no_tile{}, Af, Bf, pb, 0);
+            }, std::make_integer_sequence<int, GC>{});
+        }
+#ifdef QN_DW_STAMPS
+        if (blockIdx.x == 9 && tid == 256)
+            printf("dwg matrix wave: chunks %d total %lld barrier %lld\n", npad, (long long)(__builtin_amdgcn_s_memtime() - tmg_0), tmg_bar);
+#endif
+        __syncthreads();                                                 // drain step
+        if (nchunks > 0) {                                               // the last group's tiles 1..3
+            const int pp = ((npad - 1) / GC) & 1;
+#pragma unroll
+            for (int t = 1; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double ts = (double)acc[t][NLEV - 1][r];
+#pragma unroll
+                    for (int l = NLEV - 2; l >= 0; --l) ts = fma(ts, 256.0, (double)acc[t][l][r]);
+                    fl_[(4 * t + r) * 64] = fma(ts, ring[pp * 64 + 16 * m + 4 * q + r], fl_[(4 * t + r) * 64]);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) O[(int64_t)(j0 + 16 * m + 4 * q + r) * g.h_in + i0 + 16 * t + c] = fl_[(4 * t + r) * 64];
+    }
+    __syncthreads();
+    if (*badflag) {
+        // exceptional values: the tile again in plain float64 (thread = 8 outputs of one row j)
+        const int jl = tid >> 3, ib = (tid & 7) * 8;
+        double s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb = 0.0;
+        for (int n = kbeg; n < kend; ++n) {
+            const double zv = Z[(int64_t)jl * Nb + n];
+            sb += zv;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] = fma(zv, A[(int64_t)(ib + u) * Nb + n], s[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) O[(int64_t)(j0 + jl) * g.h_in + i0 + ib + u] = s[u];
+        if (want_rowsum && ib == 0) O[(int64_t)g.h_in * g.h_out + j0 + jl] = sb;
+    }
+}
+
 }  // namespace
 
 // dst + b * out_stride_b + slab * out_stride_k receives [h_out x h_in] weights (+ h_out bias sums behind them): the
@@ -326,15 +707,23 @@ int qn_i8_dw(int h_in, int h_out, int has_bias, const double* dz, const double* 
     g.has_bias = has_bias; g.kchunk = kchunk;
     g.inner = (h_in / 64) * (h_out / 64); g.per_b = ksplit; g.outer_total = ksplit * B;
     const unsigned grid = (unsigned)(((g.outer_total + 7) / 8) * 8 * g.inner);
-    const size_t lds = 2 * (size_t)DW_BUF + 16;
-    auto kern = k_i8_dw<QN_I8_LMIN>;
-    {   // raise the dynamic-LDS limit once per process (not per launch: the launch path stays capturable into a HIP graph)
+    // group scales (k_i8_dw_g) for row counts in whole chunks; the per-chunk kernel (partial chunks, odd row counts) otherwise
+    size_t lds = 2 * (size_t)DW_BUF + 16;
+    void (*kern)(DwArgs, const double*, const double*, double*) = k_i8_dw<QN_I8_LMIN>;
+    int which = 0;
+#if QN_DW_GROUP >= 2
+    if (Nb % 64 == 0 && kchunk % 64 == 0) { lds = (size_t)DWG_LDS; kern = k_i8_dw_g<QN_I8_LMIN, QN_DW_GROUP>; which = 1; }
+#endif
+    {   // raise the dynamic-LDS limit once per device (not per launch: the launch path stays capturable into a HIP graph)
         static std::mutex mu;
-        static bool armed = false;
+        static unsigned long long armed[2] = {0, 0};                     // per kernel: bit = device ordinal
+        int dev = 0;
+        QN_HIP_CHECK(hipGetDevice(&dev));
         std::lock_guard<std::mutex> lock(mu);
-        if (!armed) {
+        if (dev < 0 || dev >= 64) return QN_EUNSUPPORTED;
+        if (!(armed[which] >> dev & 1ull)) {
             QN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            armed = true;
+            armed[which] |= 1ull << dev;
         }
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(DWT), lds, st, g, dz, a_prev, dst);

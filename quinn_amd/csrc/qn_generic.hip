@@ -170,6 +170,8 @@ __global__ __launch_bounds__(BLK) void k_dW(LayerArgs a, const T* __restrict__ d
 #pragma unroll
         for (int kk = 0; kk < TK; ++kk) acc[jj][kk] = T(0);
     }
+    // (thin shapes stream one operand from HBM: two row steps in flight per thread keep enough loads outstanding)
+#pragma unroll 2
     for (int n = threadIdx.x; n < a.Nb; n += BLK) {
         T g[TJ], v[TK];
 #pragma unroll
@@ -718,9 +720,19 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                 dz = dzp;
                 continue;
             }
-            dim3 gridw((a.h_in + TK - 1) / TK, (a.h_out + TJ - 1) / TJ, B);
-            hipLaunchKernelGGL((k_dW<T, TJ, TK>), gridw, dim3(BLK), 0, st, a, dz, l ? act[l - 1] : (const T*)nullptr,
-                               X, row_idx, gradW);
+            // tile shape by layer shape: a thin input (d <= 2 / 4) or a single output wastes most of an 8 x 8 tile's loads
+            // and accumulators (same sums in the same order whatever the tile: every (j, k) is summed independently)
+            auto launch_dw = [&](auto tj_tag, auto tk_tag) {
+                constexpr int tj = decltype(tj_tag)::value, tk = decltype(tk_tag)::value;
+                dim3 gridw((a.h_in + tk - 1) / tk, (a.h_out + tj - 1) / tj, B);
+                hipLaunchKernelGGL((k_dW<T, tj, tk>), gridw, dim3(BLK), 0, st, a, dz, l ? act[l - 1] : (const T*)nullptr,
+                                   X, row_idx, gradW);
+            };
+            using std::integral_constant;
+            if (a.h_out == 1 && a.h_in >= 16) launch_dw(integral_constant<int, 1>{}, integral_constant<int, 16>{});
+            else if (a.h_in <= 2 && a.h_out >= 8) launch_dw(integral_constant<int, 8>{}, integral_constant<int, 2>{});
+            else if (a.h_in <= 4 && a.h_out >= 8) launch_dw(integral_constant<int, 8>{}, integral_constant<int, 4>{});
+            else launch_dw(integral_constant<int, TJ>{}, integral_constant<int, TK>{});
             if (l > 0 && !wide_bwd) {
                 T* dzp = dzbuf[l & 1];
                 dim3 grida(nblk, (a.h_in + KB - 1) / KB, B);

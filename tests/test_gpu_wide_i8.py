@@ -43,7 +43,10 @@ def _check(a, r):
 CASES = [((2, 128, 128, 128, 1), 8192, 6, True), ((1, 256, 256, 256, 256, 1), 1024, 5, True),
          ((1, 128, 128, 1), 63, 3, True), ((3, 128, 128, 128, 128, 128, 1), 130, 2, True),
          ((4, 256, 256, 1), 321, 4, True), ((1, 256, 256, 256, 1), 200, 3, False), ((2, 128, 128, 128, 1), 77, 9, False),
-         ((1, 256, 256, 256, 256, 256, 256, 1), 65, 2, True)]
+         ((1, 256, 256, 256, 256, 256, 256, 1), 65, 2, True),
+         # whole 64-row chunks (the group-scale weight-gradient kernel k_i8_dw_g): a partial last group, a single chunk,
+         # slabs of several groups
+         ((2, 128, 128, 128, 1), 448, 5, True), ((1, 256, 256, 256, 1), 64, 3, True), ((3, 256, 256, 256, 1), 2368, 2, False)]
 
 
 @pytest.mark.parametrize("dims,N,B,bias", CASES, ids=[f"{c[0][1]}x{len(c[0]) - 2}_d{c[0][0]}_N{c[1]}{'' if c[3] else '_nobias'}" for c in CASES])

@@ -4,7 +4,7 @@ import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["QUINN_AMD_LIB"] = os.path.join(ROOT, "quinn_amd", "lib", "libquinn_amd_dwst.so")
+os.environ["QUINN_AMD_LIB"] = os.path.join(ROOT, "quinn_amd", "lib", "libquinn_amd_dwstamps.so")
 from quinn_amd.ops import MLPArch, BatchedMLP
 dims, N, B = (1, 256, 256, 256, 256, 1), 16384, 32
 arch = MLPArch(dims, "tanh"); rs = np.random.RandomState(0)
