@@ -436,6 +436,11 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __re
         };
         auto slice_chunk = [&](int ch, const double (&vz)[4][4]) {
             unsigned char* pa = reinterpret_cast<unsigned char*>(smemd + (ch & 1) * DWG_BUF);
+            if (want_rowsum) {                                           // (a real branch: one workgroup in h_in / 64 carries the bias sums)
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rsum[u] += (vz[u][0] + vz[u][1]) + (vz[u][2] + vz[u][3]);
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int f = 16 * u + fl;
@@ -444,7 +449,6 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __re
                 const int ofs = f * 64 + 16 * (g4 ^ slot_swz(f)) + 4 * m4;
 #pragma unroll
                 for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(pa + k * 4096 + ofs) = S[k];
-                if (want_rowsum) rsum[u] += (vz[u][0] + vz[u][1]) + (vz[u][2] + vz[u][3]);
                 __builtin_amdgcn_sched_barrier(0);                       // (item by item: interleaving all four costs more registers than the sets leave)
             }
         };
