@@ -121,7 +121,7 @@ int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const
 // l = 0 .. L-2) from the stashed activations and dz_last; same workspace as the forward call of the evaluation
 int qn_i8_wide_backward(const qn_desc* d, const double* W, const double* X, const int32_t* row_idx, int B, int Nb,
                         const double* act0, int64_t act_stride, const double* dz_last, double* dz0, int64_t dz_stride, void* ws,
-                        hipStream_t st);
+                        double* gradW, int* last_done, hipStream_t st);
 // weight gradient of a hidden->hidden layer as sliced int8 products (qn_dw_i8.hip): output conventions of k_gemm64<DW>
 int qn_i8_dw(int h_in, int h_out, int has_bias, const double* dz, const double* a_prev, int B, int Nb, double* dst,
              int64_t out_stride_b, int64_t out_stride_k, int ksplit, int kchunk, hipStream_t st);

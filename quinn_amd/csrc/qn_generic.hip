@@ -666,6 +666,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         const T* dz = dz_last;
         // fused int8-slice backward through the hidden layers (qn_wide_i8.hip): dZ_l of every hidden layer in one launch
         bool wide_bwd = false;
+        int last_done = 0;                                   // the output layer's weight gradient came out of the fused backward (h = 128)
         const int64_t dz_stride = (int64_t)(qn_align((size_t)B * d->hmax * Nb * sizeof(T)) / sizeof(T));
         if constexpr (std::is_same<T, double>::value) {
 #ifndef QN_NO_I8_WIDE_BWD
@@ -673,13 +674,14 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
 #endif
             if (wide_bwd) {
                 if (int rc = qn_i8_wide_backward(d, W, X, row_idx, B, Nb, act[0], act[1] - act[0], dz_last, dzbuf[0], dz_stride,
-                                                 wide_ws, st))
+                                                 wide_ws, gradW, &last_done, st))
                     return rc;
             }
         }
         for (int l = L - 1; l >= 0; --l) {
             LayerArgs a = largs(l);
             if (wide_bwd && l < L - 1) dz = dzbuf[0] + (int64_t)l * dz_stride;
+            if (l == L - 1 && last_done) continue;
             if (gemm_layer(d, l)) {
                 GemmArgs g = gargs(l);
                 const int tiles = (g.h_in / 64) * (g.h_out / 64);

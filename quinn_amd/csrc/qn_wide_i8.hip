@@ -499,8 +499,8 @@ struct WideBwdArgs {
     int B, Nb, d, nhid, has_bias;
     int nsplit, rows_per_split, iters;
 };
-__host__ __device__ constexpr int wideb_head(int hid, int nhid) {       // Wl [h] | red [8] | scales (nhid-1) x [h] | scratch 4 x 2 h
-    return ((hid + 8 + (nhid - 1) * hid + 1) & ~1) + 4 * 2 * hid;
+__host__ __device__ constexpr int wideb_head(int hid, int nhid) {       // Wl [h] | red [8] | scales (nhid-1) x [h] | scratch 4 x 2 h | dWl of plain-float64 rows 4 x (h + 8)
+    return ((hid + 8 + (nhid - 1) * hid + 1) & ~1) + 4 * 2 * hid + 4 * (hid + 8);
 }
 __host__ __device__ constexpr size_t wideb_lds_bytes(int kc, int nhid) {
     return sizeof(double) * (size_t)wideb_head(64 * kc, nhid) + (size_t)WNBUF * kc * NS * 1024;
@@ -534,46 +534,68 @@ __device__ __forceinline__ void slice4s(const double (&a)[4], double scale, int 
 }
 
 // digit planes of the TRANSPOSED hidden matrices: "row" i of plane = input feature i, K = output feature j; scale per i.
-// grid (B, layers, parts): a workgroup takes K range [part * h / parts, ...) of every row; thread = row i (coalesced
-// reads along i).  flags: bit 0 = a weight that is not finite and < 2^100.
+// grid (B, layers, h / 16): a workgroup takes 16 rows i (= 16 columns of W: 128-byte segments per matrix row) and all of K;
+// thread (i = tid & 15, jg = tid >> 4) holds the row's entries j = 64 kc + 4 jg + r (a K-slot word per kc) in registers for
+// both passes (row maximum through LDS, then digits), and the 16 rows' planes leave through LDS as whole 16-byte pieces --
+// one thread per row reading a column of W serially and storing single words h bytes apart took 94 us at the cfg3 shape
+// (33 MB).  flags: bit 0 = a weight that is not finite and < 2^100.
 template <int LMIN>
 __global__ __launch_bounds__(256) void k_i8_slice_wT(I8Net net, const double* __restrict__ W, unsigned char* __restrict__ Wd,
                                                     double* __restrict__ sc, int* __restrict__ flags) {
+    constexpr int KCM = 4;                                       // h <= 256
+    __shared__ unsigned exs[16][17];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[NS][16][64 * KCM];
     const int b = blockIdx.x, li = blockIdx.y, tid = threadIdx.x;
-    const int h = net.h[li];                                     // square hidden matrices
+    const int h = net.h[li], nkc = h >> 6;                       // square hidden matrices, h in {128, 256}
     const double* Wg = W + (int64_t)b * net.p + net.offW[li];
     unsigned char* planes = Wd + (int64_t)b * net.dbytes + net.offD[li];
     double* scl = sc + (int64_t)b * net.sdoubles + net.offS[li];
     const int64_t plane = (int64_t)h * h;
-    const int kper = h / gridDim.z, j0 = blockIdx.z * kper;
+    const int il = tid & 15, jg = tid >> 4, i = blockIdx.z * 16 + il;
     int bad = 0;
-    for (int i = tid; i < h; i += 256) {
-        unsigned ex = 0;
-#pragma unroll 16
-        for (int j = 0; j < h; ++j) {                                 // (16 independent loads in flight)
-            const double v = Wg[(int64_t)j * h + i];
-            bad |= !qn_bounded100(v);
-            ex = max(ex, ((unsigned)__double2hiint(v) & 0x7fffffffu) >> 20);
+    double v[KCM][4];
+    unsigned ex = 0;
+#pragma unroll
+    for (int kc = 0; kc < KCM; ++kc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[kc][r] = kc < nkc ? Wg[(int64_t)(64 * kc + 4 * jg + r) * h + i] : 0.0;
+            bad |= !qn_bounded100(v[kc][r]);
+            ex = max(ex, ((unsigned)__double2hiint(v[kc][r]) & 0x7fffffffu) >> 20);
         }
-        int e = (int)ex - 1022;
-        bad |= e > I8_MAX_WEIGHT_EXP;
-        e = e < -900 ? -900 : e;
-        const double dn = ldexp(1.0, -e);
-        for (int j = j0; j < j0 + kper; j += 4) {
+    exs[il][jg] = ex;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) ex = max(ex, exs[il][g]);
+    int e = (int)ex - 1022;
+    bad |= e > I8_MAX_WEIGHT_EXP;
+    e = e < -900 ? -900 : e;
+    const double dn = ldexp(1.0, -e);
+    const int m = jg >> 2, g4 = jg & 3;
+#pragma unroll
+    for (int kc = 0; kc < KCM; ++kc) {
+        if (kc < nkc) {
             double an[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) an[r] = Wg[(int64_t)(j + r) * h + i] * dn;      // exact
+            for (int r = 0; r < 4; ++r) an[r] = v[kc][r] * dn;      // exact
             int S[NS];
             slice4(an, S);
-            const int kc = j >> 6, m = (j & 63) >> 4, g = (j & 15) >> 2;
-            unsigned char* dst = planes + (int64_t)i * h + 64 * kc + 16 * (g ^ slot_swz(i)) + 4 * m;
 #pragma unroll
-            for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(dst + k * plane) = S[k];
+            for (int k = 0; k < NS; ++k)
+                *reinterpret_cast<int*>(&stage[k][il][64 * kc + 16 * (g4 ^ slot_swz(i)) + 4 * m]) = S[k];
         }
-        if (blockIdx.z == 0) scl[i] = ldexp(1.0, e - 2 * QB + 8 * LMIN);
+    }
+    if (jg == 0) scl[i] = ldexp(1.0, e - 2 * QB + 8 * LMIN);
+    __syncthreads();
+    // plane k, rows 16 z .. 16 z + 15: 16 h contiguous bytes
+    const int per_plane = 16 * h / 16;                           // 16-byte pieces
+    for (int pc = tid; pc < NS * per_plane; pc += 256) {
+        const int k = pc / per_plane, o = (pc - k * per_plane) * 16, row = o / h, col = o - row * h;
+        *reinterpret_cast<uint4*>(planes + k * plane + (int64_t)(blockIdx.z * 16 + row) * h + col) =
+            *reinterpret_cast<const uint4*>(&stage[k][row][col]);
     }
     if (net.has_bias && blockIdx.z == 0)
-        for (int i = tid; i < h; i += 256) bad |= !qn_bounded100(W[(int64_t)b * net.p + net.offB[li] + i]);
+        for (int t = tid; t < h; t += 256) bad |= !qn_bounded100(W[(int64_t)b * net.p + net.offB[li] + t]);
     if (__any(bad) && (tid & 63) == 0) atomicOr(&flags[b], 1);
 }
 
@@ -582,19 +604,21 @@ template <int KC>
 __device__ __noinline__ void wide_slow_bwd_rows(int Nb, int d, int nhid, int has_bias, int64_t act_stride, int64_t dz_stride,
                                                 const double* __restrict__ Wb, int nbase, int b, double* __restrict__ scr,
                                                 const double* __restrict__ act0, const double* __restrict__ dz_last,
-                                                double* __restrict__ dz0) {
+                                                double* __restrict__ dz0, double* __restrict__ dwl_acc) {
     constexpr int HID = 64 * KC;
     const int lane = threadIdx.x & 63, nb = has_bias ? 1 : 0;
     const int64_t gHH = (int64_t)HID * d + nb * HID, blk = (int64_t)HID * HID + nb * HID, gWl = gHH + (int64_t)(nhid - 1) * blk;
     for (int n = nbase; n < nbase + 16 && n < Nb; ++n) {
         const double dzl = dz_last[(int64_t)b * Nb + n];
         double g[KC];
+        if (dwl_acc && lane == 0) dwl_acc[HID] += dzl;                 // (this wave's LDS slots: lane j owns entries j, j + 64, ...)
 #pragma unroll
         for (int m = 0; m < KC; ++m) {
             const int64_t idx = ((int64_t)b * HID + lane + 64 * m) * Nb + n;
             const double av = act0[(nhid - 1) * act_stride + idx];
             g[m] = (Wb[gWl + lane + 64 * m] * dzl) * (1.0 - av * av);
             dz0[(nhid - 1) * dz_stride + idx] = g[m];
+            if (dwl_acc) dwl_acc[lane + 64 * m] = fma(dzl, av, dwl_acc[lane + 64 * m]);
         }
         for (int li = nhid - 2; li >= 0; --li) {
             double* cur = scr + HID * (li & 1);
@@ -621,7 +645,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
                                                        const int32_t* __restrict__ row_idx, const unsigned char* __restrict__ WdT,
                                                        const double* __restrict__ scT, const int* __restrict__ flags,
                                                        const double* __restrict__ act0, const double* __restrict__ dz_last,
-                                                       double* __restrict__ dz0, double* __restrict__ dump) {
+                                                       double* __restrict__ dz0, double* __restrict__ dump, double* __restrict__ dwl_out) {
     constexpr int HID = 64 * KC, TL = 4 * KC, TILE_B = KC * NS * 1024, PLANE = HID * HID, LAYERB = NS * PLANE;
     constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN), NPT = NPROD * KC;
     extern __shared__ __attribute__((aligned(16))) char smemb[];
@@ -631,6 +655,11 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
     const int NH = a.nhid, NHH = NH - 1, d = a.d, nb = a.has_bias ? 1 : 0;
     const int offred = HID, offsc = HID + 8;
     double* scratch = lds + ((offsc + NHH * HID + 1) & ~1);
+    // The output layer's weight gradient dWl[f] = sum_n dz_last[n] a[f][n], dbl = sum_n dz_last[n] rides on the top phase,
+    // which has a[f][n] and dz_last[n] in registers and waits for memory (the separate kernel read the activations -- 1 GB at
+    // the cfg3 shape -- once more): at h = 128, where 32 more accumulators per lane fit.  dwl_out: [B][nsplit][HID + 1].
+    constexpr bool FOLD = KC == 2;
+    double* slow_acc = scratch + 4 * 2 * HID;                           // [4 waves][HID + 8]: rows that took the plain-float64 path
     unsigned char* ring = reinterpret_cast<unsigned char*>(lds + wideb_head(HID, NH));
     double* red = lds + offred;
     const double* Wb = W + (int64_t)b * a.p;
@@ -680,6 +709,16 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
         const double* scs = scT + (int64_t)b * NHH * HID;
         for (int e = tid; e < NHH * HID; e += WWG) lds[offsc + e] = scs[e];
     }
+    double dwl[FOLD ? TL : 1][4];
+    double dbl = 0.0;
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int t = 0; t < TL; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dwl[t][r] = 0.0;
+        for (int e = tid; e < 4 * (HID + 8); e += WWG) slow_acc[e] = 0.0;
+    }
+    const bool fold = FOLD && dwl_out != nullptr;
     const bool w_bad = block_or(bad, red + 6);
 
     const int lofs = c * 64 + 16 * (q ^ slot_swz(c));
@@ -696,7 +735,8 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
         const bool exceptional = block_or(w_bad | xbad, red + 6);
         if (exceptional) {
             wide_slow_bwd_rows<KC>(a.Nb, d, NH, a.has_bias, a.act_stride, a.dz_stride, Wb,
-                                   split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave, act0, dz_last, dz0);
+                                   split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave, act0, dz_last, dz0,
+                                   fold ? slow_acc + (HID + 8) * wave : nullptr);
             // (flat loads / stores in there complete out of order: drain them before the counted vmcnt waits resume)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             continue;
@@ -718,6 +758,8 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
             const double* ap = act0 + (int64_t)(NH - 1) * a.act_stride + erow;
             double* zp = dz0 + (int64_t)(NH - 1) * a.dz_stride + erow;
             double abuf[2][16];
+            const double dze = live ? dzl : 0.0;                          // (rows beyond Nb read row 0: no contribution)
+            if (q == 0) dbl += dze;
             auto load_batch = [&](int bi, double (&dst)[16]) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -734,6 +776,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
                     for (int r = 0; r < 4; ++r) {
                         const int T_ = 4 * bi + t;
                         const double av = abuf[bi & 1][4 * t + r];
+                        if constexpr (FOLD) dwl[T_][r] = fma(dze, av, dwl[T_][r]);
                         const double v = (lds[16 * T_ + 4 * q + r] * dzl) * fma(-av, av, 1.0);
                         (live ? zp + (int64_t)(16 * T_) * a.Nb : dmp)[(int64_t)r * a.Nb] = v;
                         amax = fmax(amax, fabs(v));
@@ -871,6 +914,41 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
                (long long)(__builtin_amdgcn_s_memtime() - st_t0), st_sync, st_burst, st_epi, st_top, st_slice);
 #endif
     __syncthreads();                                     // (vmcnt(0): the tiles fetched ahead have landed before the LDS is released)
+    if constexpr (FOLD) {
+        if (fold) {
+            // sum over the 16 lanes (rows) that hold the same features, one slot per wave in the (now idle) scratch area,
+            // then the four waves and the plain-float64 rows in a fixed order
+            double* part = scratch + 2 * HID * wave;
+#pragma unroll
+            for (int t = 0; t < TL; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double v = dwl[t][r];
+                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                    if (c == 0) part[16 * t + 4 * q + r] = v;
+                }
+            double vb = dbl;                                      // (nonzero on the lanes q = 0 only)
+            vb += __shfl_xor(vb, 1, 64); vb += __shfl_xor(vb, 2, 64); vb += __shfl_xor(vb, 4, 64); vb += __shfl_xor(vb, 8, 64);
+            if (lane == 0) part[HID] = vb;
+            __syncthreads();
+            for (int e = tid; e < HID + 1; e += WWG) {
+                double sv = (scratch[e] + scratch[2 * HID + e]) + (scratch[4 * HID + e] + scratch[6 * HID + e]);
+                sv += (slow_acc[e] + slow_acc[(HID + 8) + e]) + (slow_acc[2 * (HID + 8) + e] + slow_acc[3 * (HID + 8) + e]);
+                dwl_out[((int64_t)b * a.nsplit + split) * (HID + 1) + e] = sv;
+            }
+        }
+    }
+}
+
+// gradW[b][offW + f] = sum over the row splits of the output layer's partial weight gradients (entry h: the bias)
+__global__ void k_wide_dwl_sum(const double* __restrict__ slab, int nsplit, int h, int has_bias, int64_t p, int64_t offW, int64_t offB,
+                               double* __restrict__ gradW) {
+    const int b = blockIdx.x;
+    for (int e = threadIdx.x; e < h + (has_bias ? 1 : 0); e += blockDim.x) {
+        double sv = 0.0;
+        for (int k = 0; k < nsplit; ++k) sv += slab[((int64_t)b * nsplit + k) * (h + 1) + e];
+        gradW[(int64_t)b * p + (e < h ? offW + e : offB)] = sv;
+    }
 }
 
 __global__ void k_wide_sum(const double* __restrict__ partial, int nsplit, int B, double* __restrict__ sse) {
@@ -935,8 +1013,10 @@ size_t qn_i8_wide_workspace(const qn_desc* d, int B, int Nb, int want_grad) {
                  qn_align((size_t)B * sizeof(int)) + qn_align((size_t)B * a.nsplit * sizeof(double)) +
                  qn_align(((size_t)3 * Nb + 64) * sizeof(double));
     // backward: digit planes of the transposed matrices | their scales | chain flags
+    // ... | (h = 128) per-split partial sums of the output layer's weight gradient
     if (want_grad)
-        tot += qn_align((size_t)B * nhh * NS * h * h) + qn_align((size_t)B * nhh * h * sizeof(double)) + qn_align((size_t)B * sizeof(int));
+        tot += qn_align((size_t)B * nhh * NS * h * h) + qn_align((size_t)B * nhh * h * sizeof(double)) + qn_align((size_t)B * sizeof(int)) +
+               qn_align((size_t)B * a.nsplit * (h + 1) * sizeof(double));
     return tot;
 }
 // One launch: sse [B] (+ pred [B][Nb], dz_last [B][Nb] = 2 (pred - y), hidden activations act0 + l * act_stride
@@ -993,9 +1073,12 @@ int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const
 // dZ_l = d sse / d (pre-activation of hidden layer l), l = 0 .. L-2, as float64 [B][h][Nb] at dz0 + l * dz_stride, from the
 // forward's stashed activations (act0 + l * act_stride) and dz_last = 2 (pred - y).  `ws` is the SAME workspace the forward
 // call of this evaluation used (its dump area is shared; the backward's own regions lie behind the forward's).
+// gradW (may be null): the flat gradient [B][p]; at h = 128 the OUTPUT layer's weight / bias gradient is written there too
+// (*last_done = 1: the caller skips its own kernel for that layer)
 int qn_i8_wide_backward(const qn_desc* d, const double* W, const double* X, const int32_t* row_idx, int B, int Nb,
                         const double* act0, int64_t act_stride, const double* dz_last, double* dz0, int64_t dz_stride, void* ws,
-                        hipStream_t st) {
+                        double* gradW, int* last_done, hipStream_t st) {
+    if (last_done) *last_done = 0;
     if (!qn_i8_wide_applies(d)) return QN_EUNSUPPORTED;
     const int h = d->dims[1], nhh = d->nlayers - 2;
     I8Net net;
@@ -1019,21 +1102,30 @@ int qn_i8_wide_backward(const qn_desc* d, const double* W, const double* X, cons
     double* scT = reinterpret_cast<double*>(base);
     base += qn_align((size_t)B * net.sdoubles * sizeof(double));
     int* flags = reinterpret_cast<int*>(base);
+    base += qn_align((size_t)B * sizeof(int));
+    double* dwl_slab = reinterpret_cast<double*>(base);
+    const bool fold_last = h == 128 && gradW != nullptr && last_done != nullptr;
     WideBwdArgs a;
     a.p = d->p; a.act_stride = act_stride; a.dz_stride = dz_stride; a.B = B; a.Nb = Nb; a.d = d->dims[0];
     a.nhid = d->nlayers - 1; a.has_bias = d->has_bias;
     a.nsplit = fa.nsplit; a.rows_per_split = fa.rows_per_split; a.iters = fa.iters;
     QN_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), st));
-    hipLaunchKernelGGL((k_i8_slice_wT<QN_I8_LMIN>), dim3(B, nhh, 4), dim3(256), 0, st, net, W, WdT, scT, flags);
+    hipLaunchKernelGGL((k_i8_slice_wT<QN_I8_LMIN>), dim3(B, nhh, h / 16), dim3(256), 0, st, net, W, WdT, scT, flags);
     const int dp = a.d <= 2 ? 2 : 4;
     const size_t lds = wideb_lds_bytes(h / 64, a.nhid);
     using kfn = void (*)(WideBwdArgs, const double*, const double*, const int32_t*, const unsigned char*, const double*,
-                         const int*, const double*, const double*, double*, double*);
+                         const int*, const double*, const double*, double*, double*, double*);
     kfn kern = h == 128 ? (dp == 2 ? k_i8_wide_bwd<2, 2, QN_I8_LMIN> : k_i8_wide_bwd<2, 4, QN_I8_LMIN>)
                         : (dp == 2 ? k_i8_wide_bwd<4, 2, QN_I8_LMIN> : k_i8_wide_bwd<4, 4, QN_I8_LMIN>);
     if (int rc = wide_arm(reinterpret_cast<const void*>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(qn_fused_grid(a.nsplit, B)), dim3(WWG), lds, st, a, W, X, row_idx, (const unsigned char*)WdT,
-                       (const double*)scT, (const int*)flags, act0, dz_last, dz0, dump);
+                       (const double*)scT, (const int*)flags, act0, dz_last, dz0, dump, fold_last ? dwl_slab : (double*)nullptr);
+    if (fold_last) {
+        const int L = d->nlayers;
+        hipLaunchKernelGGL(k_wide_dwl_sum, dim3(B), dim3(192), 0, st, (const double*)dwl_slab, a.nsplit, h, d->has_bias, d->p,
+                           d->offW[L - 1], d->offB[L - 1], gradW);
+        *last_done = 1;
+    }
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }
