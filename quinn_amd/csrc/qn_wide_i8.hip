@@ -27,6 +27,10 @@
 #include <mutex>
 #include <unordered_set>
 
+#ifndef QN_WIDE_FOLD_ALL
+#define QN_WIDE_FOLD_ALL 0            // 1: the output layer's weight gradient rides on the backward kernel at h = 256 too (A/B)
+#endif
+
 namespace {
 
 constexpr int WNBUF = 3;                    // ring of weight-tile buffers
@@ -658,7 +662,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
     // The output layer's weight gradient dWl[f] = sum_n dz_last[n] a[f][n], dbl = sum_n dz_last[n] rides on the top phase,
     // which has a[f][n] and dz_last[n] in registers and waits for memory (the separate kernel read the activations -- 1 GB at
     // the cfg3 shape -- once more): at h = 128, where 32 more accumulators per lane fit.  dwl_out: [B][nsplit][HID + 1].
-    constexpr bool FOLD = KC == 2;
+    constexpr bool FOLD = QN_WIDE_FOLD_ALL || KC == 2;
     double* slow_acc = scratch + 4 * 2 * HID;                           // [4 waves][HID + 8]: rows that took the plain-float64 path
     unsigned char* ring = reinterpret_cast<unsigned char*>(lds + wideb_head(HID, NH));
     double* red = lds + offred;
@@ -1104,7 +1108,7 @@ int qn_i8_wide_backward(const qn_desc* d, const double* W, const double* X, cons
     int* flags = reinterpret_cast<int*>(base);
     base += qn_align((size_t)B * sizeof(int));
     double* dwl_slab = reinterpret_cast<double*>(base);
-    const bool fold_last = h == 128 && gradW != nullptr && last_done != nullptr;
+    const bool fold_last = (h == 128 || QN_WIDE_FOLD_ALL) && gradW != nullptr && last_done != nullptr;
     WideBwdArgs a;
     a.p = d->p; a.act_stride = act_stride; a.dz_stride = dz_stride; a.B = B; a.Nb = Nb; a.d = d->dims[0];
     a.nhid = d->nlayers - 1; a.has_bias = d->has_bias;
