@@ -46,7 +46,8 @@ from ..ops import BatchedMLP
 
 class DeviceAMCMC:
     def __init__(self, op: BatchedMLP, sigma, gamma=0.1, t0=100, tadapt=1000, cov_ini=None, seed=0,
-                 use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=True, groups=1, max_rows=4096):
+                 use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=True, groups=1, max_rows=4096,
+                 overlap_hist=True):
         if op.dtype != "float64":
             raise NotImplementedError("the device AMCMC engine runs the float64 operator")
         self.op, self.sigma = op, float(sigma)
@@ -70,6 +71,12 @@ class DeviceAMCMC:
         # block by block from this one host thread: a group's small kernels (accept, apply-delta, partial sums --
         # a fifth of a step at cfg2, one workgroup per chain) overlap the other groups' forward kernels
         self.groups = max(1, int(groups))
+        # the increments of the NEXT block of TB steps are formed on a second stream while the current block's steps run
+        # (they depend on the frozen snapshot and the step numbers only): the history product streams the chains'
+        # histories from HBM, the log-posterior kernel is bound by vector issue, and the accept kernels leave most of the
+        # GPU idle.  Same random numbers, same results (tests/test_gpu_device_amcmc.py)
+        self.overlap_hist = bool(overlap_hist) and not os.environ.get("QUINN_AMD_NO_HIST_OVERLAP")
+        self._side = None
         self._subs = None
         self._L = _lib.lib()
 
@@ -88,11 +95,13 @@ class DeviceAMCMC:
                                            sd.data_ptr() if sd is not None else None, c1, C, self.chain0, p, self.seed,
                                            self._step_ptr(s), out.data_ptr(), self._stream()), "qn_mcmc_propose")
 
-    def _propose_hist_block(self, s, snap, coef, delta):
+    def _propose_hist_block(self, s, snap, coef, delta, step_abs=None):
+        """Increments of TB steps from the device step counter on (step_abs None), or from the absolute step step_abs."""
         C, _, p = delta.shape
         _lib.check(self._L.qn_mcmc_propose_hist_block(
             s['hist'].data_ptr(), snap['w'].data_ptr(), snap['k'].data_ptr(), snap['mean'].data_ptr(), snap['s_lr'],
-            snap['s_iso'], C, self.chain0, p, s['hist'].shape[2], s['hist'].shape[1], self.seed, 0, self._step_ptr(s),
+            snap['s_iso'], C, self.chain0, p, s['hist'].shape[2], s['hist'].shape[1], self.seed,
+            0 if step_abs is None else int(step_abs), self._step_ptr(s) if step_abs is None else None,
             coef.data_ptr(),
             delta.data_ptr(), None if os.environ.get("QUINN_AMD_NO_ORDER") else snap['order'].data_ptr(),     # (env: A/B)
             self._stream()), "qn_mcmc_propose_hist_block")
@@ -149,7 +158,8 @@ class DeviceAMCMC:
             op = self.op
             engs = [DeviceAMCMC(BatchedMLP(op.arch, op.X, op.Y, device=op.device, dtype=op.dtype), self.sigma, self.gamma,
                                 self.t0, self.tadapt, self.cov_ini, self.seed, self.use_graph, self.max_history_bytes,
-                                self.chain0 + bounds[g], self.fuse_propose, max_rows=self.max_rows) for g in range(G)]
+                                self.chain0 + bounds[g], self.fuse_propose, max_rows=self.max_rows,
+                                overlap_hist=self.overlap_hist) for g in range(G)]
             self._subs = (engs, [torch.cuda.Stream(device=self.dev) for _ in range(G)])
         engs, streams = self._subs
         chain = torch.empty(C, nmcmc + 1, p, dtype=torch.float64, device=self.dev) if store_chain else None
@@ -282,7 +292,8 @@ class DeviceAMCMC:
         if getattr(self, '_bufs', None) is not None and self._bufs[0] == key:
             return self._bufs[1], self._bufs[2]
         coef = torch.empty(C * ((kcap + 3) // 4 * 4 + 1) * TB, dtype=torch.float32, device=dev)
-        delta = torch.empty(C, TB, p, dtype=torch.float64, device=dev)
+        # (two increment buffers: the next block's is written while the current one is read)
+        delta = torch.empty(2 if self.overlap_hist else 1, C, TB, p, dtype=torch.float64, device=dev)
         self._bufs = (key, coef, delta)
         k = torch.zeros(C, dtype=torch.int32, device=dev)
         torch.argsort(k, descending=True).to(torch.int32)
@@ -350,7 +361,7 @@ class DeviceAMCMC:
         s['lps'][:, 0] = cur_lp
         std0 = torch.sqrt(0.09 * s['x0'].abs())
         prop = torch.empty(C, p, dtype=f64, device=dev)
-        state = {'snap': None, 'L': None, 'have_prop': False}
+        state = {'snap': None, 'L': None, 'have_prop': False, 'dbuf': 0, 'ahead': None}
         if self.cov_ini is not None:
             state['L'] = torch.linalg.cholesky(torch.as_tensor(np.asarray(self.cov_ini), dtype=f64, device=dev))
             z = torch.empty(C, p, dtype=f64, device=dev)
@@ -381,17 +392,37 @@ class DeviceAMCMC:
                 have = nxt is not None
             return have
 
-        def block_adapted(nsteps):
+        def block_adapted(nsteps, step_abs=None, more=False):
             # increments of TB consecutive steps in ONE pass over the history (they do not depend on the chain's
             # state), then nsteps <= TB steps; the block starts at the device step counter.  With fusion the accept
-            # kernel of step t writes the proposal of step t + 1 (inside the block)
-            self._propose_hist_block(s, state['snap'], coef, delta)
+            # kernel of step t writes the proposal of step t + 1 (inside the block).
+            # step_abs (= the device step counter, known to the host): the block's increments may have been formed
+            # ahead on the side stream; more: another block of this window follows -- form ITS increments meanwhile
             snap = state['snap']
+            overlap = self.overlap_hist and step_abs is not None
+            buf = state['dbuf'] if overlap else 0
+            dl = delta[buf]
+            if overlap and state['ahead'] is not None:
+                torch.cuda.current_stream(dev).wait_event(state['ahead'])
+                state['ahead'] = None
+            else:
+                self._propose_hist_block(s, snap, coef, dl, step_abs)
+            if overlap and more:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=dev)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))                     # (the other buffer's last readers are enqueued before this)
+                self._side.wait_event(ev)
+                with torch.cuda.stream(self._side):
+                    self._propose_hist_block(s, snap, coef, delta[1 - buf], step_abs + TB)
+                    state['ahead'] = torch.cuda.Event()
+                    state['ahead'].record(self._side)
+                state['dbuf'] = 1 - buf
             have = False
             for t in range(nsteps):
                 if not have:
-                    self._apply_delta(s, snap, delta, t, prop)
-                nxt = (2, None, 0.0, delta, t + 1, snap['s_iso']) if fuse and t + 1 < nsteps else None
+                    self._apply_delta(s, snap, dl, t, prop)
+                nxt = (2, None, 0.0, dl, t + 1, snap['s_iso']) if fuse and t + 1 < nsteps else None
                 self._accept(s, prop, self.op.sse_parts(prop), nmcmc, nxt)
                 have = nxt is not None
 
@@ -451,7 +482,7 @@ class DeviceAMCMC:
                 while rest > 0:
                     if _tm and rest == nrun:
                         torch.cuda.synchronize(dev); _t1 = _time.perf_counter()
-                    block_adapted(min(rest, TB))
+                    block_adapted(min(rest, TB), None if self.use_graph else i + nrun - rest, rest > TB)
                     if _tm and rest == nrun:
                         torch.cuda.synchronize(dev); print("[timing] step %d: first adapted block of %d steps %.1f ms" % (i, min(rest, TB), 1e3 * (_time.perf_counter() - _t1)), flush=True, file=__import__("sys").stderr)
                     rest -= min(rest, TB)

@@ -226,6 +226,28 @@ def test_fused_next_proposal_is_bit_identical(graph):
     assert (a['accrate'] > 0).all()
 
 
+def test_history_product_formed_ahead_is_bit_identical():
+    """The next block's increments formed on a second stream while the current block's steps run (`overlap_hist`) use the
+    same step numbers, snapshot and arithmetic as the product at the block's start: identical chains, over several
+    windows (adaptations reset the look-ahead), windows that are not whole blocks, bounded histories and groups."""
+    from quinn_amd.mcmc.device_amcmc import DeviceAMCMC
+    from quinn_amd.ops import MLPArch, BatchedMLP
+    x, y = _problem(6)
+    arch = MLPArch((1, 8, 8, 1), "tanh")
+    op = BatchedMLP(arch, x, y)
+    C, nmcmc = 6, 1230
+    ini = np.stack([np.random.RandomState(700 + c).rand(arch.nparams) for c in range(C)])
+    for kw in (dict(gamma=0.1, t0=40, tadapt=300, seed=3), dict(gamma=0.1, t0=40, tadapt=200, seed=3, max_rows=320),
+               dict(gamma=0.1, t0=100, tadapt=450, seed=5, groups=2)):
+        a = DeviceAMCMC(op, 0.2, overlap_hist=False, **kw).run(nmcmc, ini)
+        eng = DeviceAMCMC(op, 0.2, overlap_hist=True, **kw)
+        assert eng.overlap_hist
+        b = eng.run(nmcmc, ini)
+        for k in ('chain', 'logpost', 'alphas', 'accrate', 'mapparams', 'maxpost'):
+            assert torch.equal(a[k], b[k]), (kw, k)
+        assert (a['accrate'] > 0).all()
+
+
 def test_graph_replay_with_odd_stretches_equals_direct_launches():
     """A captured block bakes in the step-parity slots it starts from; an odd number of directly launched steps between
     two replays (odd `tadapt`, t0 > tadapt) flips the parity, so the engine keeps one graph per starting parity."""
