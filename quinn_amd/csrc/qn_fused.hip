@@ -1291,6 +1291,9 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
         if (uses_i8(d, want_grad)) {
             kern = qn_fused_i8_kernel(a.d, a.o);
             lds_bytes = qn_fused_i8_lds_bytes(a.d, nhid);
+#ifdef QN_DEBUG_LDS_PAD
+            if (const char* pad = getenv("QN_DEBUG_LDS_PAD")) lds_bytes += (size_t)atoi(pad);     // (occupancy experiments)
+#endif
         }
         if (!kern) {
             qn_set_error("qn_fused_run: no forward kernel instance for H=%d act=%d", H, a.act);

@@ -116,11 +116,11 @@ def test_padded_twin_takes_the_wide_kernel():
 
 
 @pytest.mark.parametrize("where", ["weight_nan", "weight_inf", "weight_huge", "bias_nan", "x_nan", "x_inf", "w0_inf", "wl_nan"])
-@pytest.mark.parametrize("h", [128, 256])
-def test_exceptional_values_follow_the_layerwise_kernels(where, h):
+@pytest.mark.parametrize("h,N", [(128, 150), (256, 150), (128, 192), (256, 320)])       # (whole 64-row chunks: k_i8_dw_g)
+def test_exceptional_values_follow_the_layerwise_kernels(where, h, N):
     dims = (1, h, h, h, 1)
     arch = MLPArch(dims, "tanh")
-    x, y = _data(150, 1, seed=1)
+    x, y = _data(N, 1, seed=1)
     rs = np.random.RandomState(2)
     W = 0.2 * rs.randn(3, arch.nparams)
     off_w1 = h + h + 5 * h + 7                               # an entry of the first hidden matrix
@@ -168,10 +168,11 @@ def test_forward_only_calls_at_width_128_leave_the_streaming_kernel():
 TINY = [((2, 64, 64, 64, 64, 1), 700, 3, False), ((1, 64, 64, 64, 1), 130, 2, True),           # fused 64-wide forward
         ((2, 128, 128, 128, 128, 128, 1), 1754, 1, False), ((3, 256, 256, 256, 1), 300, 4, False),   # wide forward / backward / dW
         ((3, 128, 128, 128, 1), 200, 3, True), ((6, 128, 128, 128, 128, 1), 257, 2, False),    # d = 6: layer-wise int8 forward
-        ((2, 100, 100, 100, 1), 150, 2, False)]                                                # padded twin
+        ((2, 100, 100, 100, 1), 150, 2, False),                                                # padded twin
+        ((2, 128, 128, 128, 1), 512, 2, False), ((1, 256, 256, 256, 1), 320, 3, False)]        # whole chunks: group-scale dW
 
 
-@pytest.mark.parametrize("dims,N,B,bias", TINY, ids=[f"{c[0][1]}x{len(c[0]) - 2}_d{c[0][0]}{'' if c[3] else '_nobias'}" for c in TINY])
+@pytest.mark.parametrize("dims,N,B,bias", TINY, ids=[f"{c[0][1]}x{len(c[0]) - 2}_d{c[0][0]}_N{c[1]}{'' if c[3] else '_nobias'}" for c in TINY])
 @pytest.mark.parametrize("wscale", [1e-3, 3e-2])
 def test_tiny_activations_keep_relative_accuracy(dims, N, B, bias, wscale):
     """Weights ~ 1e-3 (and no bias): activations shrink layer by layer (1e-2, 1e-4, ... 1e-10).  The int8-slice kernels

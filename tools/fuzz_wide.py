@@ -18,6 +18,7 @@ for case in range(ncases):
     if big:                                         # many rows / many vectors: other row splits, grids beyond one wave of workgroups
         N = int(rs.randint(3000, 40000)); B = int(rs.randint(1, max(2, 1500000 // N)))
         if rs.rand() < 0.3: N, B = int(rs.randint(1, 300)), int(rs.randint(300, 3000))
+    if h >= 128 and rs.rand() < 0.5: N = max(64, N // 64 * 64)      # whole 64-row chunks: the group-scale weight-gradient kernel
     bias = bool(rs.rand() < 0.8); wscale = float(rs.choice([1e-3, 0.1, 1.0, 4.0])) / np.sqrt(h)
     dims = (d,) + (h,) * nhid + (1,)
     arch = MLPArch(dims, "tanh", bias=bias)
