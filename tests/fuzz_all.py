@@ -565,6 +565,14 @@ if __name__ == "__main__":
     nc, sd = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0
     first = lambda r: r[0] if isinstance(r, tuple) else r
     total = 0
+    # a heartbeat on stderr once a minute: the host-sampler family runs minutes of CPU-side reference loops without a line of
+    # output, and a GPU box takes seven silent minutes for a hang
+    import threading
+    _stop = threading.Event()
+    def _beat():
+        while not _stop.wait(60.0):
+            print("[fuzz_all] running", flush=True, file=sys.stderr)
+    threading.Thread(target=_beat, daemon=True).start()
     for name, fn, n in (("operator", run, nc), ("residual networks", run_rnet, max(10, nc // 2)), ("ELBO", run_vi, max(10, nc // 4)),
                         ("not-finite values", run_exceptional, nc), ("training loops", run_fit, max(10, nc // 5)),
                         ("ensembles", run_ens, max(6, nc // 10)), ("VI fits", run_vifit, max(6, nc // 10)),
