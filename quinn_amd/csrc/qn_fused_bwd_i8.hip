@@ -169,20 +169,21 @@ __device__ __forceinline__ void tanh_tab64_n(const double (&z)[N], double (&out)
     for (int r = 0; r < N; ++r) b3[r] = bb[r] * b2[r];
 #pragma unroll
     for (int r = 0; r < N; ++r) tb[r] = fma(b3[r], pp[r], bb[r]);
+    // (reciprocal-free tail of qn_tanh_f64_tab64: T + (1 - T^2) tb (1 - e)(1 + e^2 + e^4), e = T tb)
 #pragma unroll
-    for (int r = 0; r < N; ++r) num[r] = Tt[r] + tb[r];
+    for (int r = 0; r < N; ++r) num[r] = Tt[r] * tb[r];                 // e
 #pragma unroll
-    for (int r = 0; r < N; ++r) den[r] = fma(Tt[r], tb[r], 1.0);
+    for (int r = 0; r < N; ++r) den[r] = fma(-Tt[r], Tt[r], 1.0);       // 1 - T^2
 #pragma unroll
-    for (int r = 0; r < N; ++r) y0[r] = __builtin_amdgcn_rcp(den[r]);
+    for (int r = 0; r < N; ++r) e0[r] = num[r] * num[r];                // e^2
 #pragma unroll
-    for (int r = 0; r < N; ++r) e0[r] = fma(-den[r], y0[r], 1.0);
+    for (int r = 0; r < N; ++r) y0[r] = fma(-tb[r], num[r], tb[r]);     // tb (1 - e)
 #pragma unroll
-    for (int r = 0; r < N; ++r) e0[r] = fma(e0[r], e0[r], e0[r]);
+    for (int r = 0; r < N; ++r) e0[r] = fma(e0[r], e0[r], e0[r]);       // e^2 + e^4
 #pragma unroll
-    for (int r = 0; r < N; ++r) y0[r] = fma(y0[r], e0[r], y0[r]);
+    for (int r = 0; r < N; ++r) y0[r] = fma(y0[r], e0[r], y0[r]);       // u
 #pragma unroll
-    for (int r = 0; r < N; ++r) out[r] = __builtin_copysign(num[r] * y0[r], z[r]);
+    for (int r = 0; r < N; ++r) out[r] = __builtin_copysign(fma(den[r], y0[r], Tt[r]), z[r]);
 }
 // quad_xpose for N words, step-major (a DPP move needs two wait states behind the instruction that wrote its source)
 template <int N>

@@ -406,25 +406,28 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
                     case 8:
                         tb[r] = fma(b2[r], pp[r], bb[r]);
                         break;
+                    // (qn_tanh_f64_tab64 of qn_math.h, reciprocal-free tail: T + (1 - T^2) tb (1 - e)(1 + e^2 + e^4), e = T tb)
                     case 9:
-                        num[r] = Tt[r] + tb[r];
-                        den[r] = fma(Tt[r], tb[r], 1.0);
+                        num[r] = Tt[r] * tb[r];                       // e
+                        den[r] = fma(-Tt[r], Tt[r], 1.0);             // 1 - T^2
                         break;
                     case 10:
-                        y0[r] = __builtin_amdgcn_rcp(den[r]);
+                        e0[r] = num[r] * num[r];                      // e^2
+                        y0[r] = fma(-tb[r], num[r], tb[r]);           // tb (1 - e)
                         break;
                     case 11:
-                        e0[r] = fma(-den[r], y0[r], 1.0);
+                        e0[r] = fma(e0[r], e0[r], e0[r]);             // e^2 + e^4
                         break;
                     case 12:
-                        e0[r] = fma(e0[r], e0[r], e0[r]);
+                        y0[r] = fma(y0[r], e0[r], y0[r]);             // u
                         break;
                     case 13:
-                        y0[r] = fma(y0[r], e0[r], y0[r]);
+                        num[r] = fma(den[r], y0[r], Tt[r]);
                         break;
                     case 14:
-                        av[r] = __builtin_copysign(num[r] * y0[r], z[r]);
+                        av[r] = __builtin_copysign(num[r], z[r]);
                         break;
+
                     case 15:
                         if constexpr (LAST) {
 #pragma unroll

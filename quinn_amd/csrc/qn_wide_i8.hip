@@ -362,16 +362,17 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
                         b2[r] = bb[r] * b2[r];
                         tb[r] = fma(b2[r], pp[r], bb[r]);
                     } else if constexpr (st == NLEV + 5) {
-                        num[r] = Tt[r] + tb[r];
-                        den[r] = fma(Tt[r], tb[r], 1.0);
+                        // (reciprocal-free tail of qn_tanh_f64_tab64: T + (1 - T^2) tb (1 - e)(1 + e^2 + e^4), e = T tb)
+                        num[r] = Tt[r] * tb[r];
+                        den[r] = fma(-Tt[r], Tt[r], 1.0);
                     } else if constexpr (st == NLEV + 6) {
-                        y0[r] = __builtin_amdgcn_rcp(den[r]);
+                        e0[r] = num[r] * num[r];
+                        y0[r] = fma(-tb[r], num[r], tb[r]);
                     } else if constexpr (st == NLEV + 7) {
-                        e0[r] = fma(-den[r], y0[r], 1.0);
                         e0[r] = fma(e0[r], e0[r], e0[r]);
                     } else if constexpr (st == NLEV + 8) {
                         y0[r] = fma(y0[r], e0[r], y0[r]);
-                        num[r] = num[r] * y0[r];
+                        num[r] = fma(den[r], y0[r], Tt[r]);
                     } else if constexpr (st == NLEV + 9) {
                         av[r] = __builtin_copysign(num[r], z[r]);
                         if constexpr (STASH) stp[(int64_t)r * a.Nb] = av[r];
