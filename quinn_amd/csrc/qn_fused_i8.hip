@@ -274,6 +274,11 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
 #endif
     double magic52 = 6755399441055744.0, magicS = kMagic;       // rounding constants as opaque register pairs (see the epilogue)
     asm volatile("" : "+v"(magic52), "+v"(magicS));
+    // 32-bit constants as SCALAR registers the compiler cannot see through: as literals they make every instruction 8 bytes,
+    // 7.2-7.5 issue cycles instead of 5.2 (tools/ubench_xpose.hip) -- 96 recombination fma's (65536.0), 48 residual fma's
+    // (-1/64) and 42 digit xor's per 16 rows
+    int k80;
+    asm volatile("s_mov_b32 %0, 0x80808080" : "=s"(k80));
     fetch(0);                                                   // (in flight during the staging)
 #ifdef QN_FWD8_STAMPS
     long long sst[4] = {0, 0, 0, 0};
@@ -377,13 +382,13 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
                         ts[r] = (NLEV & 1) ? (double)acc[NLEV - 1][r] : (double)(acc[NLEV - 2][r] + (acc[NLEV - 1][r] << 8));
                         break;
                     case 1:
-                        if constexpr (NLEV >= 5) { constexpr int l = ((NLEV & 1) ? NLEV - 3 : NLEV - 4); ts[r] = fma(ts[r], 65536.0, (double)(acc[l][r] + (acc[l + 1][r] << 8))); }
+                        if constexpr (NLEV >= 5) { constexpr int l = ((NLEV & 1) ? NLEV - 3 : NLEV - 4); { const double cv_ = (double)(acc[l][r] + (acc[l + 1][r] << 8)); asm("v_fma_f64 %0, %1, %2, %3" : "=v"(ts[r]) : "v"(ts[r]), "s"(65536.0), "v"(cv_)); } }
                         break;
                     case 2:
-                        if constexpr (NLEV >= 5) { constexpr int l = ((NLEV & 1) ? NLEV - 5 : NLEV - 6); ts[r] = fma(ts[r], 65536.0, (double)(acc[l][r] + (acc[l + 1][r] << 8))); }
+                        if constexpr (NLEV >= 5) { constexpr int l = ((NLEV & 1) ? NLEV - 5 : NLEV - 6); { const double cv_ = (double)(acc[l][r] + (acc[l + 1][r] << 8)); asm("v_fma_f64 %0, %1, %2, %3" : "=v"(ts[r]) : "v"(ts[r]), "s"(65536.0), "v"(cv_)); } }
                         break;
                     case 3:
-                        if constexpr (NLEV == 7) ts[r] = fma(ts[r], 65536.0, (double)(acc[0][r] + (acc[1][r] << 8)));
+                        if constexpr (NLEV == 7) { const double cv_ = (double)(acc[0][r] + (acc[1][r] << 8)); asm("v_fma_f64 %0, %1, %2, %3" : "=v"(ts[r]) : "v"(ts[r]), "s"(65536.0), "v"(cv_)); }
                         z[r] = fma(ts[r], sc[r].x, sc[r].y);
                         break;
                     case 4:
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
                         break;
                     case 5:
                         Tt[r] = tanh_tab[__double2loint(zm[r])];
-                        bb[r] = fma(zm[r] - 6755399441055744.0, -0.015625, ax[r]);
+                        { const double nf_ = zm[r] - magic52; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(bb[r]) : "v"(nf_), "s"(-0.015625), "v"(ax[r])); }
                         break;
                     case 6:
                         b2[r] = bb[r] * bb[r];
@@ -451,15 +456,15 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
                     }
                     if (st == 17) {
                         r01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400); r23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400);
-                        S[0] = __builtin_amdgcn_perm(p23, p01, 0x05040100) ^ 0x80808080;
-                        S[1] = __builtin_amdgcn_perm(p23, p01, 0x07060302) ^ 0x80808080;
+                        S[0] = __builtin_amdgcn_perm(p23, p01, 0x05040100) ^ k80;
+                        S[1] = __builtin_amdgcn_perm(p23, p01, 0x07060302) ^ k80;
                     }
                     if (st == 18) {
-                        S[2] = __builtin_amdgcn_perm(q23, q01, 0x05040100) ^ 0x80808080;
-                        S[3] = __builtin_amdgcn_perm(q23, q01, 0x07060302) ^ 0x80808080;
+                        S[2] = __builtin_amdgcn_perm(q23, q01, 0x05040100) ^ k80;
+                        S[3] = __builtin_amdgcn_perm(q23, q01, 0x07060302) ^ k80;
                     }
                     if (st == 19) {
-                        S[4] = __builtin_amdgcn_perm(r23, r01, 0x05040100) ^ 0x80808080;
+                        S[4] = __builtin_amdgcn_perm(r23, r01, 0x05040100) ^ k80;
                         S[5] = __builtin_amdgcn_perm(r23, r01, 0x07060302);
                     }
                 }
