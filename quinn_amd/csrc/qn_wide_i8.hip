@@ -61,6 +61,11 @@ __host__ __device__ constexpr size_t wide_lds_bytes(int kc, int dp, int nhid) {
 __device__ __forceinline__ void wglds16(const unsigned char* src, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory", "m0");
 }
+// the same with the address as a uniform base (scalar register pair) + a 32-bit per-lane offset: no 64-bit vector arithmetic
+// per instruction (it was a dozen v_lshl_add_u64 per weight tile and wave)
+__device__ __forceinline__ void wglds16s(unsigned voff, const unsigned char* sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
 #pragma clang diagnostic pop
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
@@ -149,18 +154,21 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c = lane & 15;
 
     // ---- the weight-tile stream: tile (li, T) = output features 16 T .. 16 T + 15 of hidden->hidden layer li, whole K
-    const unsigned char* wdc = Wd + (int64_t)b * NHH * LAYERB + (int64_t)(lane >> 2) * HID + 16 * (lane & 3);
+    const unsigned char* wbase = Wd + (int64_t)b * NHH * LAYERB;       // (uniform)
     const unsigned ring_addr = lds_addr_of(ring);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned dma_off[KC * NS / 4];                                      // this lane's byte offsets inside a tile, per DMA instruction
+#pragma unroll
+    for (int u = 0; u < KC * NS / 4; ++u) {
+        const int i = wave_u + 4 * u, kc = i / NS, wi = i - kc * NS;
+        dma_off[u] = (unsigned)((lane >> 2) * HID + 16 * (lane & 3) + wi * PLANE + 64 * kc);
+    }
     int pf_li = 0, pf_T = 0, pf_slot = 0;
     auto dma_next = [&]() {
-        const unsigned char* src = wdc + (int64_t)pf_li * LAYERB + (int64_t)(16 * pf_T) * HID;
+        const unsigned char* src = wbase + (int64_t)pf_li * LAYERB + (int64_t)(16 * pf_T) * HID;     // (uniform)
         const unsigned dst = ring_addr + pf_slot * TILE_B;
 #pragma unroll
-        for (int u = 0; u < KC * NS / 4; ++u) {
-            const int i = wave_u + 4 * u, kc = i / NS, wi = i - kc * NS;
-            wglds16(src + (int64_t)wi * PLANE + 64 * kc, dst + i * 1024);
-        }
+        for (int u = 0; u < KC * NS / 4; ++u) wglds16s(dma_off[u], src, dst + (wave_u + 4 * u) * 1024);
         if (++pf_T == TL) {
             pf_T = 0;
             if (++pf_li == NHH) pf_li = 0;
@@ -214,6 +222,11 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
     const bool w_bad = block_or(bad, red + 6);
 
     const int lofs = c * 64 + 16 * (q ^ slot_swz(c));          // this lane's 16 bytes inside one [16 rows][64 B] block
+    // rounding constants as opaque register pairs, small constants through scalar registers (qn_fused_i8.hip: a known 64-bit
+    // constant is re-materialised by a v_mov in front of every v_fmac_f64 that adds it; 32-bit literals make an instruction
+    // 8 bytes and ~2 issue cycles dearer)
+    double magic52 = 6755399441055744.0, magicS = kMagic;
+    asm volatile("" : "+v"(magic52), "+v"(magicS));
     double sse = 0.0;
     double xn[DP], yn;
     int nrow_n, xbad_n;
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
         // + 2..3 x 4); scheduling fences keep the compiler from regrouping.  K > 64: levels are recombined one by one
         // in float64 (pair sums would not fit int32).
         auto epilogue = [&](auto last_tag, auto next_tag, const v4i (&acc)[NLEV], v4i (&accn)[NLEV], const unsigned char* tile_next,
-                            const double* sbt, const double* wlt, double* stp, int (&S)[NS]) {
+                            const double* sbt, const double* wlt, double* (&sp)[4], int64_t sstride, int (&S)[NS]) {
             constexpr bool LAST = decltype(last_tag)::value, NEXT = decltype(next_tag)::value;
             constexpr int NST = 11 + NLEV;                        // per-element stages (NLEV recombination stages first)
             constexpr int NMICRO = NST * 4 + 4;                   // + 4 steps: digit transposition, or the last layer's dot
@@ -346,15 +359,15 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
                         sc[r] = *reinterpret_cast<const double2*>(sbt + 2 * r);
                         ts[r] = (double)acc[NLEV - 1][r];
                     } else if constexpr (st < NLEV) {
-                        ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 1 - st][r]);
+                        { const double cv_ = (double)acc[NLEV - 1 - st][r]; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(ts[r]) : "v"(ts[r]), "s"(256.0), "v"(cv_)); }
                     } else if constexpr (st == NLEV) {
                         z[r] = fma(ts[r], sc[r].x, sc[r].y);
                         asm("v_min_f64 %0, |%1|, %2" : "=v"(ax[r]) : "v"(z[r]), "s"(20.0));
                     } else if constexpr (st == NLEV + 1) {
-                        zm[r] = fma(ax[r], 64.0, 6755399441055744.0);
+                        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(zm[r]) : "v"(ax[r]), "s"(64.0), "v"(magic52));
                         Tt[r] = tanh_tab[__double2loint(zm[r])];
                     } else if constexpr (st == NLEV + 2) {
-                        bb[r] = fma(zm[r] - 6755399441055744.0, -0.015625, ax[r]);
+                        { const double nf_ = zm[r] - magic52; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(bb[r]) : "v"(nf_), "s"(-0.015625), "v"(ax[r])); }
                     } else if constexpr (st == NLEV + 3) {
                         b2[r] = bb[r] * bb[r];
                         pp[r] = fma(b2[r], 1.33333333333333333e-01, -3.33333333333333333e-01);
@@ -375,10 +388,11 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
                         num[r] = fma(den[r], y0[r], Tt[r]);
                     } else if constexpr (st == NLEV + 9) {
                         av[r] = __builtin_copysign(num[r], z[r]);
-                        if constexpr (STASH) stp[(int64_t)r * a.Nb] = av[r];
+                        if constexpr (STASH) { *sp[r] = av[r]; sp[r] += sstride; }     // (running pointers: one 64-bit add per element)
                     } else {
                         if constexpr (!LAST) {
-                            const double x = fma(av[r], 0x1p46, kMagic);
+                            double x;
+                            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(x) : "v"(av[r]), "s"(0x1p46), "v"(magicS));
                             lo[r] = __double2loint(x);
                             hi[r] = __double2hiint(x);
                         }
@@ -413,6 +427,13 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
             const double* sb = lds + offsb + li * 2 * HID + 2 * 4 * q;       // this lane group's features 16 T + 4 q + r
             const double* wl = lds + offWl + 4 * q;
             double* stl = STASH ? act0 + (int64_t)(li + 1) * a.act_stride + srow : nullptr;
+            // the stash pointers of a tile's four elements advance by 16 features per tile (rows beyond Nb: the dump area, no
+            // advance): recomputed from the layer's base for every store they cost four 64-bit vector adds per element
+            double* sp[4];
+            int64_t sstride = live ? (int64_t)16 * a.Nb : 0;
+            asm volatile("" : "+v"(sstride));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sp[r] = STASH ? (live ? stl : dmp) + (int64_t)r * a.Nb : nullptr;
             v4i Bout[KC][NS];
             v4i Bcur[NS];
             v4i accA[NLEV], accB[NLEV];
@@ -424,14 +445,13 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
                 int S[NS];
                 rd_slot = rd_slot + 1 == WNBUF ? 0 : rd_slot + 1;            // (now the slot of tile Tt_ + 1)
                 const unsigned char* nxt = ring + rd_slot * TILE_B + lofs;
-                double* stp = STASH ? (live ? stl + (int64_t)(16 * Tt_) * a.Nb : dmp) : nullptr;
                 if constexpr (Tt_ + 1 < TL) {
                     QN_ST(st_sync, sync_tile())
-                    if constexpr (Tt_ & 1) QN_ST(st_epi, epilogue(last_tag, std::true_type{}, accB, accA, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S))
-                    else QN_ST(st_epi, epilogue(last_tag, std::true_type{}, accA, accB, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S))
+                    if constexpr (Tt_ & 1) QN_ST(st_epi, epilogue(last_tag, std::true_type{}, accB, accA, nxt, sb + 32 * Tt_, wl + 16 * Tt_, sp, sstride, S))
+                    else QN_ST(st_epi, epilogue(last_tag, std::true_type{}, accA, accB, nxt, sb + 32 * Tt_, wl + 16 * Tt_, sp, sstride, S))
                 } else {
-                    if constexpr (Tt_ & 1) QN_ST(st_epi, epilogue(last_tag, std::false_type{}, accB, accA, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S))
-                    else QN_ST(st_epi, epilogue(last_tag, std::false_type{}, accA, accB, nxt, sb + 32 * Tt_, wl + 16 * Tt_, stp, S))
+                    if constexpr (Tt_ & 1) QN_ST(st_epi, epilogue(last_tag, std::false_type{}, accB, accA, nxt, sb + 32 * Tt_, wl + 16 * Tt_, sp, sstride, S))
+                    else QN_ST(st_epi, epilogue(last_tag, std::false_type{}, accA, accB, nxt, sb + 32 * Tt_, wl + 16 * Tt_, sp, sstride, S))
                 }
                 if constexpr (!LAST) {
 #pragma unroll
@@ -671,18 +691,21 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c = lane & 15;
 
     // ---- weight-tile stream: layers from the top down (li = NHH-1 .. 0), tiles T = 16 input features of layer li
-    const unsigned char* wdc = WdT + (int64_t)b * NHH * LAYERB + (int64_t)(lane >> 2) * HID + 16 * (lane & 3);
+    const unsigned char* wbase = WdT + (int64_t)b * NHH * LAYERB;       // (uniform)
     const unsigned ring_addr = lds_addr_of(ring);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned dma_off[KC * NS / 4];                                      // this lane's byte offsets inside a tile, per DMA instruction
+#pragma unroll
+    for (int u = 0; u < KC * NS / 4; ++u) {
+        const int i = wave_u + 4 * u, kc = i / NS, wi = i - kc * NS;
+        dma_off[u] = (unsigned)((lane >> 2) * HID + 16 * (lane & 3) + wi * PLANE + 64 * kc);
+    }
     int pf_li = NHH - 1, pf_T = 0, pf_slot = 0;
     auto dma_next = [&]() {
-        const unsigned char* src = wdc + (int64_t)pf_li * LAYERB + (int64_t)(16 * pf_T) * HID;
+        const unsigned char* src = wbase + (int64_t)pf_li * LAYERB + (int64_t)(16 * pf_T) * HID;     // (uniform)
         const unsigned dst = ring_addr + pf_slot * TILE_B;
 #pragma unroll
-        for (int u = 0; u < KC * NS / 4; ++u) {
-            const int i = wave_u + 4 * u, kc = i / NS, wi = i - kc * NS;
-            wglds16(src + (int64_t)wi * PLANE + 64 * kc, dst + i * 1024);
-        }
+        for (int u = 0; u < KC * NS / 4; ++u) wglds16s(dma_off[u], src, dst + (wave_u + 4 * u) * 1024);
         if (++pf_T == TL) {
             pf_T = 0;
             if (--pf_li < 0) pf_li = NHH - 1;
