@@ -870,6 +870,18 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
                 ab[0][r] = apl[(int64_t)r * a.Nb];
                 ab[1][r] = apl[(int64_t)(16 + r) * a.Nb];
             }
+            // running pointers of a tile's four elements (activation loads two tiles ahead, dZ stores): 16 features per
+            // tile; recomputed from the layer's base for every access they cost four to five 64-bit vector adds per element.
+            // Rows beyond Nb store to the dump area and do not advance.
+            const double* lp[4];
+            double* sp[4];
+            int64_t lstride = (int64_t)16 * a.Nb, sstride = live ? (int64_t)16 * a.Nb : 0;
+            asm volatile("" : "+v"(lstride), "+v"(sstride));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lp[r] = apl + (int64_t)((TL > 2 ? 32 : 16 * (TL - 1)) + r) * a.Nb;
+                sp[r] = (live ? zpl : dmp) + (int64_t)r * a.Nb;
+            }
             v4i accA[NLEV], accB[NLEV];
             int topl = 0;
             QN_ST(st_sync, sync_tile())
@@ -881,13 +893,14 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
                 constexpr int NST = NLEV + 3, NMICRO = NST * 4, LEAD = 2;
                 v4i Af[2][NS];
                 double ts[4], g[4], v[4];
-                double* stp = live ? zpl + (int64_t)(16 * Tt_) * a.Nb : dmp;
                 const double (&ac)[4] = ab[Tt_ % 3];
                 // (always 4 loads per epilogue: sync_tile counts on them; past the last tile they re-read the last one)
                 {
-                    constexpr int Tn = Tt_ + 2 < TL ? Tt_ + 2 : TL - 1;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ab[(Tt_ + 2) % 3][r] = apl[(int64_t)(16 * Tn + r) * a.Nb];
+                    for (int r = 0; r < 4; ++r) {
+                        ab[(Tt_ + 2) % 3][r] = *lp[r];
+                        if constexpr (Tt_ + 3 < TL) lp[r] += lstride;
+                    }
                 }
                 auto micro = [&](auto id_tag) {
                     constexpr int id = decltype(id_tag)::value;
@@ -905,13 +918,14 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
                     if constexpr (st == 0) {
                         ts[r] = (double)acc[NLEV - 1][r];
                     } else if constexpr (st < NLEV) {
-                        ts[r] = fma(ts[r], 256.0, (double)acc[NLEV - 1 - st][r]);
+                        { const double cv_ = (double)acc[NLEV - 1 - st][r]; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(ts[r]) : "v"(ts[r]), "s"(256.0), "v"(cv_)); }
                     } else if constexpr (st == NLEV) {
                         g[r] = fma(-ac[r], ac[r], 1.0) * rs;
                     } else if constexpr (st == NLEV + 1) {
                         v[r] = (ts[r] * sct[16 * Tt_ + r]) * g[r];
                     } else {
-                        stp[(int64_t)r * a.Nb] = v[r];
+                        *sp[r] = v[r];
+                        sp[r] += sstride;
                         amax = fmax(amax, fabs(v[r]));
                         V[Tt_][r] = to_acc_d(v[r]);
                     }
