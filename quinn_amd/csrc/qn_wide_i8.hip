@@ -58,11 +58,9 @@ __host__ __device__ constexpr size_t wide_lds_bytes(int kc, int dp, int nhid) {
 // (sync_tile).  `lds_addr`: byte address in LDS of the wave's 1 KB destination (wave-uniform).
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"         // (m0 on the clobber list: that is the point)
-__device__ __forceinline__ void wglds16(const unsigned char* src, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory", "m0");
-}
-// the same with the address as a uniform base (scalar register pair) + a 32-bit per-lane offset: no 64-bit vector arithmetic
-// per instruction (it was a dozen v_lshl_add_u64 per weight tile and wave)
+// 16 bytes per lane from global memory straight into LDS (m0 = LDS address of the wave's 1 KB piece): the address is a uniform
+// base (scalar register pair) + a 32-bit per-lane offset -- with a full 64-bit vector address per instruction the tile stream
+// cost a dozen v_lshl_add_u64 per weight tile and wave
 __device__ __forceinline__ void wglds16s(unsigned voff, const unsigned char* sbase, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
