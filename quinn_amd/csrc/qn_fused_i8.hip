@@ -560,8 +560,9 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
 // ---- what qn_fused.hip needs to dispatch to this kernel
 int qn_fused_i8_rows_per_iteration() { return (WGT / 64) * 16 * G; }
 bool qn_fused_i8_applies(int Hh, int nhid, int act, int d, int o) {
-    // (several outputs: the staged epilogue with a 4-output dot spills ~170 registers; those networks keep the f64 kernel)
-    if (Hh != H || act != QN_ACT_TANH || nhid < 2 || d > 4 || o != 1) return false;
+    // (1..4 outputs: the 4-output instance took ~170 spilled registers in round 2; with the shorter tanh tail and the
+    // constants out of the way it fits -- 216 registers, no scratch)
+    if (Hh != H || act != QN_ACT_TANH || nhid < 2 || d > 4 || o < 1 || o > OMAX) return false;
     return qn_fused_i8_lds_bytes(d, nhid) <= 160 * 1024;
 }
 size_t qn_fused_i8_lds_bytes(int d, int nhid) {
@@ -572,7 +573,7 @@ qn_fwd_fn qn_fused_i8_kernel(int d, int o) {
 #ifndef QN_I8_LMIN
 #define QN_I8_LMIN 4
 #endif
-    (void)o;
+    if (o > 1) return d <= 2 ? k_fused_fwd_i8<2, QN_I8_LMIN, OMAX> : k_fused_fwd_i8<4, QN_I8_LMIN, OMAX>;
     return d <= 2 ? k_fused_fwd_i8<2, QN_I8_LMIN, 1> : k_fused_fwd_i8<4, QN_I8_LMIN, 1>;
 }
 

@@ -60,9 +60,10 @@ def test_matches_oracle_and_float64_kernels(dims, N, B, wscale):
     print(f"max |pred - layerwise| / max|pred|: int8 slices {err8:.2e}, f64 MFMA {errd:.2e}")
 
 
-def test_row_subsets_and_ragged_tail():
-    dims = (2, 64, 64, 64, 1)
-    x, y = _data(777, 2, 1, seed=3)
+@pytest.mark.parametrize("o", [1, 2])
+def test_row_subsets_and_ragged_tail(o):
+    dims = (2, 64, 64, 64, o)
+    x, y = _data(777, 2, o, seed=3)
     arch = MLPArch(dims, "tanh")
     rs = np.random.RandomState(5)
     W = 0.2 * rs.randn(6, arch.nparams)
@@ -77,10 +78,11 @@ def test_row_subsets_and_ragged_tail():
 
 
 @pytest.mark.parametrize("where", ["weight_nan", "weight_inf", "weight_huge", "bias_nan", "x_nan", "x_inf", "y_nan", "w0_inf"])
-def test_exceptional_values_follow_the_layerwise_kernels(where):
-    dims = (1, 64, 64, 64, 1)
+@pytest.mark.parametrize("o", [1, 3])                                   # (o > 1: the 4-output instance of the int8-slice kernel)
+def test_exceptional_values_follow_the_layerwise_kernels(where, o):
+    dims = (1, 64, 64, 64, o)
     arch = MLPArch(dims, "tanh")
-    x, y = _data(200, 1, 1, seed=1)
+    x, y = _data(200, 1, o, seed=1)
     rs = np.random.RandomState(2)
     W = 0.2 * rs.randn(3, arch.nparams)
     off_w1 = 64 + 64 + 5 * 64 + 7                                        # an entry of the first hidden matrix
