@@ -141,13 +141,15 @@ __device__ __forceinline__ double recombine(const v4i (&acc)[NLEV], int r) {
 // so that a wave that is alone on its SIMD always has four independent instructions between a result and its use (written
 // element by element the compiler keeps each element's dependent chain together and the wave waits out every latency).
 template <int NLEV>
-__device__ __forceinline__ void recombine4(const v4i (&acc)[NLEV], double (&ts)[4]) {
+__device__ __forceinline__ void recombine4(const v4i (&acc)[NLEV], double (&ts)[4], double c65536) {
+    // c65536: 65536.0 in a register pair the compiler cannot see through (as a literal it makes each of these fma's an
+    // 8-byte v_fmac_f64; an inline-asm fma would drop out of the scheduling requests' count of vector instructions)
 #pragma unroll
     for (int r = 0; r < 4; ++r) ts[r] = (NLEV & 1) ? (double)acc[NLEV - 1][r] : (double)(acc[NLEV - 2][r] + (acc[NLEV - 1][r] << 8));
 #pragma unroll
     for (int l = ((NLEV & 1) ? NLEV - 3 : NLEV - 4); l >= 0; l -= 2)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ts[r] = fma(ts[r], 65536.0, (double)(acc[l][r] + (acc[l + 1][r] << 8)));
+        for (int r = 0; r < 4; ++r) ts[r] = fma(ts[r], c65536, (double)(acc[l][r] + (acc[l + 1][r] << 8)));
 }
 // qn_tanh_f64_tab64 (qn_math.h) for N arguments at once, stage-major; same operations, same results
 template <int N>
@@ -351,8 +353,8 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
     const int selA = (c & 1) ? 0x03070105 : 0x06020400, selB = (c & 2) ? 0x03020706 : 0x05040100;
     int bad_run = 0;
     double sse = 0.0;
-    double magic52 = 6755399441055744.0, magicS = kMagic, cm13 = -3.33333333333333333e-01;      // constants as opaque register pairs
-    asm volatile("" : "+v"(magic52), "+v"(magicS), "+v"(cm13));
+    double magic52 = 6755399441055744.0, magicS = kMagic, cm13 = -3.33333333333333333e-01, c65536 = 65536.0;      // constants as opaque register pairs
+    asm volatile("" : "+v"(magic52), "+v"(magicS), "+v"(cm13), "+v"(c65536));
 
     double dWacc[NM][4][4];                                             // rows 16 wave + 4 q + r, columns 16 ti + c
 #pragma unroll
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
                     double ts[4], z[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sc[r] = *reinterpret_cast<const double2*>(sb + 32 * t + 2 * r);
-                    recombine4<NLEV>(accs[t & 1], ts);
+                    recombine4<NLEV>(accs[t & 1], ts, c65536);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) z[r] = fma(ts[r], sc[r].x, sc[r].y);
                     tanh_tab64_n<4>(z, act[l][t], tanh_tab, magic52, cm13);
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
             };
             auto dw_epilogue = [&](const v4i (&acc)[NLEV], int ti) {
                 double ts[4];
-                recombine4<NLEV>(acc, ts);
+                recombine4<NLEV>(acc, ts, c65536);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     dWacc[l - 1][ti][r] = fma(ts[r], sdw, dWacc[l - 1][ti][r]);
@@ -571,7 +573,7 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
                 double ts[4], g[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g[r] = sT[16 * t + r] * rs;
-                recombine4<NLEV>(acc, ts);
+                recombine4<NLEV>(acc, ts, c65536);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g[r] *= fma(-act[l - 1][t][r], act[l - 1][t][r], 1.0);
 #pragma unroll
