@@ -203,6 +203,8 @@ __global__ __launch_bounds__(BLK) void k_hist_coef_sum(HistBlockArgs a, const fl
     const int K = ksnap[b] < a.kcap ? ksnap[b] : a.kcap;
     const float* cb = coef + (int64_t)b * a.kstride * TB;
     float sacc = 0.f;
+    // (eight loads in flight, the additions in the same order: one 64-workgroup launch whose time is load latency x K / 4)
+#pragma unroll 8
     for (int k = g; k < K; k += BLK / TB) sacc += cb[(int64_t)k * TB + t];
     part[g][t] = sacc;
     __syncthreads();
