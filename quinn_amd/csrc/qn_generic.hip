@@ -542,8 +542,14 @@ inline bool gemm_layer(const qn_desc* d, int l) {
     return l >= 1 && l + 1 < d->nlayers && d->dims[l] % 64 == 0 && d->dims[l + 1] % 64 == 0;
 }
 // split-K factor of the dW GEMM: enough workgroups for ~4 resident per CU (LDS-limited) over several rounds
-inline int dw_ksplit(int B, int tiles, int Nb) {
-    int ks = (4096 + B * tiles - 1) / (B * tiles);
+#ifndef QN_DW_I8_TARGET_WGS
+#define QN_DW_I8_TARGET_WGS 1024
+#endif
+// target: 4096 workgroups for the float64 GEMM (4 resident per CU); the int8-slice kernel holds a CU alone (129 KB of LDS)
+// and pays ~8 us of set-up per workgroup (the first group's exponents, three loads in sequence), so it gets long slabs:
+// 1024 workgroups = 4 whole rounds on 256 CUs (A/B in one call against 4096 / 2048: cfg3 gradient 47.5 / 48.6 / 49.2 TFLOP/s)
+inline int dw_ksplit(int B, int tiles, int Nb, int target = 4096) {
+    int ks = (target + B * tiles - 1) / (B * tiles);
     const int kmax = (Nb + 255) / 256;
     if (ks > kmax) ks = kmax;
     if (ks > 16) ks = 16;
@@ -588,7 +594,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         for (int l = 1; l + 1 < L; ++l)
             if (gemm_layer(d, l)) {
                 const int tiles = (d->dims[l] / 64) * (d->dims[l + 1] / 64);
-                const int ks = dw_ksplit(B, tiles, Nb);
+                const int ks = dw_ksplit(B, tiles, Nb);          // (the larger of the two targets: an upper bound for the int8 path)
                 if (ks > 1) need = std::max(need, (size_t)B * ks * ((size_t)d->dims[l] * d->dims[l + 1] + d->dims[l + 1]));
             }
         if (need) dwslab = c.take<T>(need);
@@ -685,7 +691,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
             if (gemm_layer(d, l)) {
                 GemmArgs g = gargs(l);
                 const int tiles = (g.h_in / 64) * (g.h_out / 64);
-                const int ks = dw_ksplit(B, tiles, Nb);
+                const int ks = dw_ksplit(B, tiles, Nb, wide_bwd ? QN_DW_I8_TARGET_WGS : 4096);
                 // weights and (if any) the bias block behind them: contiguous in the flat layout and in a slab
                 const int64_t nW = (int64_t)g.h_in * g.h_out + (d->has_bias ? g.h_out : 0);
                 g.ksplit = ks;
