@@ -138,6 +138,19 @@ class DeviceAMCMC:
         s['par'] ^= 1              # the kernel read slot `par` of the per-chain scalars / step counter and wrote the other
 
     def run(self, nmcmc, param_ini, store_chain=True, verbose=False):
+        """(The cyclic garbage collector is paused while the steps are enqueued: the enqueuing thread makes ~25 000 launches a
+        second and nothing it allocates per step is cyclic, but a full collection in the middle of a run is a 30 ms hole in
+        the GPU's queue -- one 1000-step window at 6.3 k steps/s among windows at 7.7 k.  Restored on the way out.)"""
+        import gc
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            return self._run(nmcmc, param_ini, store_chain, verbose)
+        finally:
+            if was:
+                gc.enable()
+
+    def _run(self, nmcmc, param_ini, store_chain=True, verbose=False):
         ini = torch.as_tensor(np.asarray(param_ini), dtype=torch.float64, device=self.dev).reshape(-1, self.op.p)
         C, p = ini.shape
         G = min(self.groups, C)
@@ -210,7 +223,7 @@ class DeviceAMCMC:
         different overall mean comes out by itself).  The current state keeps a row of its own behind them.  The chains of
         a group (<= 16: bounds the padded copy) go through ONE set of batched GEMMs / factorisations, no per-chain host work.
         spread: besides the chains that MUST be compressed now, the fullest of those that would come due within the next
-        windows are taken as well, up to C / 8 chains per call, so that the chains of a long run do not all come due in the
+        windows are taken as well, up to C / 6 chains per call, so that the chains of a long run do not all come due in the
         same window."""
         kcap = s['hist'].shape[1]
         r = max(8, kcap // 8)
@@ -221,10 +234,15 @@ class DeviceAMCMC:
         sel = list(must)
         if spread:
             # chains that would come due within the next windows (one more window even if every step were accepted) are taken early while the call has room in
-            # its budget of C / 8 chains: evens out the windows in which many chains fill up together
+            # its budget of C / 6 chains: evens out the windows in which many chains fill up together
+            # The chains of a run fill up in step (similar acceptance rates), so without help their FIRST compressions all come
+            # due in the same window (45 ms for 64 chains: that window ran at 5.7 k steps/s against 7.5-8 k around it).  The
+            # early-eligibility threshold is therefore staggered by chain (global id mod 8, a quarter window apart): the first
+            # cycle is spread over the windows before, and the later cycles inherit the spread.
             high = kcap - 2 * room
-            budget = max(len(sel), -(-len(kc_h) // 8))
-            extra = [c for c in np.argsort(-kc_h) if ok[c] and kc_h[c] > high and c not in set(sel)]
+            stag = ((self.chain0 + np.arange(len(kc_h))) % 8) * (room // 4)
+            budget = max(len(sel), -(-len(kc_h) // 6))                          # (a chain comes due every ~6 windows at acceptance 0.3)
+            extra = [c for c in np.argsort(-(kc_h + stag)) if ok[c] and kc_h[c] + stag[c] > high and c not in set(sel)]
             sel += extra[:max(0, budget - len(sel))]
         dev = s['hist'].device
         for g0 in range(0, len(sel), 16):
@@ -308,7 +326,7 @@ class DeviceAMCMC:
             gen = torch.Generator(device=dev)
             gen.manual_seed(1)
             pstride = (p + 3) // 4 * 4
-            for n in sorted({1, min(16, max(1, -(-C // 8)))}):
+            for n in sorted({1, min(16, max(1, -(-C // 6)))}):
                 fake = {'hist': torch.randn(n, kcap, pstride, dtype=torch.float32, device=dev, generator=gen),
                         'mult': torch.ones(n, kcap, dtype=torch.int32, device=dev), 'par': 0}
                 for q4 in range(1, 5):                                          # every row-count bucket a compression can meet
@@ -410,13 +428,15 @@ class DeviceAMCMC:
             if overlap and more:
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=dev)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(dev))                     # (the other buffer's last readers are enqueued before this)
-                self._side.wait_event(ev)
+                    # (two events for the whole run, re-recorded: a fresh pair per block was ~1600 Python objects per 50 000
+                    # steps, and a collector pause of the enqueuing thread shows up as a 30 ms hole in one window)
+                    self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+                self._ev_fork.record(torch.cuda.current_stream(dev))         # (the other buffer's last readers are enqueued before this)
+                self._side.wait_event(self._ev_fork)
                 with torch.cuda.stream(self._side):
                     self._propose_hist_block(s, snap, coef, delta[1 - buf], step_abs + TB)
-                    state['ahead'] = torch.cuda.Event()
-                    state['ahead'].record(self._side)
+                    self._ev_join.record(self._side)
+                    state['ahead'] = self._ev_join
                 state['dbuf'] = 1 - buf
             have = False
             for t in range(nsteps):
