@@ -1323,7 +1323,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
             int* flags = reinterpret_cast<int*>(static_cast<char*>(ws) + npart + nslab);
             qn_bwd_i8_fn k8 = qn_fused_bwd_i8_kernel(nhid, a.d);
             if (int rc = arm_lds(reinterpret_cast<const void*>(k8))) return rc;
-            hipLaunchKernelGGL(k8, grid, dim3(WG), qn_fused_bwd_i8_lds_bytes(nhid), st, a, (const double*)W, (const double*)X,
+            hipLaunchKernelGGL(k8, grid, dim3(WG), qn_fused_bwd_i8_lds_bytes(nhid, a.d), st, a, (const double*)W, (const double*)X,
                                (const double*)Y, row_idx, (double*)pred, partial, slab, flags);
             flagged = flags;
         }

@@ -60,8 +60,13 @@ constexpr int BWG = 256;
 
 // LDS, doubles first: W0 [64][DP] | b0 [64] | Wl [64] | bl, pad | red [8] | wave exponents [4] | {scale, bias} (NH-1) x [64][2]
 // | column scales (NH-1) x [64] | tanh table; then bytes: (NH-1) planes of W | (NH-1) planes of W^T | stash dZ | stash A
+// (3 or 4 inputs: W0 takes 128 doubles more and the image at three hidden layers would be 128 BYTES over the 160 KB of a CU; the
+// tanh table then ends at n = 1264 (|x| clamped to 19.75 instead of 20): tanh is 1.0 to the last bit from 19.07 on, so the
+// results are the same)
+constexpr int TANH_TAB_SHORT_N = 1265;
+__host__ __device__ constexpr int bwd_tab_doubles(int dp) { return dp <= 2 ? ((TANH_TAB + 1) & ~1) : ((TANH_TAB_SHORT_N + 1) & ~1); }
 __host__ __device__ constexpr int bwd_head_doubles(int dp, int nhid) {
-    return ((H * dp + H + H + 2 + 8 + 4 + (nhid - 1) * 3 * H + 1) & ~1) + ((TANH_TAB + 1) & ~1);
+    return ((H * dp + H + H + 2 + 8 + 4 + (nhid - 1) * 3 * H + 1) & ~1) + bwd_tab_doubles(dp);
 }
 __host__ __device__ constexpr size_t bwd_lds_bytes(int dp, int nhid) {
     return sizeof(double) * (size_t)bwd_head_doubles(dp, nhid) + (size_t)(2 * (nhid - 1) + 2) * LAYER_BYTES;
@@ -152,11 +157,11 @@ __device__ __forceinline__ void recombine4(const v4i (&acc)[NLEV], double (&ts)[
         for (int r = 0; r < 4; ++r) ts[r] = fma(ts[r], c65536, (double)(acc[l][r] + (acc[l + 1][r] << 8)));
 }
 // qn_tanh_f64_tab64 (qn_math.h) for N arguments at once, stage-major; same operations, same results
-template <int N>
+template <int N, bool SHORT_TAB = false>
 __device__ __forceinline__ void tanh_tab64_n(const double (&z)[N], double (&out)[N], const double* __restrict__ tab, double magic52, double cm13) {
     double ax[N], zm[N], Tt[N], bb[N], b2[N], pp[N], b3[N], tb[N], num[N], den[N], y0[N], e0[N];
 #pragma unroll
-    for (int r = 0; r < N; ++r) asm("v_min_f64 %0, |%1|, %2" : "=v"(ax[r]) : "v"(z[r]), "s"(20.0));
+    for (int r = 0; r < N; ++r) asm("v_min_f64 %0, |%1|, %2" : "=v"(ax[r]) : "v"(z[r]), "s"(SHORT_TAB ? 19.75 : 20.0));
 #pragma unroll
     for (int r = 0; r < N; ++r) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(zm[r]) : "v"(ax[r]), "s"(64.0), "v"(magic52));      // magic52 = 1.5 * 2^52 (see slice4_scaled)
 #pragma unroll
@@ -295,14 +300,15 @@ __device__ __forceinline__ int stage_bwd(double* __restrict__ lds, unsigned char
     return bad;
 }
 
-// DD = number of inputs (1 or 2; the LDS image of W0 is 2 columns wide either way)
+// DD = number of inputs (1..4; the LDS image of W0 is 2 columns wide for DD <= 2, 4 otherwise)
 template <int NH, int DD, int LMIN>
 __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const double* __restrict__ W, const double* __restrict__ X,
                                                         const double* __restrict__ Y, const int32_t* __restrict__ row_idx,
                                                         double* __restrict__ pred_out, double* __restrict__ partial,
                                                         double* __restrict__ slab, int* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN), NM = NH - 1, DP = 2;
+    constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN), NM = NH - 1, DP = DD <= 2 ? 2 : 4;
+    constexpr bool SHORT_TAB = DP > 2;
     double* lds = reinterpret_cast<double*>(smem);
     int b, split;
     if (!qn_fused_wg(a.nsplit, a.B, &b, &split)) return;
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
         yn = Y[rr];
     };
     fetch(0);
-    qn_tanh_table64_stage(tanh_tab, tid, BWG);
+    for (int e = tid; e < (SHORT_TAB ? TANH_TAB_SHORT_N : QN_TANH_TAB64_N); e += BWG) tanh_tab[e] = qn_tanh_table64_g[e];
     const bool w_bad = block_or(stage_bwd<NH, DP, LMIN>(lds, wq, wqT, Wb, a), red + 6);
     if (w_bad) {                                                        // the float64 kernel recomputes the whole chain
         if (tid == 0) {
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
                 for (int k = 0; k < DD; ++k)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) z[r] = fma(lds[(16 * t + 4 * q + r) * DP + k], xk[k], z[r]);
-                tanh_tab64_n<4>(z, act[0][t], tanh_tab, magic52, cm13);
+                tanh_tab64_n<4, SHORT_TAB>(z, act[0][t], tanh_tab, magic52, cm13);
                 int S[NS];
                 slice4_scaled(act[0][t], 0x1p46, magicS, S);
 #pragma unroll
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
                     recombine4<NLEV>(accs[t & 1], ts, c65536);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) z[r] = fma(ts[r], sc[r].x, sc[r].y);
-                    tanh_tab64_n<4>(z, act[l][t], tanh_tab, magic52, cm13);
+                    tanh_tab64_n<4, SHORT_TAB>(z, act[l][t], tanh_tab, magic52, cm13);
                     if (l == NM) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) pd = fma(lds[offWl + 16 * t + 4 * q + r], act[l][t][r], pd);
@@ -709,10 +715,13 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
 
 // ---- what qn_fused.hip needs to dispatch to this kernel
 bool qn_fused_bwd_i8_applies(int Hh, int nhid, int act, int d, int o) {
-    return Hh == H && act == QN_ACT_TANH && (nhid == 2 || nhid == 3) && d >= 1 && d <= 2 && o == 1;
+    return Hh == H && act == QN_ACT_TANH && (nhid == 2 || nhid == 3) && d >= 1 && d <= 4 && o == 1;
 }
-size_t qn_fused_bwd_i8_lds_bytes(int nhid) { return bwd_lds_bytes(2, nhid); }
+size_t qn_fused_bwd_i8_lds_bytes(int nhid, int d) { return bwd_lds_bytes(d <= 2 ? 2 : 4, nhid); }
 qn_bwd_i8_fn qn_fused_bwd_i8_kernel(int nhid, int d) {
     if (d == 1) return nhid == 2 ? k_fused_bwd_i8<2, 1, QN_I8_LMIN> : k_fused_bwd_i8<3, 1, QN_I8_LMIN>;
-    return nhid == 2 ? k_fused_bwd_i8<2, 2, QN_I8_LMIN> : k_fused_bwd_i8<3, 2, QN_I8_LMIN>;
+    if (d == 2) return nhid == 2 ? k_fused_bwd_i8<2, 2, QN_I8_LMIN> : k_fused_bwd_i8<3, 2, QN_I8_LMIN>;
+    if (d == 3) return nhid == 2 ? k_fused_bwd_i8<2, 3, QN_I8_LMIN> : k_fused_bwd_i8<3, 3, QN_I8_LMIN>;
+    return nhid == 2 ? k_fused_bwd_i8<2, 4, QN_I8_LMIN> : k_fused_bwd_i8<3, 4, QN_I8_LMIN>;
 }
+static_assert(bwd_lds_bytes(4, 3) <= 160 * 1024 && bwd_lds_bytes(2, 3) <= 160 * 1024, "the LDS image of the three-hidden-layer kernel has to fit a CU");

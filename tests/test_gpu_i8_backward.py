@@ -45,8 +45,12 @@ def _three(op, W, row_idx=None):
 
 @pytest.mark.parametrize("dims,N,B,wscale", [((1, 64, 64, 64, 1), 4096, 64, 0.1), ((1, 64, 64, 1), 300, 5, 1.0), ((2, 64, 64, 64, 1), 1000, 7, 2.0),
                                              ((1, 64, 64, 64, 1), 64, 1, 0.3), ((2, 64, 64, 1), 333, 5, 0.5), ((1, 50, 50, 50, 1), 500, 4, 0.5),
-                                             ((1, 64, 64, 64, 1), 77, 300, 0.3)],
-                         ids=["cfg2", "2hid", "d2_bigw", "one_chain", "d2_2hid", "padded50", "many_chains"])
+                                             ((1, 64, 64, 64, 1), 77, 300, 0.3),
+                                             # 3 and 4 inputs: the 4-column image of W0 and the tanh table that ends at n = 1264
+                                             ((3, 64, 64, 64, 1), 1000, 6, 0.4), ((4, 64, 64, 64, 1), 333, 5, 2.5), ((4, 64, 64, 1), 130, 9, 0.5),
+                                             ((3, 40, 40, 40, 1), 257, 3, 0.7)],
+                         ids=["cfg2", "2hid", "d2_bigw", "one_chain", "d2_2hid", "padded50", "many_chains", "d3", "d4_bigw", "d4_2hid",
+                              "d3_padded40"])
 def test_gradient_matches_oracle_and_float64_kernels(dims, N, B, wscale):
     x, y = _data(N, dims[0])
     arch = MLPArch(dims, "tanh")
@@ -84,22 +88,23 @@ def test_row_subsets_ragged_tail_and_determinism():
 
 
 @pytest.mark.parametrize("where", ["weight_nan", "weight_inf", "weight_huge", "weight_2e25", "bias_nan", "x_nan", "x_inf", "y_nan", "y_huge", "w0_inf", "tiny_weights"])
-def test_chains_outside_the_contract_are_recomputed_in_float64(where):
+@pytest.mark.parametrize("d", [1, 3])                                   # (3 inputs: the 4-column W0 image, the shorter tanh table)
+def test_chains_outside_the_contract_are_recomputed_in_float64(where, d):
     """One chain (or the data) breaks the fast path's contract: the flagged chains come from k_fused_bwd_f64 -- NaN / Inf
     pattern and finite values of the layer-wise kernels -- and the OTHER chains' results do not change by a bit."""
-    dims = (1, 64, 64, 64, 1)
+    dims = (d, 64, 64, 64, 1)
     arch = MLPArch(dims, "tanh")
-    x, y = _data(200, 1, seed=1)
+    x, y = _data(200, d, seed=1)
     W = _weights(arch, 3, 0.3, 2)
     clean = BatchedMLP(arch, x, y)
     s0, g0 = (t.cpu().numpy() for t in clean.sse_grad(W))
-    off_w1 = 64 + 64 + 5 * 64 + 7                                        # an entry of the first hidden matrix
+    off_w1 = 64 * d + 64 + 5 * 64 + 7                                    # an entry of the first hidden matrix
     data_case = where in ("x_nan", "x_inf", "y_nan", "y_huge")
     if where == "weight_nan": W[1, off_w1] = np.nan
     if where == "weight_inf": W[1, off_w1] = np.inf
     if where == "weight_huge": W[1, off_w1] = 1e200
     if where == "weight_2e25": W[1, off_w1] = 2.0 ** 25                  # finite, but beyond what a sliced matrix may hold (2^20)
-    if where == "bias_nan": W[1, 64 + 3] = np.nan
+    if where == "bias_nan": W[1, 64 * d + 3] = np.nan
     if where == "w0_inf": W[1, 3] = -np.inf
     if where == "tiny_weights": W[1] *= 1e-4                             # activations all tiny: fixed-scale digits lose relative accuracy
     if where == "x_nan": x[17, 0] = np.nan
