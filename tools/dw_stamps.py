@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: in-kernel stamps of k_i8_dw (library variant built with -DQN_DW_STAMPS): one cfg4-shape gradient call."""
+"""Diagnostic: in-kernel stamps of k_i8_dw_g / k_i8_dw (library variant built by `python tools/ab_build2.py dwstamps qn_dw_i8.hip -DQN_DW_STAMPS`): one cfg4-shape gradient call."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
