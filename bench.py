@@ -46,16 +46,17 @@ def synthetic(n, d, noise=0.02, seed=0):
     return x, y
 
 
-def cpu_baseline(arch, x, y, budget_s=24.0):
+def cpu_baseline(arch, x, y, budget_s=20.0):
     """The oracle's sequential float64 path (one eval at a time: unflatten -> Linear/tanh ->
     NegLogPost -> .item(), as the reference does) on this host's cores; bounded sample.
-    Timed with 1 thread, 16 threads and os.cpu_count() threads; the fastest is `value`."""
+    Timed with 1 thread and with min(16, os.cpu_count()) threads; the faster is `value`.  (More threads than 16
+    only lose on this 64-wide network: the round-3 run with all 256 hardware threads of the box made 1.0 eval/s.)"""
     from oracle import mlp_ref
     mod = mlp_ref.build_module(mlp_ref.MLPSpec(arch.dims, arch.activ))
     yd = [v for v in y]
     ws = [0.1 * np.random.RandomState(1000 + c).randn(arch.nparams) for c in range(16)]
     ncpu = os.cpu_count() or 1
-    counts = sorted({1, min(16, ncpu), ncpu})
+    counts = sorted({1, min(16, ncpu)})
     rates = {}
     old_threads = torch.get_num_threads()
     for nt in counts:
@@ -82,41 +83,109 @@ def cpu_baseline(arch, x, y, budget_s=24.0):
             "host_cpus": ncpu}
 
 
-def extras(op, arch, batches, args):
-    """Secondary measurements on the same resident workload (not part of `value`): the other kind of
-    eval (gradient <-> log-posterior) and the end-to-end device-resident AMCMC loop (proposal draw +
-    log-posterior + accept + history write per step, before the first adaptation)."""
-    out = {}
-    dev = op.device
-    other = "logpost" if args.kind == "grad" else "grad"
-    fn = (lambda W: op.sse(W)) if other == "logpost" else (lambda W: op.sse_grad(W))
-    for i in range(5):
-        fn(batches[i % NBATCH])
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    n = 50
-    for i in range(n):
-        fn(batches[i % NBATCH])
-    torch.cuda.synchronize(dev)
-    el = time.perf_counter() - t0
-    flops = arch.flops_fwd(N) if other == "logpost" else arch.flops_fwdbwd(N)
-    out[other + "_evals_per_s"] = CHAINS * n / el
-    out[other + "_tflops"] = CHAINS * n * flops / el / 1e12
-    if args.dtype == "f64":
-        from quinn_amd.mcmc.device_amcmc import DeviceAMCMC
-        ini = np.stack([np.random.RandomState(1000 + c).rand(arch.nparams) for c in range(CHAINS)])
-        eng = DeviceAMCMC(op, SIGMA, gamma=0.01, t0=100, tadapt=1000, seed=1)
-        eng.run(20, ini, store_chain=True)
+def graph_rate(fn, dev, settle_ms=300.0, regions=5, min_region_ms=20.0):
+    """Seconds per call of `fn` by the method of the headline number: the call captured in a HIP graph (as many consecutive
+    calls as make >= 2 ms), replayed untimed for `settle_ms` (clock ramp of a fresh process), then `regions` timed regions of
+    >= `min_region_ms` each between HIP events on the launch stream; returns (median, min, max) seconds per call."""
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        fn()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        r = eng.run(300, ini, store_chain=True)
+        fn()
         torch.cuda.synchronize(dev)
-        el = time.perf_counter() - t0
-        out["amcmc_end_to_end_steps_per_s"] = 300 / el
-        out["amcmc_end_to_end_logpost_evals_per_s"] = 300 * CHAINS / el
+        once = max(time.perf_counter() - t0, 1e-6)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    per = int(min(50, max(1, 2e-3 // once)))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(per):
+            fn()
+    g.replay()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < settle_ms:
+        g.replay()
+        torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    g.replay()
+    torch.cuda.synchronize(dev)
+    nrep = int(max(1, min_region_ms * 1e-3 // max(time.perf_counter() - t0, 1e-6) + 1))
+    times = []
+    for _ in range(regions):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(nrep):
+            g.replay()
+        b.record()
+        torch.cuda.synchronize(dev)
+        times.append(a.elapsed_time(b) * 1e-3 / (nrep * per))
+    del g
+    return float(np.median(times)), float(min(times)), float(max(times))
+
+
+# the other BASELINE configurations at the sizes of tools/bench_configs.py (parity-test cases, not bench lines)
+EXTRA_CFGS = (("cfg3_3x128_N8192_S128", (2, 128, 128, 128, 1), 8192, 128),
+              ("cfg4_4x256_N16384_M64", (1, 256, 256, 256, 256, 1), 16384, 64),
+              ("cfg5_4x256_N32768_C32", (1, 256, 256, 256, 256, 1), 32768, 32))
+
+
+def extras(op, arch, batches, args):
+    """Secondary measurements (not part of `value`), every rate by `graph_rate` -- the method of the headline number (HIP
+    graph, settled clock, HIP events, median of 5 regions): the other kind of eval on the resident workload, the headline step in
+    plain float64 arithmetic (`exact_f64`: the float64-MFMA fused kernels), the end-to-end device-resident AMCMC loop, and
+    the other BASELINE network shapes."""
+    out = {"method": "each rate: call captured in a HIP graph, replayed 300 ms untimed, then the median of 5 regions (>= 20 ms each) "
+                     "between HIP events; TFLOP/s = algorithmic float64 flops (SURVEY 8d) / time"}
+    dev = op.device
+    peak = PEAK_TFLOPS[args.dtype]
+    other = "logpost" if args.kind == "grad" else "grad"
+    k = [0]
+
+    def rot(f):
+        def call():
+            k[0] += 1
+            return f(batches[k[0] % NBATCH])
+        return call
+    fn = rot(op.sse) if other == "logpost" else rot(op.sse_grad)
+    flops = arch.flops_fwd(N) if other == "logpost" else arch.flops_fwdbwd(N)
+    nloc = batches[0].shape[0]
+    t, tmin, tmax = graph_rate(fn, dev)
+    out[other + "_evals_per_s"] = nloc / t
+    out[other + "_tflops"] = nloc * flops / t / 1e12
+    out[other + "_frac"] = nloc * flops / t / 1e12 / peak
+    out[other + "_ms_per_step"] = {"median": 1e3 * t, "min": 1e3 * tmin, "max": 1e3 * tmax}
+    if args.dtype == "f64" and args.path == "auto":
+        # the same step in plain float64 arithmetic (kernels='float64': k_fused_fwd_f64 / k_fused_bwd_f64 on the float64 matrix cores)
+        old = op.set_path(_lib.PATH_FUSED_DP)
+        try:
+            ex = {}
+            for kind, f2, fl in (("logpost", rot(op.sse), arch.flops_fwd(N)), ("grad", rot(op.sse_grad), arch.flops_fwdbwd(N))):
+                t, tmin, tmax = graph_rate(f2, dev)
+                ex[kind] = {"evals_per_s": nloc / t, "tflops": nloc * fl / t / 1e12, "frac": nloc * fl / t / 1e12 / peak,
+                            "ms_per_step": 1e3 * t}
+            ex["kernels"] = "k_fused_fwd_f64 / k_fused_bwd_f64 (QN_PATH_FUSED_DP: float64 MFMA + float64 VALU, no operand rounding)"
+            out["exact_f64"] = ex
+        finally:
+            op.set_path(old)
+    if args.dtype == "f64":
+        from quinn_amd.mcmc.device_amcmc import DeviceAMCMC
+        ini = np.stack([np.random.RandomState(1000 + c).rand(arch.nparams) for c in range(nloc)])
+        eng = DeviceAMCMC(op, SIGMA, gamma=0.01, t0=100, tadapt=1000, seed=1)
+        eng.run(300, ini, store_chain=True)                                  # (also settles the clock on this launch pattern)
+        torch.cuda.synchronize(dev)
+        rates = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            r = eng.run(600, ini, store_chain=True)
+            torch.cuda.synchronize(dev)
+            rates.append(600 / (time.perf_counter() - t0))
+        out["amcmc_end_to_end_steps_per_s"] = float(np.median(rates))
+        out["amcmc_end_to_end_logpost_evals_per_s"] = float(np.median(rates)) * nloc
         out["amcmc_accrate"] = float(r["accrate"].mean())
         # with adaptation switched on early (t0=100, tadapt=200): adapted proposals are drawn in sample
-        # space from the stored distinct states (qn_mcmc_propose_hist); cost grows with accepted moves
+        # space from the stored distinct states (qn_mcmc_propose_hist_block); cost grows with accepted moves
         eng = DeviceAMCMC(op, SIGMA, gamma=0.01, t0=100, tadapt=200, seed=1)
         eng.run(1000, ini, store_chain=True)
         torch.cuda.synchronize(dev)
@@ -126,25 +195,20 @@ def extras(op, arch, batches, args):
         el = time.perf_counter() - t0
         out["amcmc_adapting_steps_per_s"] = 1000 / el
         out["amcmc_adapting_accrate"] = float(r["accrate"].mean())
-        # the other BASELINE network shapes through the same operator (configs[2], configs[3]: parity-test cases, not bench
-        # lines): forward-only and forward + backward rates of the int8-slice kernels for 128 / 256-wide networks
-        del eng
-        for name, dims, n_rows, nb in (("cfg3_3x128_N8192_S128", (2, 128, 128, 128, 1), 8192, 128),
-                                       ("cfg4_4x256_N16384_M32", (1, 256, 256, 256, 256, 1), 16384, 32)):
+        del eng, r
+        torch.cuda.empty_cache()
+        for name, dims, n_rows, nb in EXTRA_CFGS:
             a2 = MLPArch(dims, "tanh")
             x2, y2 = synthetic(n_rows, dims[0])
             op2 = BatchedMLP(a2, x2, y2, device=dev)
             W2 = op2.weights(0.1 * np.random.RandomState(7).randn(nb, a2.nparams))
-            res = {}
+            res = {"arith_fwd": op2.arith(nb, n_rows, False), "arith_grad": op2.arith(nb, n_rows, True)}
             for kind, f2, fl in (("fwd", lambda: op2.sse(W2), a2.flops_fwd(n_rows)), ("grad", lambda: op2.sse_grad(W2), a2.flops_fwdbwd(n_rows))):
-                f2(); torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-                for _ in range(3):
-                    f2()
-                torch.cuda.synchronize(dev)
-                el = (time.perf_counter() - t0) / 3
-                res[kind + "_evals_per_s"] = nb / el
-                res[kind + "_tflops"] = nb * fl / el / 1e12
+                t, tmin, tmax = graph_rate(f2, dev)
+                res[kind + "_evals_per_s"] = nb / t
+                res[kind + "_tflops"] = nb * fl / t / 1e12
+                res[kind + "_frac"] = nb * fl / t / 1e12 / peak
+                res[kind + "_ms"] = {"median": 1e3 * t, "min": 1e3 * tmin, "max": 1e3 * tmax}
             out[name] = res
             del op2, W2
             torch.cuda.empty_cache()
@@ -166,11 +230,11 @@ def parse_args():
                     help="kernel family (fused_dp: the float64-MFMA fused kernels, without the sliced int8-product forward)")
     ap.add_argument("--graph", type=int, default=-1, help="capture this many consecutive steps in one HIP graph and "
                     "replay it (0 = direct launches, -1 = the largest divisor of --steps up to 50)")
-    ap.add_argument("--settle-ms", type=float, default=250.0, help="untimed run of the step before the timed region until the GPU "
+    ap.add_argument("--regions", type=int, default=5, help="timed regions of EXACTLY --steps steps each (barrier + synchronize on both "
+                    "sides, max over ranks); `value` / `ms_per_step` come from the MEDIAN region, all of them are listed in `config`")
+    ap.add_argument("--settle-ms", type=float, default=500.0, help="untimed run of the step before the timed region until the GPU "
                     "clock has settled (it ramps up over the first ~500 launches of a fresh process: the same kernel takes 97 us "
                     "right after start-up and 80 us from then on, profiles/r03_clock_ramp_kernel_trace.txt); 0 = off")
-    ap.add_argument("--spread", type=int, default=20, help="extra replays of the dominant kernel alone, after the timed "
-                    "region, for roofline.kernel_ms_min / _median / _max")
     return ap.parse_args()
 
 
@@ -260,6 +324,12 @@ def main():
     if args.graph:
         assert args.steps % args.graph == 0
         graph, out = capture(run, args.graph)
+    # the dominant kernel ALONE (what rocprofv3 reports for it): for the log-posterior the forward without the arrival
+    # epilogue that adds the row-split partial sums of a chain (qn_mlp_sse_fwd_parts); replayed after EACH timed region,
+    # i.e. interleaved with them at the same clock
+    alone = (lambda W: (op.sse_parts(W), None)) if (not want_grad and op.sse_parts(batches[0]).shape[1] > 1) else run
+    g2n = args.graph if args.graph else 1
+    g2, _ = capture(alone, g2n)
     # untimed: the step itself, replayed until the clock of a freshly started GPU has settled
     settle_steps = 0
     if args.settle_ms > 0:
@@ -273,53 +343,50 @@ def main():
                     out = run(batches[i % NBATCH])
                 settle_steps += 10
             torch.cuda.synchronize(dev)
-    barrier()
     nlaunch = args.steps // args.graph if args.graph else args.steps
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlaunch)]
-    t0 = time.perf_counter()
-    if args.graph:
-        for i in range(nlaunch):
-            ev[i][0].record()
-            graph.replay()
-            ev[i][1].record()
-    else:
-        for i in range(args.steps):
-            ev[i][0].record()
-            out = run(batches[i % NBATCH])
-            ev[i][1].record()
-    barrier()
-    el = time.perf_counter() - t0
-    # device time per step (one launch group = forward kernel + partial-sum kernel), HIP events on the launch stream
-    per = args.graph if args.graph else 1
-    step_dev_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / per
+    nrep2 = max(1, args.steps // g2n)
+    regions = max(1, args.regions)
+    el_r, dev_r, kern_r = [], [], []
+    for r in range(regions):
+        # ---- one timed region: EXACTLY --steps steps between barrier + synchronize on both sides
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        e0.record()
+        if args.graph:
+            for i in range(nlaunch):
+                graph.replay()
+        else:
+            for i in range(args.steps):
+                out = run(batches[i % NBATCH])
+        e1.record()
+        barrier()
+        el_r.append(time.perf_counter() - t0)
+        dev_r.append(e0.elapsed_time(e1) / args.steps)                       # device ms per step (HIP events, launch stream)
+        # ---- the kernel alone, same number of steps, right behind the region
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record()
+        for i in range(nrep2):
+            g2.replay()
+        k1.record()
+        torch.cuda.synchronize(dev)
+        kern_r.append(k0.elapsed_time(k1) / (nrep2 * g2n))
     lp_last = -neg_log_post_from_sse(out[0].cpu().numpy(), N, SIGMA)
     assert np.all(np.isfinite(lp_last))
-
-    # the dominant kernel ALONE (what rocprofv3 reports for it): for the log-posterior the forward without the
-    # 64-thread kernel that adds the row-split partial sums of a chain (qn_mlp_sse_fwd_parts); replayed
-    # max(nlaunch, --spread) times AFTER the timed region, one event pair per replay -> mean and spread
-    kern = {"kernel_ms": step_dev_ms}
-    if rank == 0:
-        alone = (lambda W: op.sse_parts(W)) if (not want_grad and op.sse_parts(batches[0]).shape[1] > 1) else run
-        g2n = args.graph if args.graph else 1
-        g2, _ = capture(alone, g2n)
-        torch.cuda.synchronize(dev)
-        nrep = max(nlaunch, args.spread)
-        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nrep)]
-        for a_, b_ in ev2:
-            a_.record()
-            g2.replay()
-            b_.record()
-        torch.cuda.synchronize(dev)
-        ms = np.array([a_.elapsed_time(b_) for a_, b_ in ev2]) / g2n
-        kern = {"kernel_ms": float(ms.mean()), "kernel_ms_min": float(ms.min()), "kernel_ms_median": float(np.median(ms)),
-                "kernel_ms_max": float(ms.max()), "kernel_ms_samples": int(nrep), "kernel_steps_per_sample": int(g2n)}
+    # region times: MAX over ranks per region, then the MEDIAN region is the one reported
+    el_t = torch.tensor(el_r, dtype=torch.float64)
+    if dist is not None:
+        t = el_t.to(cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el_t = t.cpu()
+    el = float(el_t.median())                                                # (lower median for an even count)
+    step_dev_ms = float(np.median(dev_r))
+    kms = np.array(kern_r)
+    kern = {"kernel_ms": float(np.median(kms)), "kernel_ms_min": float(kms.min()), "kernel_ms_median": float(np.median(kms)),
+            "kernel_ms_max": float(kms.max()), "kernel_ms_samples": int(regions), "kernel_steps_per_sample": int(nrep2 * g2n)}
 
     t_max = el
     if dist is not None:
-        t = torch.tensor([el], device=cdev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_max = float(t.item())
         # the single end-of-run collective (RCCL): every rank's final log-posteriors, padded to the largest shard
         nmax = -(-total // world)
         send = torch.zeros(nmax, device=cdev, dtype=torch.float64)
@@ -368,6 +435,8 @@ def main():
                "kind": args.kind, "kernel_path": kpath, "kernel": kernel, "settle_ms": args.settle_ms, "settle_steps": settle_steps,
                "launch": (f"HIP graph of {args.graph} steps, replayed {args.steps // args.graph}x" if args.graph
                           else "direct launches"),
+               "timed_regions": int(regions), "value_from": f"median of {regions} timed regions of {args.steps} steps each (max over ranks per region)",
+               "region_ms_per_step": [1e3 * float(v) / args.steps for v in el_t],
                "parallelism": f"chains sharded x{world}, no data-path collective, one all_gather at the end"}
         if backend != "nccl" and world > 1:
             cfg["rehearsal"] = f"{world} ranks share cuda:0 of a {torch.cuda.device_count()}-GPU box, {backend} collectives"

@@ -70,6 +70,14 @@ size_t qn_workspace_bytes(const qn_desc* desc, int B, int Nb, int want_grad, int
 
 /* Which kernel family the next call with these sizes would run (QN_PATH_GENERIC/FUSED). */
 int qn_mlp_path(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
+/* Which ARITHMETIC the next call with these sizes would form the hidden-layer products in: QN_ARITH_PLAIN -- the arithmetic
+ * of `dtype` throughout; QN_ARITH_I8_FUSED -- sliced exact int8 products in the one-launch kernels of 64-wide tanh networks
+ * (qn_fused_i8.hip / qn_fused_bwd_i8.hip; also a narrower network's zero-padded 64-wide twin); QN_ARITH_I8_WIDE -- the
+ * int8-slice kernels of 128 / 256-wide tanh networks (qn_wide_i8.hip, qn_dw_i8.hip); QN_ARITH_I8_LAYERS -- the layer-wise
+ * int8-slice forward of other tanh networks whose widths are multiples of 64.  (The reference has one arithmetic, torch
+ * float64: quinn/nns/tchutils.py:9; tests use this query to prove which kernels a parity case exercised.) */
+enum { QN_ARITH_PLAIN = 0, QN_ARITH_I8_FUSED = 1, QN_ARITH_I8_WIDE = 2, QN_ARITH_I8_LAYERS = 3 };
+int qn_mlp_arith(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
 /* Force a kernel family for the calls made with THIS descriptor (QN_PATH_AUTO restores dispatch by shape).  Returns
  * the previous setting.  There is no process-wide state: two operators in one process do not see each other's
  * choice.  QN_PATH_GENERIC is the layer-wise family at the EXACT layer widths; under QN_PATH_AUTO hidden widths that

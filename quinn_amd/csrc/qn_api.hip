@@ -430,6 +430,16 @@ extern "C" int qn_mlp_path(const qn_desc* d, int B, int Nb, int want_grad, int d
     return use_fused(d, B, Nb, want_grad, dtype) ? QN_PATH_FUSED : QN_PATH_GENERIC;
 }
 
+extern "C" int qn_mlp_arith(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
+    if (!d) return QN_EINVAL;
+    if (d->kind != QN_KIND_MLP || dtype != QN_F64) return QN_ARITH_PLAIN;
+    if (use_fused(d, B, Nb, want_grad, dtype)) return qn_fused_uses_i8(fused_desc(d), want_grad) ? QN_ARITH_I8_FUSED : QN_ARITH_PLAIN;
+    if (d->path != QN_PATH_AUTO) return QN_ARITH_PLAIN;
+    const qn_desc* g = use_padded_generic(d) ? d->padded : d;                 // the network the layer-wise family runs
+    if (qn_i8_wide_applies(g)) return QN_ARITH_I8_WIDE;
+    return qn_i8_layers_apply(g) ? QN_ARITH_I8_LAYERS : QN_ARITH_PLAIN;
+}
+
 extern "C" size_t qn_workspace_bytes(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
     if (!d || B <= 0 || Nb <= 0) return 0;
     if (d->kind == QN_KIND_RNET) {      // sized for either family so that qn_mlp_desc_set_path never invalidates a caller's buffer

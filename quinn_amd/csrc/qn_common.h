@@ -74,3 +74,4 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
                  const int32_t* row_idx, int B, int N, int Nb, double* sse, void* pred,
                  void* gradW, void* ws, size_t ws_bytes, hipStream_t st, bool parts_out = false);
 int qn_fused_parts(const qn_desc* d, int B, int Nb);
+bool qn_fused_uses_i8(const qn_desc* d, int want_grad);     // the sliced int8-product kernels would run (not the float64-MFMA ones)

@@ -1227,6 +1227,8 @@ int arm_lds(const void* fn) {
 
 }  // namespace
 
+bool qn_fused_uses_i8(const qn_desc* d, int want_grad) { return want_grad ? uses_i8_bwd(d) : uses_i8(d, 0); }
+
 bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtype) {
     int H, nhid;
     if (dtype != QN_F64) return false;

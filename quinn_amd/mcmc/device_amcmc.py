@@ -239,8 +239,11 @@ class DeviceAMCMC:
             # due in the same window (45 ms for 64 chains: that window ran at 5.7 k steps/s against 7.5-8 k around it).  The
             # early-eligibility threshold is therefore staggered by chain (global id mod 8, a quarter window apart): the first
             # cycle is spread over the windows before, and the later cycles inherit the spread.
+            # Only a chain's FIRST compression is staggered (s['ncomp'] counts them): afterwards a chain restarts from
+            # 2 r + 1 rows, and an offset of up to 1.75 windows would keep it "due" from the moment it was compressed.
             high = kcap - 2 * room
-            stag = ((self.chain0 + np.arange(len(kc_h))) % 8) * (room // 4)
+            ncomp = s.setdefault('ncomp', np.zeros(len(kc_h), dtype=np.int64))
+            stag = np.where(ncomp == 0, ((self.chain0 + np.arange(len(kc_h))) % 8) * (room // 4), 0)
             budget = max(len(sel), -(-len(kc_h) // 6))                          # (a chain comes due every ~6 windows at acceptance 0.3)
             extra = [c for c in np.argsort(-(kc_h + stag)) if ok[c] and kc_h[c] + stag[c] > high and c not in set(sel)]
             sel += extra[:max(0, budget - len(sel))]
@@ -295,6 +298,8 @@ class DeviceAMCMC:
             s['mult'][idx, 2 * r] = (ncs - 2 * r).to(s['mult'].dtype)
             s['mult'][idx, 2 * r + 1] = cur_mult
             s['kcur'][par, idx] = 2 * r + 1
+        if 'ncomp' in s or sel:
+            s.setdefault('ncomp', np.zeros(len(kc_h), dtype=np.int64))[[int(c) for c in sel]] += 1
         return len(sel)
 
     def prepare(self, nmcmc, nchains):

@@ -285,6 +285,11 @@ class BatchedMLP:
     def path(self, B, Nb=None, want_grad=False):
         return int(self._L.qn_mlp_path(self._desc, B, Nb or self.N, int(want_grad), self.qdt))
 
+    def arith(self, B, Nb=None, want_grad=False):
+        """`_lib.ARITH_PLAIN` / `ARITH_I8_FUSED` / `ARITH_I8_WIDE` / `ARITH_I8_LAYERS`: the arithmetic the next call with these
+        sizes forms the hidden-layer products in (qn_mlp_arith)."""
+        return int(self._L.qn_mlp_arith(self._desc, B, Nb or self.N, int(want_grad), self.qdt))
+
     def set_path(self, path):
         """Force a kernel family for THIS operator (`_lib.PATH_AUTO` / `PATH_GENERIC` / `PATH_FUSED`; tests and
         profiling); returns the previous setting.  Per descriptor: other operators are unaffected."""

@@ -525,3 +525,87 @@ def g11():
 
 if __name__ == "__main__" and "ens_noval" in sys.argv[1:]:
     g11()
+
+
+# ---------------------------------------------------------------- G12: chains / ELBO on the shapes the DEFAULT kernels take
+def g12():
+    """Chains whose log-posterior / gradient evaluations are routed to the sliced int8-product kernels by the build
+    (64-wide tanh networks: k_fused_fwd_i8 / k_fused_bwd_i8; a 40-wide network through its zero-padded 64-wide twin;
+    a 128-wide network through k_i8_wide_*): HMC (L = 3, L = 10) and MALA on MLP(1,1,(64,64,64),'tanh'), adaptive
+    Metropolis with the adaptation firing three times on MLP(1,1,(40,40),'tanh'), viloss + gradients at (2,128,128,1).
+    Step sizes are chosen so that acceptances AND rejections occur (mh_prob on both sides of the uniform draw).
+    The start point is data (0.1 * RandomState(s).rand(p)): the sampler classes are driven directly, as in G3."""
+    import contextlib
+    import io
+    d, o, hls, act, N, sigma = 1, 1, (64, 64, 64), "tanh", 96, 0.2
+    x, y = data(N, d, o, 0.05, 200)
+    for name, kind, eps, L, nmcmc, seed in [("g12_hmc_0.npz", "hmc", 0.006, 3, 80, 11), ("g12_hmc_1.npz", "hmc", 0.004, 10, 60, 12),
+                                            ("g12_mala.npz", "mala", 0.005, 1, 80, 13)]:
+        solver = NN_MCMC(MLP(d, o, hls, activ=act), verbose=False)
+        solver.lpinfo = {"model": nn_p, "xd": x, "yd": [yy for yy in y], "ltype": "classical", "lparams": {"sigma": sigma}}
+        ini = 0.1 * np.random.RandomState(seed + 1000).rand(solver.pdim)
+        np.random.seed(seed)
+        drawn, orig = _record_uniforms()
+        mc = HMC(epsilon=eps, L=L) if kind == "hmc" else MALA(epsilon=eps)
+        mc.setLogPost(solver.logpost, solver.logpostgrad, lpinfo=solver.lpinfo)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = mc.run(param_ini=ini, nmcmc=nmcmc)
+        finally:
+            np.random.random_sample = orig
+        acc = (res["chain"][1:] != res["chain"][:-1]).any(axis=1)
+        assert 0.2 < acc.mean() < 0.95, acc.mean()
+        # (p = 8513: the full chain would be 5 MB per fixture -- every step of 256 strided columns, plus three full states)
+        cols = np.arange(0, solver.pdim, 34)[:256]
+        save(name, dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y, sigma=sigma, seed=seed, nmcmc=nmcmc, L=L,
+             epsilon=eps, param_ini=ini, accepted=acc, cols=cols, chain_cols=res["chain"][:, cols], chain_mid=res["chain"][nmcmc // 2],
+             chain_final=res["chain"][-1], logpost=res["logpost"], alphas=res["alphas"], accrate=res["accrate"],
+             mapparams=res["mapparams"], maxpost=res["maxpost"], uniforms=np.array(drawn))
+    # adaptive Metropolis, p = 1761 (the reference refactorises the 1761 x 1761 proposal covariance on every draw: ~1.1 s per step)
+    hls, N, seed, nmcmc = (40, 40), 80, 14, 70
+    x, y = data(N, d, o, 0.05, 201)
+    solver = NN_MCMC(MLP(d, o, hls, activ=act), verbose=False)
+    solver.lpinfo = {"model": nn_p, "xd": x, "yd": [yy for yy in y], "ltype": "classical", "lparams": {"sigma": sigma}}
+    ini = 0.1 * np.random.RandomState(seed + 1000).rand(solver.pdim)
+    sp = {"gamma": 3.0, "t0": 10, "tadapt": 20}
+    np.random.seed(seed)
+    drawn, orig = _record_uniforms()
+    mc = AMCMC(cov_ini=1e-5 * np.eye(solver.pdim), **sp)
+    mc.setLogPost(solver.logpost, None, lpinfo=solver.lpinfo)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = mc.run(param_ini=ini, nmcmc=nmcmc)
+    finally:
+        np.random.random_sample = orig
+    acc = (res["chain"][1:] != res["chain"][:-1]).any(axis=1)
+    assert 0.2 < acc.mean() < 0.95 and 0 < acc[21:].mean() < 1, acc.mean()
+    save("g12_amcmc.npz", dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y, sigma=sigma, seed=seed, nmcmc=nmcmc,
+         cov_ini_diag=1e-5, param_ini=ini, chain=res["chain"], logpost=res["logpost"], alphas=res["alphas"],
+         accrate=res["accrate"], mapparams=res["mapparams"], maxpost=res["maxpost"], uniforms=np.array(drawn), **sp)
+    # viloss + gradients on a 128-wide network (the wide int8-slice kernels), S = 3
+    d, o, hls, N, S, prior = 2, 1, (128, 128), 200, 3, (0.5, 1.0, 1.0)
+    torch.manual_seed(120)
+    net = MLP(d, o, hls, activ=act)
+    x, y = data(N, d, o, 0.05, 202)
+    bm = BNet(net, pi=prior[0], sigma1=prior[1], sigma2=prior[2])
+    mu, rho = _bnet_flat(bm)
+    datanoise, nb = 0.1, 2
+    bm.loss_params = [datanoise, S, nb]
+    drawn, orig = _record_normals()
+    try:
+        xt, yt = torch.tensor(x), torch.tensor(y)
+        lp, lq, nll = bm.sample_elbo(xt, yt, S, likparams=[datanoise])
+        n_first = len(drawn)
+        loss = bm.viloss(xt, yt)
+    finally:
+        torch.distributions.Normal.sample = orig
+    loss.backward()
+    dmu, drho = _bnet_grads(bm)
+    save("g12_viloss.npz", dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y, mu=mu, rho=rho, nsam=S,
+         datanoise=datanoise, num_batches=nb, prior=np.array(prior), eps_elbo=np.concatenate(drawn[:n_first]).reshape(S, -1),
+         elbo_log_prior=lp.item(), elbo_log_q=lq.item(), elbo_nll=nll.item(),
+         eps_loss=np.concatenate(drawn[n_first:]).reshape(S, -1), loss=loss.item(), dmu=dmu, drho=drho, torch_seed=120)
+
+
+if __name__ == "__main__" and "g12" in sys.argv[1:]:
+    g12()
