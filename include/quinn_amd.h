@@ -190,15 +190,20 @@ int qn_mcmc_propose(const double* cur, const double* sd, double c1, int C, int c
  *   counter.  cur_lp, best_lp, kcur: [2, C] and step_ptr: [2] -- slot `parity` (0 / 1) is read, slot 1 - parity
  *   written; the caller alternates parity from step to step (slot 0 holds the initial state for parity 0).
  *   With hist != NULL it also maintains what the adapted proposal is drawn from
- *   (qn_mcmc_propose_hist): hist [C, kcap, pstride] float32 = the DISTINCT states visited, minus x0
- *   (row 0 = the start, a new row per accepted move), mult [C, kcap] their multiplicities in the
- *   chain so far, kcur [2, C] the index of the current state's row, sumx [C, p] the running sum of
- *   (x_i - x0) over all samples.  kcur[c] >= kcap means the history is full (rows are not stored). */
+ *   (qn_mcmc_propose_hist): hist [C, kcap, pstride] FLOAT16 = the DISTINCT states visited, as (x - x0[c]) * hscale[c]
+ *   (x0 [C, p] float64: the chain's reference point -- the start, or wherever the caller re-bases the rows to; hscale [C]
+ *   float64 or NULL = 1: a power of two that keeps the rows in float16's range, values are clamped to +-65504; half the bytes
+ *   of float32 rows for the kernel that streams the whole history, and its products on the float16 matrix cores; rounding
+ *   2^-11 of |x - x0|) (row 0 = the start, a new row per accepted move), mult [C, kcap] their multiplicities in the
+ *   chain so far, kcur [2, C] the index of the current state's row, sumx [C, p] the sum of mult x (x - x0) over the
+ *   states the chain has LEFT (a stay is added when the chain leaves the state -- no per-step pass over the vector; the sum
+ *   of (x_i - x0) over all samples so far is sumx + mult[c, kcur[c]] x (cur[c] - x0[c])).  kcur[c] >= kcap means the history
+ *   is full: rows, multiplicities and the sum are no longer maintained (the caller compresses before that happens). */
 int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int chain0, int64_t p,
                    int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
-                   double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0, float* hist,
-                   int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride, int64_t* step_ptr,
-                   int parity, int nparts, void* stream);
+                   double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0, void* hist,
+                   const double* hscale, int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride,
+                   int64_t* step_ptr, int parity, int nparts, void* stream);
 
 /* qn_mcmc_accept_propose: qn_mcmc_accept that also writes the NEXT step's proposal from the state it has just decided
  * (one launch and one pass over the state fewer per step): next_mode 0 = nothing more; 1 = prop_next = cur' + sd z +
@@ -207,40 +212,44 @@ int qn_mcmc_accept(const double* prop, const double* sse_prop, double sigma, int
  * prop_next may be the buffer `prop`. */
 int qn_mcmc_accept_propose(const double* prop, const double* sse_prop, double sigma, int n_rows, int C, int chain0,
                            int64_t p, int nmcmc, uint64_t seed, double* cur, double* cur_lp, double* best, double* best_lp,
-                           double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0, float* hist,
-                           int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride, int64_t* step_ptr,
-                           int next_mode, const double* sd, double c1, const double* delta, int t_next, double s_iso,
+                           double* chain, double* lps, double* alphas, int64_t* nacc, const double* x0, void* hist,
+                           const double* hscale, int32_t* mult, int32_t* kcur, double* sumx, int kcap, int64_t pstride,
+                           int64_t* step_ptr, int next_mode, const double* sd, double c1, const double* delta, int t_next, double s_iso,
                            double* prop_next, int parity, int nparts, void* stream);
 
 /* qn_mcmc_propose_hist: the ADAPTED proposal of adaptive Metropolis (admcmc.py:52-70), drawn in sample
  *   space.  After an adaptation at step i the reference proposes from N(x, c (cov_i + 1e-8 I)) with
  *   cov_i the unbiased sample covariance of x_0..x_i and c = gamma 2.4^2 / p.  With the K distinct
  *   states x_k of that history, multiplicities w_k, mean m and n = i + 1,
- *       out[c,:] = cur[c,:] + s_lr * sum_k wsnap[c,k] u_k (hist[c,k,:] - msnap[c,:]) + s_iso * v,
+ *       out[c,:] = cur[c,:] + s_lr * sum_k wsnap[c,k] u_k (hist[c,k,:] / hscale[c] - msnap[c,:]) + s_iso * v,
  *   u_k, v_j iid N(0,1), wsnap = sqrt(w), s_lr = sqrt(c/(n-1)), s_iso = sqrt(c 1e-8), has exactly that
  *   covariance: a K x p GEMV over the stored states instead of a p x p factor (cfg2: K ~ 10^2..10^3
  *   rows of 34 KB per chain and step instead of 290-580 MB).  ksnap [C] = K per chain, msnap [C, p] =
- *   mean of (x - x0) at the adaptation, both frozen until the next adaptation.  pstride even, >= p
+ *   mean of (x - x0) at the adaptation, both frozen until the next adaptation.  hist: float16 rows (x_k - x0) * hscale
+ *   (qn_mcmc_accept); the coefficients wsnap u_k are rounded to float16 as well (the matrix cores' operand type; both the
+ *   single-step and the block kernel use the rounded values, products accumulate in float32 / float64).  pstride even, >= p
  *   (a multiple of 4 for qn_mcmc_propose_hist_block). */
-int qn_mcmc_propose_hist(const double* cur, const float* hist, const float* wsnap, const int32_t* ksnap,
-                         const double* msnap, double s_lr, double s_iso, int C, int chain0, int64_t p, int64_t pstride,
-                         int kcap, uint64_t seed, const int64_t* step_ptr, double* out, void* stream);
+int qn_mcmc_propose_hist(const double* cur, const void* hist, const float* wsnap, const int32_t* ksnap,
+                         const double* msnap, const double* hscale, double s_lr, double s_iso, int C, int chain0, int64_t p,
+                         int64_t pstride, int kcap, uint64_t seed, const int64_t* step_ptr, double* out, void* stream);
 
 /* The same draw for TB = qn_mcmc_hist_block_steps() (= 64) consecutive steps in one pass over the stored states:
  * the increment of step t depends only on the frozen snapshot and on that step's random numbers (keyed
  * by the absolute step, exactly as in qn_mcmc_propose_hist), not on the chain's state, so
- *   delta[c, t, :] = s_lr * sum_k wsnap[c,k] u_k^(step0+t) (hist[c,k,:] - msnap[c,:])
+ *   delta[c, t, :] = s_lr * sum_k wsnap[c,k] u_k^(step0+t) (hist[c,k,:] / hscale[c] - msnap[c,:])
  * for t = 0..TB-1 reads the history once: HBM traffic per step / TB, a (TB x K).(K x p) product per chain
- * (float32 matrix cores).  step_ptr != NULL: step0 is read from the device step counter when the kernels
- * run (a static launch, capturable in a HIP graph).  coef: scratch of C * (ceil4(kcap) + 1) * TB float32; delta: [C, TB, p] float64.
+ * (v_mfma_f32_32x32x16_f16: float16 operands, float32 accumulation).  step_ptr != NULL: step0 is read from the device step
+ * counter when the kernels run (a static launch, capturable in a HIP graph).  coef: scratch of
+ * qn_mcmc_hist_block_coef_bytes(C, kcap) bytes; delta: [C, TB, p] float64.
  * order (optional, [C] int32): a permutation of the chains giving the dispatch order of the history product -- pass the
  * chains sorted by ksnap, longest first (the work per chain is proportional to ksnap[c]); results do not depend on it.
  * qn_mcmc_apply_delta: out[c,:] = cur[c,:] + delta[c, t, :] + s_iso * v (the proposal of step step0 + t; v on the
  * stream of the CURRENT step *step_ptr, as in qn_mcmc_propose_hist; s_iso is unused by the block call). */
 int qn_mcmc_hist_block_steps(void);
-int qn_mcmc_propose_hist_block(const float* hist, const float* wsnap, const int32_t* ksnap, const double* msnap,
-                               double s_lr, double s_iso, int C, int chain0, int64_t p, int64_t pstride, int kcap,
-                               uint64_t seed, int64_t step0, const int64_t* step_ptr, float* coef, double* delta,
+size_t qn_mcmc_hist_block_coef_bytes(int C, int kcap);
+int qn_mcmc_propose_hist_block(const void* hist, const float* wsnap, const int32_t* ksnap, const double* msnap,
+                               const double* hscale, double s_lr, double s_iso, int C, int chain0, int64_t p, int64_t pstride,
+                               int kcap, uint64_t seed, int64_t step0, const int64_t* step_ptr, void* coef, double* delta,
                                const int32_t* order, void* stream);
 int qn_mcmc_apply_delta(const double* cur, const double* delta, int t, double s_iso, int C, int chain0, int64_t p,
                         uint64_t seed, const int64_t* step_ptr, double* out, void* stream);

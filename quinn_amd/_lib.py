@@ -21,7 +21,7 @@ ARITH_PLAIN, ARITH_I8_FUSED, ARITH_I8_WIDE, ARITH_I8_LAYERS = 0, 1, 2, 3
 # every symbol include/quinn_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = ["qn_mlp_desc_create", "qn_rnet_desc_create", "qn_rnet_desc_set_uses", "qn_mlp_desc_destroy", "qn_mlp_num_params", "qn_workspace_bytes",
            "qn_mlp_path", "qn_mlp_arith", "qn_mlp_desc_set_path", "qn_mlp_sse_fwd", "qn_mlp_sse_parts", "qn_mlp_sse_fwd_parts", "qn_mlp_sse_fwdbwd", "qn_vi_sample_kl",
-           "qn_vi_grad", "qn_adam_batched", "qn_mcmc_propose", "qn_mcmc_propose_hist", "qn_mcmc_hist_block_steps", "qn_mcmc_propose_hist_block",
+           "qn_vi_grad", "qn_adam_batched", "qn_mcmc_propose", "qn_mcmc_propose_hist", "qn_mcmc_hist_block_steps", "qn_mcmc_hist_block_coef_bytes", "qn_mcmc_propose_hist_block",
            "qn_mcmc_apply_delta", "qn_mcmc_accept", "qn_mcmc_accept_propose", "qn_hmc_parts", "qn_hmc_begin", "qn_hmc_leap", "qn_hmc_accept", "qn_pred_moments", "qn_debug_tanh", "qn_debug_tanh_finite", "qn_debug_tanh_table", "qn_last_error",
            "qn_version"]
 
@@ -123,18 +123,20 @@ def lib():
     u64 = ctypes.c_uint64
     L.qn_mcmc_propose.argtypes = [vp, vp, f64, i32, i32, i64, u64, vp, vp, vp]
     L.qn_mcmc_propose.restype = i32
-    L.qn_mcmc_propose_hist.argtypes = [vp, vp, vp, vp, vp, f64, f64, i32, i32, i64, i64, i32, u64, vp, vp, vp]
+    L.qn_mcmc_propose_hist.argtypes = [vp, vp, vp, vp, vp, vp, f64, f64, i32, i32, i64, i64, i32, u64, vp, vp, vp]
     L.qn_mcmc_propose_hist.restype = i32
     L.qn_mcmc_hist_block_steps.argtypes = []
     L.qn_mcmc_hist_block_steps.restype = i32
-    L.qn_mcmc_propose_hist_block.argtypes = [vp, vp, vp, vp, f64, f64, i32, i32, i64, i64, i32, u64, i64, vp, vp, vp, vp, vp]
+    L.qn_mcmc_hist_block_coef_bytes.argtypes = [i32, i32]
+    L.qn_mcmc_hist_block_coef_bytes.restype = sz
+    L.qn_mcmc_propose_hist_block.argtypes = [vp, vp, vp, vp, vp, f64, f64, i32, i32, i64, i64, i32, u64, i64, vp, vp, vp, vp, vp]
     L.qn_mcmc_propose_hist_block.restype = i32
     L.qn_mcmc_apply_delta.argtypes = [vp, vp, i32, f64, i32, i32, i64, u64, vp, vp, vp]
     L.qn_mcmc_apply_delta.restype = i32
-    L.qn_mcmc_accept.argtypes = [vp, vp, f64, i32, i32, i32, i64, i32, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+    L.qn_mcmc_accept.argtypes = [vp, vp, f64, i32, i32, i32, i64, i32, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                  vp, i32, i64, vp, i32, i32, vp]
     L.qn_mcmc_accept.restype = i32
-    L.qn_mcmc_accept_propose.argtypes = [vp, vp, f64, i32, i32, i32, i64, i32, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+    L.qn_mcmc_accept_propose.argtypes = [vp, vp, f64, i32, i32, i32, i64, i32, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                          vp, vp, vp, i32, i64, vp, i32, vp, f64, vp, i32, f64, vp, i32, i32, vp]
     L.qn_mcmc_accept_propose.restype = i32
     L.qn_hmc_parts.argtypes = [i64]

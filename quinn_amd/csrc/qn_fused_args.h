@@ -51,7 +51,12 @@ __device__ __forceinline__ void qn_sse_finish(double* __restrict__ partial, unsi
     unsigned count = 0;
     if (lane == 0) {
         __hip_atomic_store(&partial[(int64_t)b * nsplit + split], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): the store is acknowledged
+        // vmcnt(0): the store is acknowledged before the arrival is issued.  The two relaxed atomics are on different addresses,
+        // so the language gives the compiler no order between them: the signal fences pin it (compiler-only, no instruction).
+        // gfx950-specific: the hardware order rests on the sc1 write-through store being complete when vmcnt reaches 0.
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         unsigned long long old = __hip_atomic_fetch_add(&arrive[b], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((old >> 16) == QN_ARRIVE_MAGIC) {
             count = (unsigned)(old & 0xffff) + 1;

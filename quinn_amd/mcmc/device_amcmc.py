@@ -47,7 +47,7 @@ from ..ops import BatchedMLP
 class DeviceAMCMC:
     def __init__(self, op: BatchedMLP, sigma, gamma=0.1, t0=100, tadapt=1000, cov_ini=None, seed=0,
                  use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=True, groups=1, max_rows=4096,
-                 overlap_hist=True):
+                 overlap_hist=True, hist_scale0=256.0):
         if op.dtype != "float64":
             raise NotImplementedError("the device AMCMC engine runs the float64 operator")
         self.op, self.sigma = op, float(sigma)
@@ -75,6 +75,9 @@ class DeviceAMCMC:
         # (they depend on the frozen snapshot and the step numbers only): the history product streams the chains'
         # histories from HBM, the log-posterior kernel is bound by vector issue, and the accept kernels leave most of the
         # GPU idle.  Same random numbers, same results (tests/test_gpu_device_amcmc.py)
+        # history rows are float16((x - ref) * S): S starts at `hist_scale0` (a power of two; rows saturate at |x - ref| =
+        # 65504 / S) with ref = the start, and is re-chosen per chain -- together with ref -- at every compression of its history
+        self.hist_scale0 = float(2.0 ** round(np.log2(hist_scale0)))
         self.overlap_hist = bool(overlap_hist) and not os.environ.get("QUINN_AMD_NO_HIST_OVERLAP")
         self._side = None
         self._subs = None
@@ -99,7 +102,8 @@ class DeviceAMCMC:
         """Increments of TB steps from the device step counter on (step_abs None), or from the absolute step step_abs."""
         C, _, p = delta.shape
         _lib.check(self._L.qn_mcmc_propose_hist_block(
-            s['hist'].data_ptr(), snap['w'].data_ptr(), snap['k'].data_ptr(), snap['mean'].data_ptr(), snap['s_lr'],
+            s['hist'].data_ptr(), snap['w'].data_ptr(), snap['k'].data_ptr(), snap['mean'].data_ptr(), s['hscale'].data_ptr(),
+            snap['s_lr'],
             snap['s_iso'], C, self.chain0, p, s['hist'].shape[2], s['hist'].shape[1], self.seed,
             0 if step_abs is None else int(step_abs), self._step_ptr(s) if step_abs is None else None,
             coef.data_ptr(),
@@ -122,7 +126,7 @@ class DeviceAMCMC:
                 prop.data_ptr(), sse.data_ptr(), self.sigma, self.op.N, C, self.chain0, p, nmcmc, self.seed,
                 s['cur'].data_ptr(), s['cur_lp'].data_ptr(), s['best'].data_ptr(), s['best_lp'].data_ptr(),
                 s['chain'].data_ptr() if s['chain'] is not None else None, s['lps'].data_ptr(), s['alphas'].data_ptr(),
-                s['nacc'].data_ptr(), s['x0'].data_ptr(), s['hist'].data_ptr(), s['mult'].data_ptr(),
+                s['nacc'].data_ptr(), s['x0'].data_ptr(), s['hist'].data_ptr(), s['hscale'].data_ptr(), s['mult'].data_ptr(),
                 s['kcur'].data_ptr(), s['sumx'].data_ptr(), s['hist'].shape[1], s['hist'].shape[2], s['step'].data_ptr(),
                 mode, sd.data_ptr() if sd is not None else None, c1, delta.data_ptr() if delta is not None else None,
                 int(t), s_iso, prop.data_ptr(), s['par'], nparts, self._stream()), "qn_mcmc_accept_propose")
@@ -132,7 +136,7 @@ class DeviceAMCMC:
             prop.data_ptr(), sse.data_ptr(), self.sigma, self.op.N, C, self.chain0, p, nmcmc, self.seed, s['cur'].data_ptr(),
             s['cur_lp'].data_ptr(), s['best'].data_ptr(), s['best_lp'].data_ptr(),
             s['chain'].data_ptr() if s['chain'] is not None else None, s['lps'].data_ptr(), s['alphas'].data_ptr(),
-            s['nacc'].data_ptr(), s['x0'].data_ptr(), s['hist'].data_ptr(), s['mult'].data_ptr(),
+            s['nacc'].data_ptr(), s['x0'].data_ptr(), s['hist'].data_ptr(), s['hscale'].data_ptr(), s['mult'].data_ptr(),
             s['kcur'].data_ptr(), s['sumx'].data_ptr(), s['hist'].shape[1], s['hist'].shape[2],
             s['step'].data_ptr(), s['par'], nparts, self._stream()), "qn_mcmc_accept")
         s['par'] ^= 1              # the kernel read slot `par` of the per-chain scalars / step counter and wrote the other
@@ -164,15 +168,15 @@ class DeviceAMCMC:
         # ---- several groups of chains side by side
         bounds = [C * g // G for g in range(G + 1)]
         pstride = (p + 3) // 4 * 4
-        if C * self._kcap(nmcmc) * pstride * 4 > self.max_history_bytes:
-            raise MemoryError(f"state history {C} x {self._kcap(nmcmc)} x {pstride} float32 exceeds max_history_bytes="
+        if C * self._kcap(nmcmc) * pstride * 2 > self.max_history_bytes:
+            raise MemoryError(f"state history {C} x {self._kcap(nmcmc)} x {pstride} float16 exceeds max_history_bytes="
                               f"{self.max_history_bytes}: lower max_rows or raise the limit")
         if self._subs is None or [e.chain0 - self.chain0 for e in self._subs[0]] != bounds[:-1]:
             op = self.op
             engs = [DeviceAMCMC(BatchedMLP(op.arch, op.X, op.Y, device=op.device, dtype=op.dtype), self.sigma, self.gamma,
                                 self.t0, self.tadapt, self.cov_ini, self.seed, self.use_graph, self.max_history_bytes,
                                 self.chain0 + bounds[g], self.fuse_propose, max_rows=self.max_rows,
-                                overlap_hist=self.overlap_hist) for g in range(G)]
+                                overlap_hist=self.overlap_hist, hist_scale0=self.hist_scale0) for g in range(G)]
             self._subs = (engs, [torch.cuda.Stream(device=self.dev) for _ in range(G)])
         engs, streams = self._subs
         chain = torch.empty(C, nmcmc + 1, p, dtype=torch.float64, device=self.dev) if store_chain else None
@@ -195,6 +199,15 @@ class DeviceAMCMC:
         out = {k: torch.cat([r[k] for r in res]) for k in ('mapparams', 'maxpost', 'accrate', 'logpost', 'alphas')}
         out['chain'] = chain
         return out
+
+    @staticmethod
+    def _sum_of_samples(s):
+        """sum over ALL samples so far of (x_i - x0), [C, p] float64: the accept kernel keeps `sumx` = the stays of the states a
+        chain has LEFT (mult x (x - x0), added when it leaves: no per-step pass over the vector); the current state's stay is
+        added here (a handful of elementwise ops, once per adaptation)."""
+        kc = s['kcur'][s['par']].long().clamp_(max=s['mult'].shape[1] - 1)
+        wc = s['mult'].gather(1, kc[:, None]).to(torch.float64)
+        return s['sumx'] + wc * (s['cur'] - s['x0'])
 
     def _kcap(self, nmcmc):
         """Rows of the history buffer: every accepted move of the run if that fits max_rows, else max_rows (which must
@@ -259,15 +272,31 @@ class DeviceAMCMC:
             mult = s['mult'][idx, :kmax] * live
             ncs = mult.sum(dim=1)                                               # [n] int64
             w = mult.to(torch.float32)
-            B = s['hist'][idx, :kmax, :p]                                       # [n, kmax, p] (a copy: advanced indexing)
-            B.masked_fill_(~live[:, :, None], 0.0)                              # (rows beyond a chain's k are uninitialised memory)
-            mc = torch.bmm(w[:, None, :], B)[:, 0, :] / ncs[:, None].to(torch.float32)
-            B -= mc[:, None, :]
-            B *= w.sqrt()[:, :, None]                                           # (rows beyond a chain's k: weight 0)
+            sw = w.sqrt()                                                       # [n, kmax] (rows beyond a chain's k: weight 0)
+            S_old = s['hscale'][idx]                                            # [n] float64
+            inv_s = (1.0 / S_old).to(torch.float32)
+            # mean of the compressed states about the chain's reference point: exactly, from the float64 sum of the stays the
+            # chain has left (rows 0 .. k-1 ARE those states)
+            mc = (s['sumx'][idx] / ncs[:, None].double()).to(torch.float32)     # [n, p]
             gen = torch.Generator(device=dev)
             gen.manual_seed((self.seed * 1000003 + (self.chain0 + grp[0]) * 7919 + int(step)) & (2 ** 62 - 1))   # sketch keyed by (seed, chain, step)
-            # (the sketch on the bf16 matrix cores was A/B-tested: 12.4 -> 11.3 ms per 8 chains, and the low-rank test lost variance)
-            Y = B @ torch.randn(p, r, dtype=torch.float32, device=dev, generator=gen)          # [n, kmax, r]
+            Om = torch.randn(p, r, dtype=torch.float32, device=dev, generator=gen).to(torch.float16)
+            # Y = B Omega with B = diag(sqrt w)(H / S - 1 m^T): the big product runs on the STORED float16 rows as they lie in the
+            # history buffer (no [n, kmax, p] float32 copy of the histories: round 3 made six passes over one), float16 operands,
+            # float32 result; the mean term is a rank-one correction.  (Round 3: two float32 GEMMs of 36 GFLOP per chain, 10 of
+            # the 16 ms a window's compressions took.)
+            n = len(grp)
+            Yh = torch.zeros(n, kmax, r, dtype=torch.float32, device=dev)
+            # (row counts rounded up to a multiple of 128 -- a handful of GEMM shapes for the BLAS library to pick kernels for; the
+            # rows in between are free rows of the buffer: zeroed here, weight 0)
+            kr = {c: min(kmax, -(-int(kc_h[c]) // 128) * 128) for c in grp}
+            for q, c in enumerate(grp):
+                kq = int(kc_h[c])
+                s['hist'][c, kq:kr[c]] = 0.0
+                Yh[q, :kr[c]] = torch.mm(s['hist'][c, :kr[c], :p], Om, out_dtype=torch.float32)
+            mom = mc @ Om.float()                                               # [n, r]
+            Y = sw[:, :, None] * (Yh * inv_s[:, None, None] - mom[:, None, :])   # [n, kmax, r]
+            del Yh
             # Q^T = (L2 L1)^-1 Y^T: Cholesky-QR applied twice (the second pass restores the orthonormality the first loses
             # when Y is ill-conditioned: with Q orthonormal to float32 accuracy R^T R can never exceed B^T B)
             Yt = Y.transpose(1, 2)
@@ -279,20 +308,43 @@ class DeviceAMCMC:
                 ok_chol = bool((info == 0).all())
             if ok_chol:
                 Qt = torch.linalg.solve_triangular(L2.to(torch.float32), Qt, upper=False)
-                R = Qt @ B                                                                      # [n, r, p]
             else:
                 # (the float32 Gram matrix: its rounding noise separates the zero eigenvalues of an exactly rank-deficient Y^T Y,
                 # on which the divide-and-conquer solver does not converge)
                 lam, V = torch.linalg.eigh((Yt @ Y).double())                                   # [n, r], [n, r, r]
                 keep = lam > lam[:, -1:] * 1e-10                                                # (rank(B) < r: drop the null directions)
                 scale = torch.where(keep, lam.clamp_min(1e-300).rsqrt(), torch.zeros_like(lam))
-                R = (V * scale[:, None, :]).transpose(1, 2).float() @ (Yt @ B)                  # L^-1/2 V^T (Y^T B)
+                Qt = (V * scale[:, None, :]).transpose(1, 2).float() @ Yt                       # L^-1/2 V^T Y^T
+            # R = Q^T B = (Q^T diag(sqrt w)) H / S - (Q^T sqrt w) m^T: again on the stored rows; the left factor is split into
+            # float16 high and low parts (two products, float32 results): its rounding would otherwise be 2^-11 per entry
+            A = Qt * sw[:, None, :]                                                             # [n, r, kmax]
+            A_hi = A.to(torch.float16)
+            A_lo = (A - A_hi.float()).to(torch.float16)
+            R = torch.empty(n, r, p, dtype=torch.float32, device=dev)
+            for q, c in enumerate(grp):
+                Hq = s['hist'][c, :kr[c], :p]
+                R[q] = torch.mm(A_hi[q, :, :kr[c]], Hq, out_dtype=torch.float32) + torch.mm(A_lo[q, :, :kr[c]], Hq, out_dtype=torch.float32)
+            R *= inv_s[:, None, None]
+            R -= A.sum(dim=2)[:, :, None] * mc[:, None, :]
+            del A, A_hi, A_lo, Qt, Y
             R *= 0.5 ** 0.5
-            cur_rows, cur_mult = s['hist'][idx, ks, :p], s['mult'][idx, ks]                     # (copies)
-            s['hist'][idx, 0:2 * r:2, :p] = mc[:, None, :] + R
-            s['hist'][idx, 1:2 * r:2, :p] = mc[:, None, :] - R
-            s['hist'][idx, 2 * r, :p] = mc
-            s['hist'][idx, 2 * r + 1, :p] = cur_rows
+            cur_mult = s['mult'][idx, ks]                                                       # (a copy)
+            # The chain's reference point moves to the weighted mean of what was compressed, ref' = ref + m_c: the pseudo-states are
+            # +-R_j and 0 about it, the rows of the states to come are (x - ref') -- as small as the posterior spread once the
+            # chain is stationary, which is what keeps float16's 2^-11 relative rounding harmless.  The scale S' puts the largest
+            # pseudo-state entry at ~2^10 (float16 holds up to 65504: room for 64 x that before a row saturates).  The sum of the
+            # stays the chain has left is re-based with it: sum w (x - ref') = sum w (x - ref) - n_c m_c.
+            rmax = R.abs().amax(dim=(1, 2)).double().clamp_min(1e-300)
+            S_new = torch.exp2(torch.floor(torch.log2(1024.0 / rmax))).clamp_(2.0 ** -40, 2.0 ** 40)
+            mc64 = mc.double()
+            s['x0'][idx] += mc64
+            s['sumx'][idx] -= ncs[:, None].double() * mc64
+            Rs = (R * S_new.to(torch.float32)[:, None, None]).to(torch.float16)
+            s['hist'][idx, 0:2 * r:2, :p] = Rs
+            s['hist'][idx, 1:2 * r:2, :p] = -Rs
+            s['hist'][idx, 2 * r, :p] = 0.0
+            s['hist'][idx, 2 * r + 1, :p] = ((s['cur'][idx] - s['x0'][idx]) * S_new[:, None]).clamp_(-65504.0, 65504.0).to(torch.float16)
+            s['hscale'][idx] = S_new
             s['mult'][idx] = 0
             s['mult'][idx, :2 * r] = 1
             s['mult'][idx, 2 * r] = (ncs - 2 * r).to(s['mult'].dtype)
@@ -314,7 +366,7 @@ class DeviceAMCMC:
         key = (C, kcap, TB, p)
         if getattr(self, '_bufs', None) is not None and self._bufs[0] == key:
             return self._bufs[1], self._bufs[2]
-        coef = torch.empty(C * ((kcap + 3) // 4 * 4 + 1) * TB, dtype=torch.float32, device=dev)
+        coef = torch.empty(int(self._L.qn_mcmc_hist_block_coef_bytes(C, kcap)), dtype=torch.uint8, device=dev)
         # (two increment buffers: the next block's is written while the current one is read)
         delta = torch.empty(2 if self.overlap_hist else 1, C, TB, p, dtype=torch.float64, device=dev)
         self._bufs = (key, coef, delta)
@@ -332,8 +384,10 @@ class DeviceAMCMC:
             gen.manual_seed(1)
             pstride = (p + 3) // 4 * 4
             for n in sorted({1, min(16, max(1, -(-C // 6)))}):
-                fake = {'hist': torch.randn(n, kcap, pstride, dtype=torch.float32, device=dev, generator=gen),
-                        'mult': torch.ones(n, kcap, dtype=torch.int32, device=dev), 'par': 0}
+                fake = {'hist': torch.randn(n, kcap, pstride, dtype=torch.float32, device=dev, generator=gen).to(torch.float16),
+                        'mult': torch.ones(n, kcap, dtype=torch.int32, device=dev), 'par': 0,
+                        'hscale': torch.ones(n, dtype=torch.float64, device=dev), 'x0': torch.zeros(n, p, dtype=torch.float64, device=dev),
+                        'sumx': torch.zeros(n, p, dtype=torch.float64, device=dev), 'cur': torch.zeros(n, p, dtype=torch.float64, device=dev)}
                 for q4 in range(1, 5):                                          # every row-count bucket a compression can meet
                     kf = min(kcap - 2, q4 * max(1, kcap // 4) - 1)
                     if kf <= 2 * r + 1:
@@ -361,8 +415,8 @@ class DeviceAMCMC:
         # history of distinct states: one row per accepted move at most -> nmcmc + 1 rows always suffice; capped at
         # max_rows (thinned when it could fill up before the next adaptation)
         kcap, pstride = self._kcap(nmcmc), (p + 3) // 4 * 4
-        if C * kcap * pstride * 4 > self.max_history_bytes:
-            raise MemoryError(f"state history {C} x {kcap} x {pstride} float32 exceeds max_history_bytes="
+        if C * kcap * pstride * 2 > self.max_history_bytes:
+            raise MemoryError(f"state history {C} x {kcap} x {pstride} float16 exceeds max_history_bytes="
                               f"{self.max_history_bytes}: lower max_rows or raise the limit")
         # per-chain scalars the accept kernel maintains are double-buffered by step parity ([2, C]; slot `par` is current)
         s = {'cur': cur, 'cur_lp': torch.stack([cur_lp, cur_lp]), 'best': cur.clone(),
@@ -372,7 +426,8 @@ class DeviceAMCMC:
              'lps': torch.empty(C, nmcmc + 1, dtype=f64, device=dev),
              'alphas': torch.zeros(C, nmcmc + 1, dtype=f64, device=dev),
              'nacc': torch.zeros(C, dtype=torch.int64, device=dev),
-             'hist': torch.empty(C, kcap, pstride, dtype=torch.float32, device=dev),
+             'hist': torch.empty(C, kcap, pstride, dtype=torch.float16, device=dev),
+             'hscale': torch.full((C,), self.hist_scale0, dtype=f64, device=dev),
              'mult': torch.zeros(C, kcap, dtype=torch.int32, device=dev),
              'kcur': torch.zeros(2, C, dtype=torch.int32, device=dev),
              'sumx': torch.zeros(C, p, dtype=f64, device=dev),
@@ -476,7 +531,7 @@ class DeviceAMCMC:
                 # adaptation (admcmc.py:66-67) = snapshot of the history x_0..x_i: n = i + 1 samples
                 scale = self.gamma * 2.4 ** 2 / p
                 state['snap'] = {'k': (s['kcur'][s['par']] + 1).clone(), 'w': s['mult'].to(torch.float32).sqrt_(),
-                                 'mean': s['sumx'] / (i + 1), 's_lr': float(np.sqrt(scale / i)),
+                                 'mean': self._sum_of_samples(s) / (i + 1), 's_lr': float(np.sqrt(scale / i)),
                                  # dispatch order of the history product: longest history first
                                  'order': torch.argsort(s['kcur'][s['par']], descending=True).to(torch.int32),
                                  's_iso': float(np.sqrt(scale * 1e-8))}
@@ -522,6 +577,7 @@ class DeviceAMCMC:
             i += nrun
             if verbose:
                 print('%d / %d completed, acceptance rate %lg' % (i, nmcmc, float(s['nacc'].double().mean()) / i))
-        self.last_state = s            # (tests / diagnostics: history rows, multiplicities, running sums)
+        s['sumx'] = self._sum_of_samples(s)     # (the run is over: the current state's stay enters the sum)
+        self.last_state = s            # (tests / diagnostics: history rows, multiplicities, sum of all samples)
         return {'chain': s['chain'], 'mapparams': s['best'], 'maxpost': s['best_lp'][s['par']].clone(),
                 'accrate': s['nacc'].double() / max(nmcmc, 1), 'logpost': s['lps'], 'alphas': s['alphas']}

@@ -40,7 +40,7 @@ def _json_lines(text):
 def test_bench_gpus_2_starts_two_ranks(scaling):
     _no_gpu_yet()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", scaling, "--steps", "20",
-                        "--warmup", "2", "--spread", "4"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--warmup", "2", "--regions", "3"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = _json_lines(r.stdout)
     assert len(lines) == 1
@@ -50,6 +50,7 @@ def test_bench_gpus_2_starts_two_ranks(scaling):
     assert d["config"]["chains_rank0"] == (64 if scaling == "weak" else 32)
     assert d["value"] > 0 and d["roofline"]["kernel_ms_min"] <= d["roofline"]["kernel_ms_median"] <= d["roofline"]["kernel_ms_max"]
     assert abs(d["value"] - d["config"]["chains_total"] * 20 / (d["ms_per_step"] * 20e-3)) <= 1e-6 * d["value"]
+    assert d["config"]["timed_regions"] == 3 and len(d["config"]["region_ms_per_step"]) == 3
 
 
 @pytest.mark.parametrize("sampler,gather", [("amcmc", "all"), ("hmc", "all"), ("hmc", "root")])

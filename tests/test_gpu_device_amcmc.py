@@ -83,9 +83,15 @@ def test_sample_space_proposal_kernel_covariance_and_history_tracking():
     full = np.repeat(xk, w, axis=0)
     n = full.shape[0]
     dev = torch.device("cuda")
-    hist1 = np.zeros((kcap, pstride), dtype=np.float32); hist1[:K, :p] = xk - x0
-    hist1[K:] = 1e6                                                          # rows beyond K must not be read
+    # history rows are float16((x_k - x0) * S) (include/quinn_amd.h: qn_mcmc_accept); S = 64 here, the target covariance is that of
+    # the ROUNDED states
+    S = 64.0
+    hist1 = np.zeros((kcap, pstride), dtype=np.float16); hist1[:K, :p] = ((xk - x0) * S).astype(np.float16)
+    xk = x0 + hist1[:K, :p].astype(np.float64) / S
+    full = np.repeat(xk, w, axis=0)
+    hist1[K:] = np.float16(6e4)                                              # rows beyond K must not be read
     hist = torch.as_tensor(hist1, device=dev)[None].expand(C, kcap, pstride).contiguous()
+    hscale = torch.full((C,), S, dtype=torch.float64, device=dev)
     wsn = np.zeros(kcap, dtype=np.float32); wsn[:K] = np.sqrt(w)
     wsnap = torch.as_tensor(wsn, device=dev)[None].expand(C, kcap).contiguous()
     ksnap = torch.full((C,), K, dtype=torch.int32, device=dev)
@@ -95,7 +101,7 @@ def test_sample_space_proposal_kernel_covariance_and_history_tracking():
     out = torch.empty(C, p, dtype=torch.float64, device=dev)
     c = 0.1 * 2.4 ** 2 / p
     _lib.check(L.qn_mcmc_propose_hist(cur.data_ptr(), hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(),
-                                      mean.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p,
+                                      mean.data_ptr(), hscale.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p,
                                       pstride, kcap, 1234, step.data_ptr(), out.data_ptr(), None), "propose_hist")
     torch.cuda.synchronize()
     d = (out - cur).cpu().numpy()
@@ -105,21 +111,21 @@ def test_sample_space_proposal_kernel_covariance_and_history_tracking():
     # a different step counter gives different draws; the same one reproduces them bit for bit
     out2 = torch.empty_like(out)
     _lib.check(L.qn_mcmc_propose_hist(cur.data_ptr(), hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(),
-                                      mean.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p,
+                                      mean.data_ptr(), hscale.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p,
                                       pstride, kcap, 1234, step.data_ptr(), out2.data_ptr(), None), "propose_hist")
     assert torch.equal(out, out2)
     # the block kernel (TB steps per pass over the history): same random numbers per absolute step (float32 accumulation), so its
     # increment for step 17 equals the single-step kernel's up to rounding; and each step's covariance is right
     TB = L.qn_mcmc_hist_block_steps()
-    coef = torch.empty(C * ((kcap + 3) // 4 * 4 + 1) * TB, dtype=torch.float32, device=dev)
+    coef = torch.empty(L.qn_mcmc_hist_block_coef_bytes(C, kcap), dtype=torch.uint8, device=dev)
     delta = torch.empty(C, TB, p, dtype=torch.float64, device=dev)
-    _lib.check(L.qn_mcmc_propose_hist_block(hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(), mean.data_ptr(),
+    _lib.check(L.qn_mcmc_propose_hist_block(hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(), mean.data_ptr(), hscale.data_ptr(),
                                             float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p, pstride, kcap,
                                             1234, 10, None, coef.data_ptr(), delta.data_ptr(), None, None), "propose_hist_block")
     # a dispatch order (any permutation of the chains) does not change the result
     delta_p = torch.empty_like(delta)
     order = torch.randperm(C, device=dev).to(torch.int32)
-    _lib.check(L.qn_mcmc_propose_hist_block(hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(), mean.data_ptr(),
+    _lib.check(L.qn_mcmc_propose_hist_block(hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(), mean.data_ptr(), hscale.data_ptr(),
                                             float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p, pstride, kcap,
                                             1234, 10, None, coef.data_ptr(), delta_p.data_ptr(), order.data_ptr(), None),
                "propose_hist_block")
@@ -133,7 +139,7 @@ def test_sample_space_proposal_kernel_covariance_and_history_tracking():
     for t in range(TB):                                                  # every step of the block against the single-step kernel
         step[0] = 10 + t
         _lib.check(L.qn_mcmc_propose_hist(cur.data_ptr(), hist.data_ptr(), wsnap.data_ptr(), ksnap.data_ptr(),
-                                          mean.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p,
+                                          mean.data_ptr(), hscale.data_ptr(), float(np.sqrt(c / (n - 1))), float(np.sqrt(c * 1e-8)), C, 0, p,
                                           pstride, kcap, 1234, step.data_ptr(), out2.data_ptr(), None), "propose_hist")
         _lib.check(L.qn_mcmc_apply_delta(cur.data_ptr(), delta.data_ptr(), t, float(np.sqrt(c * 1e-8)), C, 0, p, 1234,
                                          step.data_ptr(), out3.data_ptr(), None), "apply_delta")
@@ -174,8 +180,9 @@ def test_history_of_distinct_states_matches_the_chain():
         K = 1 + int(moved.sum())
         assert kcur[c] == K - 1
         idx = np.concatenate([[0], 1 + np.nonzero(moved)[0]])                # first occurrence of each distinct state
-        np.testing.assert_allclose(hist[c, :K, :arch.nparams], (chain[c, idx] - chain[c, 0]).astype(np.float32),
-                                   rtol=0, atol=0)
+        # rows = float16((x_k - x_0) * S), S = hist_scale0 = 256 while the history has not been compressed: bit for bit
+        want = ((chain[c, idx] - chain[c, 0]) * 256.0).astype(np.float32).astype(np.float16)
+        assert np.array_equal(hist[c, :K, :arch.nparams], want)
         runs = np.diff(np.concatenate([idx, [nmcmc + 1]]))
         assert np.array_equal(mult[c, :K], runs) and mult[c, :K].sum() == nmcmc + 1
         np.testing.assert_allclose(sumx[c], (chain[c] - chain[c, 0]).sum(axis=0), rtol=1e-10, atol=1e-10)
@@ -290,21 +297,27 @@ def test_bounded_history_keeps_the_proposal_covariance():
     mult, x0, sumx = s['mult'].cpu().numpy(), s['x0'].cpu().numpy(), s['sumx'].cpu().numpy()
     for c in range(C):
         K = kcur[c] + 1
-        hist = s['hist'][c, :K, :13].cpu().numpy().astype(np.float64)
+        hist = s['hist'][c, :K, :13].cpu().numpy().astype(np.float64) / float(s['hscale'][c])
         assert K <= 256 and mult[c, :K].sum() == nmcmc + 1 and (mult[c, K:] == 0).all() and (mult[c, :K] > 0).all()
-        np.testing.assert_allclose(hist[kcur[c]] + x0[c], chain[c, -1], rtol=1e-6, atol=1e-6)   # current state keeps its row
+        # current state keeps its row (float16 of (x - ref) * S: 2^-11 of its distance from the chain's reference point)
+        np.testing.assert_allclose(hist[kcur[c]], chain[c, -1] - x0[c], rtol=1e-3, atol=1e-3 * np.abs(chain[c, -1] - x0[c]).max())
         mean = sumx[c] / (nmcmc + 1)
         np.testing.assert_allclose(mean + x0[c], chain[c].mean(axis=0), rtol=1e-9, atol=1e-10)
-        np.testing.assert_allclose((mult[c, :K, None] * hist).sum(axis=0) / (nmcmc + 1), mean, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose((mult[c, :K, None] * hist).sum(axis=0) / (nmcmc + 1), mean, rtol=2e-3,
+                                   atol=2e-3 * chain[c].std(axis=0).max())
         d = hist - mean
         cov = (d * mult[c, :K, None]).T @ d / nmcmc
         ref = np.cov(chain[c].T)
         assert np.linalg.norm(cov - ref) <= 0.05 * np.linalg.norm(ref), (c, np.linalg.norm(cov - ref) / np.linalg.norm(ref))
         assert abs(np.trace(cov) - np.trace(ref)) <= 0.05 * np.trace(ref)
-    full = DeviceAMCMC(op, 0.3, max_rows=1 << 20, **kw).run(nmcmc, ini)
-    assert abs(full['accrate'].mean().item() - acc.mean()) < 0.05
-    lo, hi = full['logpost'][:, nmcmc // 2:].mean().item(), r['logpost'][:, nmcmc // 2:].mean().item()
-    assert abs(lo - hi) < 1.0, (lo, hi)
+    # the bounded run behaves like the unbounded one: 24 chains each (the stationary log-posterior level of ONE chain's half run
+    # scatters by ~1.3 between chains: measured 4.85 +- 0.17 over 64 chains for bounded and unbounded alike)
+    ini24 = np.stack([0.3 * np.random.RandomState(700 + c).randn(arch.nparams) for c in range(24)])
+    full = DeviceAMCMC(op, 0.3, max_rows=1 << 20, **kw).run(nmcmc, ini24)
+    bnd = DeviceAMCMC(op, 0.3, max_rows=256, **kw).run(nmcmc, ini24)
+    assert abs(full['accrate'].mean().item() - bnd['accrate'].mean().item()) < 0.05
+    lo, hi = full['logpost'][:, nmcmc // 2:].mean().item(), bnd['logpost'][:, nmcmc // 2:].mean().item()
+    assert abs(lo - hi) < 1.2, (lo, hi)
     with pytest.raises(ValueError):
         DeviceAMCMC(op, 0.3, max_rows=120, **kw).run(nmcmc, ini)             # a compressed history + one window must fit
 
@@ -328,7 +341,7 @@ def test_bounded_history_low_rank_regime():
     assert np.all(r['accrate'].cpu().numpy() * nmcmc + 1 > 512)
     for c in range(C):
         K = kcur[c] + 1
-        hist = s['hist'][c, :K, :321].cpu().numpy().astype(np.float64)
+        hist = s['hist'][c, :K, :321].cpu().numpy().astype(np.float64) / float(s['hscale'][c])
         assert mult[c, :K].sum() == nmcmc + 1
         d = hist - sumx[c] / (nmcmc + 1)
         tr = (mult[c, :K, None] * d * d).sum() / nmcmc

@@ -87,7 +87,7 @@ def test_compute_entry_points_reject_bad_arguments(L):
     assert L.qn_adam_batched(None, one, one, one, one, 2, 5, 0, 1.0, 0.0, 0.9, 0.999, 1e-8, 1, None) != 0
     assert L.qn_mcmc_propose(None, None, 0.0, 0, 0, 5, 1, one, one, None) == EINVAL
     assert L.qn_mcmc_propose(one, None, 0.0, 2, 0, 5, 1, one, one, None) == EINVAL                               # cur without sd
-    assert L.qn_mcmc_propose_hist(one, one, one, one, one, 1.0, 1.0, 2, 0, 5, 5, 4, 1, one, one, None) == EINVAL  # odd pstride
+    assert L.qn_mcmc_propose_hist(one, one, one, one, one, None, 1.0, 1.0, 2, 0, 5, 5, 4, 1, one, one, None) == EINVAL  # odd pstride
     assert L.qn_mcmc_apply_delta(one, one, 64, 1.0, 2, 0, 5, 1, one, one, None) == EINVAL                        # t >= TB
     assert L.qn_mcmc_hist_block_steps() == 64
     assert L.qn_hmc_parts(0) == EINVAL and L.qn_hmc_parts(8513) == 9 and L.qn_hmc_parts(10 ** 7) == 64

@@ -29,7 +29,7 @@ eng.run(20, ini, store_chain=True)                      # warm-up (first launche
 # warm the caching allocator with the run's two large buffers (chain f64, state history f32): a fresh
 # hipMalloc of ~33 GB costs several hundred ms and is not part of the stepping rate
 _a = torch.empty(C, NMCMC + 1, arch.nparams, dtype=torch.float64, device=op.device) if STORE else None
-_b = torch.empty(C, min(NMCMC + 1, MAXROWS), (arch.nparams + 3) // 4 * 4, dtype=torch.float32, device=op.device)
+_b = torch.empty(C, min(NMCMC + 1, MAXROWS), (arch.nparams + 3) // 4 * 4, dtype=torch.float16, device=op.device)
 del _a, _b
 eng.prepare(NMCMC, C)                                  # adapted-phase buffers + first use of the solver paths (set-up, untimed)
 marks = []
@@ -65,6 +65,6 @@ res["accrate_mean"] = float(acc.mean()); res["accrate_min"] = float(acc.min()); 
 lp = r["logpost"]
 res["logpost_start_mean"] = float(lp[:, 0].mean()); res["logpost_end_mean"] = float(lp[:, -1].mean())
 res["peak_mem_GB"] = torch.cuda.max_memory_allocated() / 1e9
-res["history_GB"] = C * min(NMCMC + 1, MAXROWS) * ((arch.nparams + 3) // 4 * 4) * 4 / 1e9
+res["history_GB"] = C * min(NMCMC + 1, MAXROWS) * ((arch.nparams + 3) // 4 * 4) * 2 / 1e9
 res["rows_in_use_end"] = [int(v) + 1 for v in eng.last_state['kcur'][eng.last_state['par']].cpu().numpy()[:8]]
 print(json.dumps(res))
