@@ -258,16 +258,34 @@ def main():
     backend = os.environ.get("QN_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local = 0
+    if local >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank}/{world}: LOCAL_RANK {local} but {torch.cuda.device_count()} GPU(s) visible -- one process per GPU "
+              "(rehearsal of the launch on fewer GPUs: QN_BENCH_BACKEND=gloo, all ranks on cuda:0)", file=sys.stderr, flush=True)
+        sys.exit(3)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cdev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # One process per GPU, started by torchrun (or by this script's parent, before it touched the GPU).  A rank whose RCCL
+        # set-up fails says so in ONE line and exits non-zero: torchrun then ends the other ranks and returns that code; nothing
+        # here restarts or re-execs a process that has initialised the GPU.
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            probe = torch.ones(1, device=cdev, dtype=torch.float64)
+            dist.all_reduce(probe)                               # the first collective creates the communicator: fail here, not mid-run
+            torch.cuda.synchronize(dev)
+            if float(probe.item()) != float(world):
+                raise RuntimeError(f"all_reduce of ones over {world} ranks returned {float(probe.item())}")
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: rank {rank}/{world}: {backend} (RCCL) initialisation failed on cuda:{local}: {type(e).__name__}: "
+                  f"{str(e).splitlines()[0] if str(e) else ''} -- HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, "
+                  f"MASTER_ADDR={os.environ.get('MASTER_ADDR')}, visible GPUs {torch.cuda.device_count()}", file=sys.stderr, flush=True)
+            sys.exit(3)
 
     from quinn_amd.parallel import shard_bounds
     # this rank's chains [lo, hi) of the job's `total`; global chain id c: W[c] = 0.1*RandomState(1000+c).randn(p)

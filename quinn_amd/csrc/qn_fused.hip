@@ -1291,7 +1291,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
     if (!want_grad) {
         fwd_fn kern = pick_fwd(H, a.act, padded_d(a.d), a.o);
         if (uses_i8(d, want_grad)) {
-            kern = qn_fused_i8_kernel(a.d, a.o);
+            kern = qn_fused_i8_kernel(a.d, a.o, a.act);
             lds_bytes = qn_fused_i8_lds_bytes(a.d, nhid);
 #ifdef QN_DEBUG_LDS_PAD
             if (const char* pad = getenv("QN_DEBUG_LDS_PAD")) lds_bytes += (size_t)atoi(pad);     // (occupancy experiments)

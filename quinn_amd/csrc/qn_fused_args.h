@@ -97,7 +97,7 @@ using qn_fwd_fn = void (*)(FusedArgs, const double*, const double*, const double
 int qn_fused_i8_rows_per_iteration();       // data rows one workgroup covers per loop iteration
 bool qn_fused_i8_applies(int H, int nhid, int act, int d, int o);
 size_t qn_fused_i8_lds_bytes(int d, int nhid);
-qn_fwd_fn qn_fused_i8_kernel(int d, int o);
+qn_fwd_fn qn_fused_i8_kernel(int d, int o, int act);
 
 // sliced int8-product forward + backward for 64-wide tanh networks (qn_fused_bwd_i8.hip): grid, partial-sum and gradient-slab
 // conventions of k_fused_bwd_f64<64, NH, 4>; `flags` [B][nsplit]: (chain, split)s that left the fast path (the caller

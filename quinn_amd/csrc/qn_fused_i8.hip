@@ -54,11 +54,16 @@ namespace {
 // one is sliced: the first version fetched the table, the thin pieces and each matrix one after the other -- five memory
 // round trips, most of the ~6.5 us a workgroup spent here (8 % of a cfg2 launch; with 8 chains per launch, where a
 // workgroup has ONE iteration of rows behind its staging, 30 %).
-template <int DP, int LMIN>
+// |v| < 2^20 (and not NaN): the bound on EVERY weight of a relu / identity network (its activations are not bounded by 1: with
+// weights below 2^20, inputs below 2^100 and at most 15 layers no product or 64-term sum can overflow -- 2^(100 + 15 x 26))
+__device__ __forceinline__ bool bounded20(double v) { return (unsigned)(__double2hiint(v) & 0x7fffffff) < 0x41300000u; }
+__device__ __forceinline__ bool bounded100(double v) { return (unsigned)(__double2hiint(v) & 0x7fffffff) < 0x46300000u; }
+
+template <int DP, int LMIN, bool UNB = false>
 __device__ __forceinline__ int stage(double* __restrict__ lds, unsigned char* __restrict__ wq, double* __restrict__ tanh_tab,
                                      const double* __restrict__ Wb, const FusedArgs& a, long long* stamps = nullptr) {
     int bad = 0;
-    auto chk = [&](double v) { bad |= !qn_bounded(v); return v; };
+    auto chk = [&](double v) { bad |= UNB ? !bounded20(v) : !qn_bounded(v); return v; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = a.d, o = a.o, nb = a.has_bias ? 1 : 0;
     const int64_t gb0 = (int64_t)H * d, gHH = gb0 + nb * H;
@@ -179,7 +184,7 @@ __device__ __forceinline__ int stage(double* __restrict__ lds, unsigned char* __
 
 // The wave's 32 rows in plain float64 from the ORIGINAL weights (rare: non-finite / huge weights or inputs).  Lane j
 // owns feature j of one row at a time; the previous layer's activations are broadcast through `scr` (128 doubles).
-template <int DP>
+template <int DP, int ACT = QN_ACT_TANH>
 // (the arguments it needs by value: a reference to the kernel's argument struct would force a copy of the struct into
 // scratch memory at every kernel entry -- 8 MB of writes per launch in the first version)
 __device__ __noinline__ double slow_tile(int Nb, int d, int o, int nhid, int has_bias, const double* __restrict__ lds,
@@ -196,7 +201,8 @@ __device__ __noinline__ double slow_tile(int Nb, int d, int o, int nhid, int has
         const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * Nb + n] : (int64_t)n;
         double z = lds[lb0 + lane];
         for (int k = 0; k < d; ++k) z = fma(lds[lane * DP + k], X[rr * d + k], z);
-        double act = qn_tanh_f64(z);
+        auto actf = [](double v) { return ACT == QN_ACT_TANH ? qn_tanh_f64(v) : ACT == QN_ACT_RELU ? qn_relu<double>(v) : v; };
+        double act = actf(z);
         for (int layer = 1; layer < nhid; ++layer) {
             double* cur = scr + 64 * (layer & 1);
             cur[lane] = act;
@@ -204,7 +210,7 @@ __device__ __noinline__ double slow_tile(int Nb, int d, int o, int nhid, int has
             const double* Wg = Wb + gHH + (int64_t)(layer - 1) * (H * H + nb * H);
             z = nb ? Wg[H * H + lane] : 0.0;
             for (int i = 0; i < H; ++i) z = fma(Wg[lane * H + i], cur[i], z);
-            act = qn_tanh_f64(z);
+            act = actf(z);
         }
         for (int qo = 0; qo < o; ++qo) {
             const double pr = wave_sum(lds[lWl + qo * H + lane] * act) + lds[lbl + qo];      // lane 0 holds the sum
@@ -218,7 +224,12 @@ __device__ __noinline__ double slow_tile(int Nb, int d, int o, int nhid, int has
     return sse;
 }
 
-template <int DP, int LMIN, int OM>
+// ACT = tanh: activations in [-1, 1], sliced with the fixed scale 2^-46 inside each tile's epilogue.  ACT = relu / identity
+// (round 4; the reference's DEFAULT activation is relu, quinn/nns/mlp.py:23): activations are unbounded, so every data row gets
+// its own scale 2^f_n > max_j |a_j(n)| over the layer's 64 features -- a layer's 16 outputs per lane stay float64 until its last
+// tile is done (row maximum in-lane over the 4 tiles, then across the 4 lane groups), are sliced then (slice_rows), and the next
+// layer's integer sums are multiplied by 2^f_n.  Same norm-wise 47-bit bound per row; no tanh table, no tiny-activation rule.
+template <int DP, int LMIN, int OM, int ACT = QN_ACT_TANH>
 __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const double* __restrict__ W,
                                                         const double* __restrict__ X, const double* __restrict__ Y,
                                                         const int32_t* __restrict__ row_idx, double* __restrict__ pred_out,
@@ -226,6 +237,7 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
                                                         double* __restrict__ sse_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NLEV = 2 * (NS - 1) - LMIN + 1;       // levels LMIN .. 10
+    constexpr bool TANH = ACT == QN_ACT_TANH;
     double* lds = reinterpret_cast<double*>(smem);
     const int NH = a.nhid, d = a.d, o = a.o;
     int b, split;
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
 #pragma unroll
             for (int k = 0; k < DP; ++k) {
                 xn[g][k] = k < d ? X[rr * d + k] : 0.0;
-                xbad_n |= !qn_bounded(xn[g][k]);
+                xbad_n |= TANH ? !qn_bounded(xn[g][k]) : !bounded100(xn[g][k]);
             }
 #pragma unroll
             for (int qo = 0; qo < OM; ++qo) yn[g][qo] = qo < o ? Y[rr * o + qo] : 0.0;
@@ -282,12 +294,12 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
     fetch(0);                                                   // (in flight during the staging)
 #ifdef QN_FWD8_STAMPS
     long long sst[4] = {0, 0, 0, 0};
-    const int sbad = stage<DP, LMIN>(lds, wq, tanh_tab, Wb, a, sst);
+    const int sbad = stage<DP, LMIN, !TANH>(lds, wq, tanh_tab, Wb, a, sst);
     sst[3] = __builtin_amdgcn_s_memrealtime();                           // second matrix sliced
     const bool w_bad = block_or(sbad, red + 6);
     const long long rt1 = __builtin_amdgcn_s_memrealtime();
 #else
-    const bool w_bad = block_or(stage<DP, LMIN>(lds, wq, tanh_tab, Wb, a), red + 6);
+    const bool w_bad = block_or(stage<DP, LMIN, !TANH>(lds, wq, tanh_tab, Wb, a), red + 6);
 #endif
     for (int it = 0; it < a.iters; ++it) {
         double xk[G][DP], yk[G][OM];
@@ -305,15 +317,52 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
         const bool exceptional = w_bad || __any(xbad_n);
         if (it + 1 < a.iters) fetch(it + 1);
         if (exceptional) {                                              // wave-uniform
-            sse += slow_tile<DP>(a.Nb, a.d, a.o, a.nhid, a.has_bias, lds, scratch + 128 * wave, Wb, X, Y, row_idx,
+            sse += slow_tile<DP, ACT>(a.Nb, a.d, a.o, a.nhid, a.has_bias, lds, scratch + 128 * wave, Wb, X, Y, row_idx,
                                  split * a.rows_per_split + (it * (WGT / 64) + wave) * 16 * G, b, pred_out);
             continue;
         }
         // ---- first layer (VALU): a_1 = tanh(W0 x + b0), sliced straight into the B operand
         v4i Bc[G][NS];
         int top = 0;                                                    // OR of the layer's top digits (see below)
+        double rs[G];                                                   // relu / identity: 2^f_n, the row scale of the current B operand
+        double Vr[TANH ? 1 : G][TANH ? 1 : T][4];                       // relu / identity: a layer's outputs until its row maximum is known
+        double amax[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+        for (int g = 0; g < G; ++g) { rs[g] = 1.0; amax[g] = 0.0; }
+        // relu / identity: row maximum over the 4 lane groups -> exponent -> digits of the row's 64 activations (B operand)
+        auto slice_rows = [&](int g, v4i (&Bo)[NS]) {
+            if constexpr (!TANH) {
+                double m = amax[g];
+                m = fmax(m, __shfl_xor(m, 16, 64));
+                m = fmax(m, __shfl_xor(m, 32, 64));
+                int E = (__double2hiint(m) >> 20) & 0x7ff;             // |v| < 2^(E - 1022) for every v of the row
+                E = E < 122 ? 122 : E;
+                const double sl = __hiloint2double((2091 - E) << 20, 0);        // 2^(46 - f), f = E - 1022
+                rs[g] = __hiloint2double((E + 1) << 20, 0);                     // 2^f
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    int lo[4], hi[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double x = fma(Vr[g][t][r], sl, kMagic);
+                        lo[r] = __double2loint(x);
+                        hi[r] = __double2hiint(x);
+                    }
+                    const int p01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400), q01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602);
+                    const int p23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400), q23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602);
+                    const int r01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400), r23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400);
+                    Bo[0][t] = __builtin_amdgcn_perm(p23, p01, 0x05040100) ^ 0x80808080;
+                    Bo[1][t] = __builtin_amdgcn_perm(p23, p01, 0x07060302) ^ 0x80808080;
+                    Bo[2][t] = __builtin_amdgcn_perm(q23, q01, 0x05040100) ^ 0x80808080;
+                    Bo[3][t] = __builtin_amdgcn_perm(q23, q01, 0x07060302) ^ 0x80808080;
+                    Bo[4][t] = __builtin_amdgcn_perm(r23, r01, 0x05040100) ^ 0x80808080;
+                    Bo[5][t] = __builtin_amdgcn_perm(r23, r01, 0x07060302);
+                }
+                amax[g] = 0.0;
+            }
+        };
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 double av[4];
@@ -323,20 +372,29 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
                     double z = lds[offb0 + j];
 #pragma unroll
                     for (int k = 0; k < DP; ++k) z = fma(lds[j * DP + k], xk[g][k], z);
-                    av[r] = qn_tanh_f64_tab64(z, tanh_tab);
+                    if constexpr (TANH) av[r] = qn_tanh_f64_tab64(z, tanh_tab);
+                    else {
+                        av[r] = ACT == QN_ACT_RELU ? fmax(z, 0.0) : z;  // (finite here: unbounded weights / inputs took the plain loop)
+                        Vr[g][t][r] = av[r];
+                        amax[g] = fmax(amax[g], fabs(av[r]));
+                    }
                 }
-                int S[NS];
-                slice4(av, S);
+                if constexpr (TANH) {
+                    int S[NS];
+                    slice4(av, S);
 #pragma unroll
-                for (int k = 0; k < NS; ++k) Bc[g][k][t] = S[k];
-                top |= top_digits_large(S[NS - 1]);
+                    for (int k = 0; k < NS; ++k) Bc[g][k][t] = S[k];
+                    top |= top_digits_large(S[NS - 1]);
+                }
             }
+            slice_rows(g, Bc[g]);
+        }
         // Activations are sliced with the FIXED scale 2^-46 (tanh outputs lie in [-1, 1]): absolute error 2^-47, which is a
         // RELATIVE error only as long as a layer's activations are not all tiny.  A layer whose top digit is zero for every
         // activation of the wave's rows (top_digits_large: all |a| < ~2^-4.7, e.g. very small weights without bias) sends
         // the wave's rows through the plain float64 loop instead (slow_tile); otherwise the error stays <= 1.8e-13 of
         // the largest activation.  Costs two instructions per tile.
-        bool redo = !__any(top != 0);
+        bool redo = TANH && !__any(top != 0);
         // ---- hidden -> hidden layers: digit products on the int8 matrix pipe.
         // Software pipeline over the 8 (row group, output tile) items of a layer: the MFMAs of item i + 1 are issued
         // BETWEEN the vector instructions of item i's epilogue (recombine, tanh, digits).  An i8 MFMA costs a
@@ -358,7 +416,8 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
         // NEXT tile dealt out between the stages (scheduling fences keep them there): recombine the levels, scale + bias,
         // tanh (qn_tanh_f64_tab64 written out), then digits (or the last layer's dot product).
         auto epilogue = [&](auto last_tag, auto next_tag, const v4i (&acc)[NLEV], v4i (&accn)[NLEV], const unsigned char* tile_next,
-                            const v4i (&B)[NS], const double* sbt, const double* wlt, int (&S)[NS], double (&prt)[OM]) {
+                            const v4i (&B)[NS], const double* sbt, const double* wlt, int (&S)[NS], double (&prt)[OM], double rsg,
+                            double (&avo)[4]) {
             constexpr bool LAST = decltype(last_tag)::value, NEXT = decltype(next_tag)::value;
             constexpr int NSTAGE = 20;
             v4i Af[NS];
@@ -389,47 +448,59 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
                         break;
                     case 3:
                         if constexpr (NLEV == 7) { const double cv_ = (double)(acc[0][r] + (acc[1][r] << 8)); asm("v_fma_f64 %0, %1, %2, %3" : "=v"(ts[r]) : "v"(ts[r]), "s"(65536.0), "v"(cv_)); }
-                        z[r] = fma(ts[r], sc[r].x, sc[r].y);
+                        if constexpr (TANH) z[r] = fma(ts[r], sc[r].x, sc[r].y);
+                        else z[r] = fma(ts[r] * rsg, sc[r].x, sc[r].y);       // (x 2^f_n: the row scale of the B operand)
                         break;
                     case 4:
+                        if constexpr (!TANH) { av[r] = ACT == QN_ACT_RELU ? fmax(z[r], 0.0) : z[r]; break; }
                         asm("v_min_f64 %0, |%1|, %2" : "=v"(ax[r]) : "v"(z[r]), "s"(20.0));
                         // (one v_fma_f64 with the addend in an opaque register pair: for a known constant hipcc emits v_fmac_f64
                         // behind moves that re-materialise it -- 142 vector instructions fewer per 16 rows, +0.9 % A/B in one call)
                         asm("v_fma_f64 %0, %1, %2, %3" : "=v"(zm[r]) : "v"(ax[r]), "s"(64.0), "v"(magic52));
                         break;
                     case 5:
+                        if constexpr (!TANH) break;
                         Tt[r] = tanh_tab[__double2loint(zm[r])];
                         { const double nf_ = zm[r] - magic52; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(bb[r]) : "v"(nf_), "s"(-0.015625), "v"(ax[r])); }
                         break;
                     case 6:
+                        if constexpr (!TANH) break;
                         b2[r] = bb[r] * bb[r];
                         break;
                     case 7:
+                        if constexpr (!TANH) break;
                         pp[r] = fma(b2[r], 1.33333333333333333e-01, -3.33333333333333333e-01);
                         b2[r] = bb[r] * b2[r];
                         break;
                     case 8:
+                        if constexpr (!TANH) break;
                         tb[r] = fma(b2[r], pp[r], bb[r]);
                         break;
                     // (qn_tanh_f64_tab64 of qn_math.h, reciprocal-free tail: T + (1 - T^2) tb (1 - e)(1 + e^2 + e^4), e = T tb)
                     case 9:
+                        if constexpr (!TANH) break;
                         num[r] = Tt[r] * tb[r];                       // e
                         den[r] = fma(-Tt[r], Tt[r], 1.0);             // 1 - T^2
                         break;
                     case 10:
+                        if constexpr (!TANH) break;
                         e0[r] = num[r] * num[r];                      // e^2
                         y0[r] = fma(-tb[r], num[r], tb[r]);           // tb (1 - e)
                         break;
                     case 11:
+                        if constexpr (!TANH) break;
                         e0[r] = fma(e0[r], e0[r], e0[r]);             // e^2 + e^4
                         break;
                     case 12:
+                        if constexpr (!TANH) break;
                         y0[r] = fma(y0[r], e0[r], y0[r]);             // u
                         break;
                     case 13:
+                        if constexpr (!TANH) break;
                         num[r] = fma(den[r], y0[r], Tt[r]);
                         break;
                     case 14:
+                        if constexpr (!TANH) break;
                         av[r] = __builtin_copysign(num[r], z[r]);
                         break;
 
@@ -438,18 +509,20 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
 #pragma unroll
                             for (int qo = 0; qo < OM; ++qo)
                                 if (qo < o) prt[qo] = fma(wlt[qo * H + r], av[r], prt[qo]);
-                        } else {
+                        } else if constexpr (TANH) {
                             double x;
                             asm("v_fma_f64 %0, %1, %2, %3" : "=v"(x) : "v"(av[r]), "s"(0x1p46), "v"(magicS));
                             lo[r] = __double2loint(x);
                             hi[r] = __double2hiint(x);
+                        } else {
+                            avo[r] = av[r];
                         }
                         break;
                     default: break;
                     }
                 }
                 if (st == 0 && NEXT) load_frags(Af, tile_next);          // (no product before stage 2: the reads are in flight)
-                if constexpr (!LAST) {
+                if constexpr (!LAST && TANH) {
                     if (st == 16) {
                         p01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400); q01 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602);
                         p23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400); q23 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602);
@@ -493,31 +566,40 @@ __global__ __launch_bounds__(WGT, 2) void k_fused_fwd_i8(FusedArgs a, const doub
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     int S[NS];
+                    double avo[4];
                     const unsigned char* nxt = plane + (t + 1) * 16 * H;
                     if (t == T - 1) {
-                        if (t & 1) epilogue(last_tag, std::false_type{}, accB, accA, nxt, Bc[g], sb + 32 * t, wl + 16 * t, S, part[g]);
-                        else epilogue(last_tag, std::false_type{}, accA, accB, nxt, Bc[g], sb + 32 * t, wl + 16 * t, S, part[g]);
+                        if (t & 1) epilogue(last_tag, std::false_type{}, accB, accA, nxt, Bc[g], sb + 32 * t, wl + 16 * t, S, part[g], rs[g], avo);
+                        else epilogue(last_tag, std::false_type{}, accA, accB, nxt, Bc[g], sb + 32 * t, wl + 16 * t, S, part[g], rs[g], avo);
                     } else {
-                        if (t & 1) epilogue(last_tag, std::true_type{}, accB, accA, nxt, Bc[g], sb + 32 * t, wl + 16 * t, S, part[g]);
-                        else epilogue(last_tag, std::true_type{}, accA, accB, nxt, Bc[g], sb + 32 * t, wl + 16 * t, S, part[g]);
+                        if (t & 1) epilogue(last_tag, std::true_type{}, accB, accA, nxt, Bc[g], sb + 32 * t, wl + 16 * t, S, part[g], rs[g], avo);
+                        else epilogue(last_tag, std::true_type{}, accA, accB, nxt, Bc[g], sb + 32 * t, wl + 16 * t, S, part[g], rs[g], avo);
                     }
-                    if constexpr (!LAST) {
+                    if constexpr (!LAST && TANH) {
 #pragma unroll
                         for (int k = 0; k < NS; ++k) Bn[k][t] = S[k];
                     }
+                    if constexpr (!LAST && !TANH) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            Vr[g][t][r] = avo[r];
+                            amax[g] = fmax(amax[g], fabs(avo[r]));
+                        }
+                    }
                 }
-                if constexpr (!LAST) {
+                if constexpr (!LAST && TANH) {
 #pragma unroll
                     for (int k = 0; k < NS; ++k) Bc[g][k] = Bn[k];
                     topl |= (top_digits_large(Bn[NS - 1][0]) | top_digits_large(Bn[NS - 1][1])) | (top_digits_large(Bn[NS - 1][2]) | top_digits_large(Bn[NS - 1][3]));
                 }
+                if constexpr (!LAST && !TANH) slice_rows(g, Bc[g]);   // (the layer's products are done: its B operand may be overwritten)
             }
-            if constexpr (!LAST) redo |= !__any(topl != 0);
+            if constexpr (!LAST && TANH) redo |= !__any(topl != 0);
         };
         for (int layer = 1; layer < NH - 1; ++layer) hidden_layer(std::false_type{}, layer);
         hidden_layer(std::true_type{}, NH - 1);
         if (redo) {                                                     // wave-uniform; rare
-            sse += slow_tile<DP>(a.Nb, a.d, a.o, a.nhid, a.has_bias, lds, scratch + 128 * wave, Wb, X, Y, row_idx,
+            sse += slow_tile<DP, ACT>(a.Nb, a.d, a.o, a.nhid, a.has_bias, lds, scratch + 128 * wave, Wb, X, Y, row_idx,
                                  split * a.rows_per_split + (it * (WGT / 64) + wave) * 16 * G, b, pred_out);
             continue;
         }
@@ -562,19 +644,24 @@ int qn_fused_i8_rows_per_iteration() { return (WGT / 64) * 16 * G; }
 bool qn_fused_i8_applies(int Hh, int nhid, int act, int d, int o) {
     // (1..4 outputs: the 4-output instance took ~170 spilled registers in round 2; with the shorter tanh tail and the
     // constants out of the way it fits -- 216 registers, no scratch)
-    if (Hh != H || act != QN_ACT_TANH || nhid < 2 || d > 4 || o < 1 || o > OMAX) return false;
+    if (Hh != H || (act != QN_ACT_TANH && act != QN_ACT_RELU && act != QN_ACT_IDENTITY) || nhid < 2 || d > 4 || o < 1 || o > OMAX) return false;
+#ifdef QN_I8_TANH_ONLY
+    if (act != QN_ACT_TANH) return false;                      // A/B builds: relu / identity on the float64-MFMA kernel
+#endif
+    if (act != QN_ACT_TANH && nhid > 15) return false;         // (the overflow bound of the unbounded activations: stage())
     return qn_fused_i8_lds_bytes(d, nhid) <= 160 * 1024;
 }
 size_t qn_fused_i8_lds_bytes(int d, int nhid) {
     const int dp = d <= 2 ? 2 : 4;
     return sizeof(double) * (size_t)head_doubles(dp, nhid) + (size_t)(nhid - 1) * LAYER_BYTES;
 }
-qn_fwd_fn qn_fused_i8_kernel(int d, int o) {
-#ifndef QN_I8_LMIN
-#define QN_I8_LMIN 4
-#endif
-    if (o > 1) return d <= 2 ? k_fused_fwd_i8<2, QN_I8_LMIN, OMAX> : k_fused_fwd_i8<4, QN_I8_LMIN, OMAX>;
-    return d <= 2 ? k_fused_fwd_i8<2, QN_I8_LMIN, 1> : k_fused_fwd_i8<4, QN_I8_LMIN, 1>;
+template <int ACT>
+static qn_fwd_fn pick_i8(int d, int o) {
+    if (o > 1) return d <= 2 ? k_fused_fwd_i8<2, QN_I8_LMIN, OMAX, ACT> : k_fused_fwd_i8<4, QN_I8_LMIN, OMAX, ACT>;
+    return d <= 2 ? k_fused_fwd_i8<2, QN_I8_LMIN, 1, ACT> : k_fused_fwd_i8<4, QN_I8_LMIN, 1, ACT>;
+}
+qn_fwd_fn qn_fused_i8_kernel(int d, int o, int act) {
+    return act == QN_ACT_RELU ? pick_i8<QN_ACT_RELU>(d, o) : act == QN_ACT_IDENTITY ? pick_i8<QN_ACT_IDENTITY>(d, o) : pick_i8<QN_ACT_TANH>(d, o);
 }
 
 // =====================================================================================================================

@@ -53,6 +53,25 @@ def test_bench_gpus_2_starts_two_ranks(scaling):
     assert d["config"]["timed_regions"] == 3 and len(d["config"]["region_ms_per_step"]) == 3
 
 
+def test_bench_rank_without_a_gpu_of_its_own_exits_with_one_clear_line():
+    """Two RCCL ranks on a one-GPU box (launched as the driver launches them, no gloo rehearsal): the rank that has no GPU says
+    so in one line and exits non-zero, torchrun ends the other one and returns a non-zero code; nothing hangs or restarts."""
+    _no_gpu_yet()
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one GPU")
+    from quinn_amd.parallel import free_port
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("QN_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stderr.splitlines() if ln.startswith("bench.py: rank")]
+    assert len(lines) >= 1 and "GPU(s) visible" in lines[0], r.stderr[-2000:]
+    assert not _json_lines(r.stdout)
+
+
 @pytest.mark.parametrize("sampler,gather", [("amcmc", "all"), ("hmc", "all"), ("hmc", "root")])
 def test_device_engine_two_ranks_equal_one_process(sampler, gather):
     _no_gpu_yet()

@@ -1,4 +1,5 @@
-"""GPU: the sliced int8-product forward for 64-wide tanh networks (csrc/qn_fused_i8.hip) against the oracle, against the
+"""GPU: the sliced int8-product forward for 64-wide tanh / relu / identity networks (csrc/qn_fused_i8.hip; relu is the
+reference's default activation, quinn/nns/mlp.py:23, its activations sliced with one scale per data row) against the oracle, against the
 float64-MFMA fused kernel (QN_PATH_FUSED_DP) and against the layer-wise kernels: float64 tolerance 1e-11 (measured
 ~1e-14), exceptional weights / inputs through its plain-float64 tile path, and an AMCMC chain whose acceptance
 indices do not depend on which of the kernels evaluated the log-posterior."""
@@ -35,14 +36,17 @@ def _both(op, fn):
                                              ((3, 64, 64, 64, 64, 2), 257, 3, 0.3), ((4, 64, 64, 4), 64, 2, 3.0),
                                              ((2, 64, 64, 64, 1), 1000, 9, 1e-3), ((1, 50, 50, 50, 1), 333, 4, 0.2)],
                          ids=["cfg2", "2hid", "4hid_d3_o2", "d4_o4_bigw", "tinyw", "padded50"])
-def test_matches_oracle_and_float64_kernels(dims, N, B, wscale):
+@pytest.mark.parametrize("act", ["tanh", "relu", "identity"])
+def test_matches_oracle_and_float64_kernels(dims, N, B, wscale, act):
     x, y = _data(N, dims[0], dims[-1])
-    arch = MLPArch(dims, "tanh")
+    arch = MLPArch(dims, act)
     rs = np.random.RandomState(sum(dims) + N)
+    if act != "tanh":
+        wscale = min(wscale, 0.3)                                       # (unbounded activations: keep the outputs O(1) .. O(1e3))
     W = wscale * rs.randn(B, arch.nparams)
     W[0, : arch.nparams // 3] *= 1e-6                                   # rows with very different scales in one chain
     op = BatchedMLP(arch, x, y)
-    assert op.path(B, N, False) == _lib.PATH_FUSED
+    assert op.path(B, N, False) == _lib.PATH_FUSED and op.arith(B, N, False) == _lib.ARITH_I8_FUSED
     (s8, p8), (sd, pd), (sg, pg) = _both(op, lambda: tuple(t.cpu().numpy() for t in op.sse_pred(W)))
     np.testing.assert_allclose(s8, sd, rtol=1e-11)
     np.testing.assert_allclose(s8, sg, rtol=1e-11)
@@ -50,7 +54,7 @@ def test_matches_oracle_and_float64_kernels(dims, N, B, wscale):
     assert np.abs(p8 - pg).max() <= 1e-11 * scale and np.abs(p8 - pd).max() <= 1e-11 * scale
     # parts (what the device samplers consume) sum to the same SSE
     np.testing.assert_allclose(op.sse_parts(W).cpu().numpy().sum(axis=1), s8, rtol=1e-13)
-    mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, "tanh"))
+    mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, act))
     yd = [v for v in y]
     for b in range(min(B, 3)):
         ref = mlp_ref.logpost(mod, W[b], x, yd, 0.02)
@@ -61,10 +65,11 @@ def test_matches_oracle_and_float64_kernels(dims, N, B, wscale):
 
 
 @pytest.mark.parametrize("o", [1, 2])
-def test_row_subsets_and_ragged_tail(o):
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_row_subsets_and_ragged_tail(o, act):
     dims = (2, 64, 64, 64, o)
     x, y = _data(777, 2, o, seed=3)
-    arch = MLPArch(dims, "tanh")
+    arch = MLPArch(dims, act)
     rs = np.random.RandomState(5)
     W = 0.2 * rs.randn(6, arch.nparams)
     idx = rs.randint(0, 777, size=(6, 403))
@@ -79,9 +84,10 @@ def test_row_subsets_and_ragged_tail(o):
 
 @pytest.mark.parametrize("where", ["weight_nan", "weight_inf", "weight_huge", "bias_nan", "x_nan", "x_inf", "y_nan", "w0_inf"])
 @pytest.mark.parametrize("o", [1, 3])                                   # (o > 1: the 4-output instance of the int8-slice kernel)
-def test_exceptional_values_follow_the_layerwise_kernels(where, o):
+@pytest.mark.parametrize("act", ["tanh", "relu", "identity"])
+def test_exceptional_values_follow_the_layerwise_kernels(where, o, act):
     dims = (1, 64, 64, 64, o)
-    arch = MLPArch(dims, "tanh")
+    arch = MLPArch(dims, act)
     x, y = _data(200, 1, o, seed=1)
     rs = np.random.RandomState(2)
     W = 0.2 * rs.randn(3, arch.nparams)
