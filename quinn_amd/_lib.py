@@ -33,40 +33,49 @@ class QuinnAmdError(RuntimeError):
 def build(force=False, verbose=False, jobs=None):
     """Compile the HIP sources for gfx950 into quinn_amd/lib/libquinn_amd.so (hipcc
     cross-compiles without a GPU).  One object per source under quinn_amd/lib/obj/, compiled in
-    parallel and only when the source or a header is newer than its object; then one link."""
+    parallel and only when the source or a header is newer than its object; then one link.
+    With QN_HIPCC_FLAGS set (A/B builds, -DQN_...) objects and library go to their OWN directory / file name, keyed by the
+    flags (quinn_amd/lib/obj_<key>/, libquinn_amd_<key>.so; select the result with QUINN_AMD_LIB): a flagged build never
+    replaces or poisons the default library.  Concurrent callers (ranks, pytest-xdist) are serialised by a file lock."""
+    import fcntl
+    import hashlib
     from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     hdrs = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + \
            [os.path.join(_HERE, "..", "include", "quinn_amd.h")]
     hnew = max(os.path.getmtime(h) for h in hdrs)
-    if not force and os.path.exists(LIBPATH):
-        if os.path.getmtime(LIBPATH) >= max(hnew, max(os.path.getmtime(s) for s in srcs)):
-            return LIBPATH
-    objdir = os.path.join(LIBDIR, "obj")
-    os.makedirs(objdir, exist_ok=True)
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has one unified register file);
-    # without it hipcc copies every loop-carried accumulator VGPR<->AGPR per iteration (25 % of the GEMM loop)
-    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC"]
     extra = os.environ.get("QN_HIPCC_FLAGS", "").split()          # A/B builds (-DQN_...)
+    key = hashlib.sha1(" ".join(extra).encode()).hexdigest()[:10] if extra else ""
+    libpath = os.path.join(LIBDIR, f"libquinn_amd_{key}.so") if extra else LIBPATH
+    objdir = os.path.join(LIBDIR, f"obj_{key}" if extra else "obj")
+    os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and os.path.exists(libpath):
+            if os.path.getmtime(libpath) >= max(hnew, max(os.path.getmtime(s) for s in srcs)):
+                return libpath
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has one unified register file);
+        # without it hipcc copies every loop-carried accumulator VGPR<->AGPR per iteration (25 % of the GEMM loop)
+        flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC"]
 
-    def one(src):
-        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        if not force and not extra and os.path.exists(obj) and os.path.getmtime(obj) >= max(hnew, os.path.getmtime(src)):
+        def one(src):
+            obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+            if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(hnew, os.path.getmtime(src)):
+                return obj
+            cmd = [hipcc] + flags + extra + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
             return obj
-        cmd = [hipcc] + flags + extra + ["-c", src, "-o", obj]
+
+        with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+            objs = list(ex.map(one, srcs))
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", libpath] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        return obj
-
-    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(one, srcs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIBPATH] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
-    return LIBPATH
+    return libpath
 
 
 _lib = None
