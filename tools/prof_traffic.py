@@ -26,6 +26,6 @@ for kind in ("logpost", "grad"):
     fam = "fused_i8" if any("fwd_i8" in k for k in detail) else "fused_i8_bwd" if any("bwd_i8" in k for k in detail) else \
         ("fused_dp_bwd" if kind == "grad" else "fused_dp")
     res[f"{kind}_f64_{fam}"] = {"hbm_bytes_per_launch": kib * 1024.0, "fetch_kib_raw": tot.get("FETCH_SIZE"),
-                                "write_kib": tot.get("WRITE_SIZE"), "detail_kib": detail, "round": int(os.environ.get("QN_ROUND", "3"))}
+                                "write_kib": tot.get("WRITE_SIZE"), "detail_kib": detail, "round": int(os.environ.get("QN_ROUND", "4"))}
 json.dump(res, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
