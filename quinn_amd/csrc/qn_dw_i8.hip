@@ -68,11 +68,15 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
     // of the chunk: two 16-byte loads per item, each instruction 256 contiguous bytes per feature)
     auto load_block = [&](const double* base, int ch, int q16_, int fl_, double (&v)[4][4]) {
         const int c0 = kbeg + 64 * ch;
-        if (c0 + 64 <= kend && (Nb & 1) == 0) {                          // wave-uniform: a whole chunk of 16-byte aligned rows
+        if (c0 + 64 <= kend) {                                           // wave-uniform: a whole chunk
+            // 16-byte loads at 8-byte aligned addresses: with an ODD row count (an ensemble member's 80 % subset: 13107 rows at
+            // cfg4) every other feature's rows start 8 bytes off a 16-byte boundary; the hardware's unaligned mode serves them.
+            // (Round 3 sent odd row counts through the scalar branch below: 4.3 ms per matrix and 128 members against 3.x here.)
+            typedef double d2u_ __attribute__((ext_vector_type(2), aligned(8)));
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const double2* sp = reinterpret_cast<const double2*>(base + (int64_t)(16 * u + fl_) * Nb + c0 + 2 * q16_);
-                const double2 v01 = sp[0], v23 = sp[16];
+                const d2u_* sp = reinterpret_cast<const d2u_*>(base + (int64_t)(16 * u + fl_) * Nb + c0 + 2 * q16_);
+                const d2u_ v01 = sp[0], v23 = sp[16];
                 v[u][0] = v01.x; v[u][1] = v01.y; v[u][2] = v23.x; v[u][3] = v23.y;
             }
         } else {
