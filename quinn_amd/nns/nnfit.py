@@ -147,9 +147,24 @@ def fit_members(arch, W0, xtrn, ytrn, rows, xval, yval, nepochs, batch_size, lra
             Wc = W if op.tdt == torch.float64 else W.to(op.tdt)
             sse, g = op.sse_grad(Wc, row_idx=idx)
             loss_trn = tail(sse, nb)
-            loss_val = tail(opv.sse(Wc) if opv is not None else op.sse(Wc, row_idx=rows32), nval)
+            # Evaluations the reference makes per update (nnfit.py:133-140): minibatch loss (with gradient), validation loss and --
+            # on an epoch's first minibatch -- the loss over the member's whole training subset.  Two of them coincide in common
+            # settings and are then taken from ONE forward pass: a full-batch step's minibatch IS the training subset (a
+            # permutation of the same rows: equal up to summation order, 1e-16 relative), and without a validation set every
+            # member validates on its training subset (nnfit.py:106-109).  cfg4 (512 members, full batch): 1 of 3 forwards fewer.
+            sse_sub = None                                         # SSE over the member's whole training subset at the current weights
+            if nb == ntrn:
+                sse_sub = sse
+            if opv is not None:
+                loss_val = tail(opv.sse(Wc), nval)
+            else:
+                if sse_sub is None:
+                    sse_sub = op.sse(Wc, row_idx=rows32)
+                loss_val = tail(sse_sub, nval)
             if i == 0:
-                loss_full = tail(op.sse(Wc, row_idx=rows32), ntrn)
+                if sse_sub is None:
+                    sse_sub = op.sse(Wc, row_idx=rows32)
+                loss_full = tail(sse_sub, ntrn)
             gextra = None
             if prior is not None:                                  # NegLogPrior, losses.py:238-256
                 A, sp, cst = prior
