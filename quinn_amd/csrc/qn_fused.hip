@@ -597,7 +597,9 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
                                                          const double* __restrict__ X, const double* __restrict__ Y,
                                                          const int32_t* __restrict__ row_idx,
                                                          double* __restrict__ pred_out, double* __restrict__ partial,
-                                                         double* __restrict__ slab, const int* __restrict__ only_flagged) {
+                                                         double* __restrict__ slab, const int* __restrict__ only_flagged,
+                                                         double* __restrict__ gradW, double* __restrict__ sse_out,
+                                                         unsigned long long* __restrict__ arrive) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     constexpr int T = H / 16;
@@ -612,7 +614,25 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
         // second pass behind k_fused_bwd_i8 (qn_fused_bwd_i8.hip): only chains with a (chain, split) that left its fast path
         int any = 0;
         for (int k = 0; k < a.nsplit; ++k) any |= only_flagged[b * a.nsplit + k];
-        if (!any) return;
+        if (!any) {
+            // (round 4) this pass also is the slab reduction of the gradient (one launch fewer per gradient evaluation: every
+            // kernel boundary costs ~4.4 us of serial time): the chain's nsplit workgroups each sum their share of its elements
+            // over the slabs k_fused_bwd_i8 wrote, in the fixed order of k_grad_reduce; workgroup 0 adds the SSE partials
+            if (gradW) {
+                const int64_t chunk = (a.p + a.nsplit - 1) / a.nsplit, lo = (int64_t)split * chunk, hi = lo + chunk < a.p ? lo + chunk : a.p;
+                for (int64_t e = lo + threadIdx.x; e < hi; e += WG) {
+                    double sacc = 0.0;
+                    for (int k = 0; k < a.nsplit; ++k) sacc += slab[((int64_t)b * a.nsplit + k) * a.p + e];
+                    gradW[(int64_t)b * a.p + e] = sacc;
+                }
+                if (split == 0 && threadIdx.x == 0) {
+                    double sacc = 0.0;
+                    for (int i = 0; i < a.nsplit; ++i) sacc += partial[(int64_t)b * a.nsplit + i];
+                    sse_out[b] = sacc;
+                }
+            }
+            return;
+        }
     }
     const int d = a.d, o = a.o, act_kind = a.act;
     const int nb = a.has_bias ? 1 : 0;
@@ -1076,6 +1096,29 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
         for (int w = 0; w < WG / 64; ++w) sum += red[w];
         partial[(int64_t)b * a.nsplit + split] = sum;
     }
+    if (only_flagged && gradW) {
+        // a FLAGGED chain (rare): its workgroups have just rewritten every split's slab row; the last of them to arrive reduces the
+        // chain.  Agent-scope release / acquire around the arrival (the cost does not matter here).
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) reinterpret_cast<unsigned*>(red)[0] = qn_arrive_tagged(arrive, b);
+        __syncthreads();
+        if (reinterpret_cast<unsigned*>(red)[0] == (unsigned)a.nsplit) {
+            __threadfence();
+            for (int64_t e = tid; e < a.p; e += WG) {
+                double sacc = 0.0;
+                for (int k = 0; k < a.nsplit; ++k)
+                    sacc += __hip_atomic_load(&slab[((int64_t)b * a.nsplit + k) * a.p + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gradW[(int64_t)b * a.p + e] = sacc;
+            }
+            if (tid == 0) {
+                double sacc = 0.0;
+                for (int i = 0; i < a.nsplit; ++i) sacc += __hip_atomic_load(&partial[(int64_t)b * a.nsplit + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sse_out[b] = sacc;
+                __hip_atomic_store(&arrive[b], QN_ARRIVE_MAGIC << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // gradW[b][e] = sum over the nsplit slabs, fixed order; block (0, b) also adds up the chain's SSE partials (left to right, as
@@ -1166,7 +1209,7 @@ size_t lds_need(int H, int d, int o, int nhid, int want_grad) {
 
 using fwd_fn = qn_fwd_fn;
 using bwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*,
-                        double*, const int*);
+                        double*, const int*, double*, double*, unsigned long long*);
 
 // Forward geometry: 4 waves x 2 row groups per workgroup (2 workgroups / CU, 2 waves / SIMD).  The
 // alternative 8 waves x 1 row group (4 waves / SIMD, same 128 rows per iteration) measured 3.5 % slower
@@ -1329,12 +1372,24 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
                                (const double*)Y, row_idx, (double*)pred, partial, slab, flags);
             flagged = flags;
         }
+        // behind k_fused_bwd_i8 the float64 kernel's launch is the flagged chains' recomputation AND the slab reduction of all the
+        // others (one launch instead of two: 221 -> 216 us per cfg2 gradient step); alone it is followed by k_grad_reduce
+#ifdef QN_BWD_SEPARATE_REDUCE
+        const bool merged = false;                                   // A/B builds
+#else
+        const bool merged = flagged != nullptr;
+#endif
+        unsigned long long* arrive =
+            reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + qn_align((size_t)B * a.nsplit * sizeof(double)));
         hipLaunchKernelGGL(kern, grid, dim3(WG), lds_bytes, st, a, (const double*)W, (const double*)X,
-                           (const double*)Y, row_idx, (double*)pred, partial, slab, flagged);
-        int gx = (int)((d->p + 255) / 256);
-        if (gx > 64) gx = 64;
-        hipLaunchKernelGGL(k_grad_reduce, dim3(gx, B), dim3(256), 0, st, slab, a.nsplit, d->p, B, (double*)gradW,
-                           (const double*)partial, sse);
+                           (const double*)Y, row_idx, (double*)pred, partial, slab, flagged, merged ? (double*)gradW : (double*)nullptr,
+                           sse, arrive);
+        if (!merged) {
+            int gx = (int)((d->p + 255) / 256);
+            if (gx > 64) gx = 64;
+            hipLaunchKernelGGL(k_grad_reduce, dim3(gx, B), dim3(256), 0, st, slab, a.nsplit, d->p, B, (double*)gradW,
+                               (const double*)partial, sse);
+        }
     }
     if (!want_grad && partial != sse && !summed) hipLaunchKernelGGL(k_sum_partials, dim3((B + 63) / 64), dim3(64), 0, st, partial, a.nsplit, B, sse);
     QN_HIP_CHECK(hipGetLastError());

@@ -40,6 +40,19 @@ __device__ __forceinline__ bool qn_fused_wg(int nsplit, int B, int* b, int* spli
 //   SLOWER than the separate launch, A/B in one call; this protocol: 1.5-2 us faster than the separate launch.)
 #ifdef __HIPCC__
 constexpr unsigned long long QN_ARRIVE_MAGIC = 0xFFF751A7C0DEull;           // (top 48 bits of a quiet-NaN pattern with a payload)
+// One arrival at the tagged counter arrive[b] (call from ONE lane): returns how many arrivals of the running launch the slot
+// has seen, this one included.  The last arriver resets the slot to {MAGIC, 0} when it is done.
+__device__ __forceinline__ unsigned qn_arrive_tagged(unsigned long long* __restrict__ arrive, int b) {
+    unsigned long long old = __hip_atomic_fetch_add(&arrive[b], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((old >> 16) == QN_ARRIVE_MAGIC) return (unsigned)(old & 0xffff) + 1;
+    // first use of this slot (or bytes of another call): claim it; arrivals that raced with the claim retry against it
+    unsigned long long cur = __hip_atomic_load(&arrive[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const unsigned long long next = (cur >> 16) == QN_ARRIVE_MAGIC ? cur + 1 : ((QN_ARRIVE_MAGIC << 16) | 1ull);
+        if (__hip_atomic_compare_exchange_strong(&arrive[b], &cur, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            return (unsigned)(next & 0xffff);
+    }
+}
 // Called by ALL lanes of the workgroup's first wave (`value`: the workgroup's partial sum, the same in every lane).
 __device__ __forceinline__ void qn_sse_finish(double* __restrict__ partial, unsigned long long* __restrict__ arrive,
                                               double* __restrict__ sse, int b, int split, int nsplit, double value) {
@@ -57,20 +70,7 @@ __device__ __forceinline__ void qn_sse_finish(double* __restrict__ partial, unsi
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        unsigned long long old = __hip_atomic_fetch_add(&arrive[b], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((old >> 16) == QN_ARRIVE_MAGIC) {
-            count = (unsigned)(old & 0xffff) + 1;
-        } else {
-            // first use of this slot (or bytes of another call): claim it; arrivals that raced with the claim retry against it
-            unsigned long long cur = __hip_atomic_load(&arrive[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (;;) {
-                const unsigned long long next = (cur >> 16) == QN_ARRIVE_MAGIC ? cur + 1 : ((QN_ARRIVE_MAGIC << 16) | 1ull);
-                if (__hip_atomic_compare_exchange_strong(&arrive[b], &cur, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    count = (unsigned)(next & 0xffff);
-                    break;
-                }
-            }
-        }
+        count = qn_arrive_tagged(arrive, b);
     }
     count = (unsigned)__builtin_amdgcn_readfirstlane((int)count);
     if (count != (unsigned)nsplit) return;
