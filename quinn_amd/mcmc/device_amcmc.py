@@ -334,7 +334,7 @@ class DeviceAMCMC:
             # chain is stationary, which is what keeps float16's 2^-11 relative rounding harmless.  The scale S' puts the largest
             # pseudo-state entry at ~2^10 (float16 holds up to 65504: room for 64 x that before a row saturates).  The sum of the
             # stays the chain has left is re-based with it: sum w (x - ref') = sum w (x - ref) - n_c m_c.
-            rmax = R.abs().amax(dim=(1, 2)).double().clamp_min(1e-300)
+            rmax = R.abs().amax(dim=2).amax(dim=1).double().clamp_min(1e-300)      # (two stages: the fused (1, 2) reduction took 0.65 ms)
             S_new = torch.exp2(torch.floor(torch.log2(1024.0 / rmax))).clamp_(2.0 ** -40, 2.0 ** 40)
             mc64 = mc.double()
             s['x0'][idx] += mc64
