@@ -1366,7 +1366,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
             // sliced int8 products (qn_fused_bwd_i8.hip); (chain, split)s outside its contract are flagged and their chains
             // recomputed by the float64 kernel right behind it (which returns at once for every other chain)
             int* flags = reinterpret_cast<int*>(static_cast<char*>(ws) + npart + nslab);
-            qn_bwd_i8_fn k8 = qn_fused_bwd_i8_kernel(nhid, a.d);
+            qn_bwd_i8_fn k8 = qn_fused_bwd_i8_kernel(nhid, a.d, a.act);
             if (int rc = arm_lds(reinterpret_cast<const void*>(k8))) return rc;
             hipLaunchKernelGGL(k8, grid, dim3(WG), qn_fused_bwd_i8_lds_bytes(nhid, a.d), st, a, (const double*)W, (const double*)X,
                                (const double*)Y, row_idx, (double*)pred, partial, slab, flags);

@@ -105,7 +105,7 @@ qn_fwd_fn qn_fused_i8_kernel(int d, int o, int act);
 using qn_bwd_i8_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*, double*, int*);
 bool qn_fused_bwd_i8_applies(int H, int nhid, int act, int d, int o);
 size_t qn_fused_bwd_i8_lds_bytes(int nhid, int d);
-qn_bwd_i8_fn qn_fused_bwd_i8_kernel(int nhid, int d);
+qn_bwd_i8_fn qn_fused_bwd_i8_kernel(int nhid, int d, int act);
 
 // layer-wise int8-slice forward for wide tanh networks (qn_fused_i8.hip); used by qn_generic.hip
 struct qn_desc;

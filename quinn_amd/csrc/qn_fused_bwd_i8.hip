@@ -208,11 +208,15 @@ __device__ __forceinline__ void quad_xpose_n(const int (&x)[N], int (&out)[N], i
 
 // Stage chain `Wb`: thin layers as float64, every hidden matrix as digit planes of W (one scale per row) and of W^T (one
 // scale per column).  Returns whether this thread saw a weight outside the fast path's contract.
-template <int NH, int DP, int LMIN>
+// |v| < 2^20 / 2^100 (and not NaN): the bounds on every weight / input of a relu or identity network (qn_fused_i8.hip: stage())
+__device__ __forceinline__ bool bounded20(double v) { return (unsigned)(__double2hiint(v) & 0x7fffffff) < 0x41300000u; }
+__device__ __forceinline__ bool bounded100(double v) { return (unsigned)(__double2hiint(v) & 0x7fffffff) < 0x46300000u; }
+
+template <int NH, int DP, int LMIN, bool UNB = false>
 __device__ __forceinline__ int stage_bwd(double* __restrict__ lds, unsigned char* __restrict__ wq, unsigned char* __restrict__ wqT,
                                          const double* __restrict__ Wb, const FusedArgs& a) {
     int bad = 0;
-    auto chk = [&](double v) { bad |= !qn_bounded(v); return v; };
+    auto chk = [&](double v) { bad |= UNB ? !bounded20(v) : !qn_bounded(v); return v; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = a.d, nb = a.has_bias ? 1 : 0;
     const int64_t gb0 = (int64_t)H * d, gHH = gb0 + nb * H;
@@ -301,7 +305,12 @@ __device__ __forceinline__ int stage_bwd(double* __restrict__ lds, unsigned char
 }
 
 // DD = number of inputs (1..4; the LDS image of W0 is 2 columns wide for DD <= 2, 4 otherwise)
-template <int NH, int DD, int LMIN>
+// ACT = relu / identity (round 4): the activations are unbounded, so (a) the forward products slice a layer's outputs with one
+// scale per DATA ROW (row maximum over the lane's 16 values, then across the 4 lane groups; the next layer's integer sums are
+// multiplied by it), after the layer's last tile; (b) the weight-gradient products, which contract over the data rows and
+// cannot carry a per-row scale, slice the same float64 activations a second time with one scale for the workgroup's 64 rows
+// (their exponent maximum travels through LDS with the dZ exponent, same barrier); (c) the derivative is a select.
+template <int NH, int DD, int LMIN, int ACT = QN_ACT_TANH>
 __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const double* __restrict__ W, const double* __restrict__ X,
                                                         const double* __restrict__ Y, const int32_t* __restrict__ row_idx,
                                                         double* __restrict__ pred_out, double* __restrict__ partial,
@@ -309,6 +318,7 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN), NM = NH - 1, DP = DD <= 2 ? 2 : 4;
     constexpr bool SHORT_TAB = DP > 2;
+    constexpr bool TANH = ACT == QN_ACT_TANH;
     double* lds = reinterpret_cast<double*>(smem);
     int b, split;
     if (!qn_fused_wg(a.nsplit, a.B, &b, &split)) return;
@@ -343,8 +353,9 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
         yn = Y[rr];
     };
     fetch(0);
-    for (int e = tid; e < (SHORT_TAB ? TANH_TAB_SHORT_N : QN_TANH_TAB64_N); e += BWG) tanh_tab[e] = qn_tanh_table64_g[e];
-    const bool w_bad = block_or(stage_bwd<NH, DP, LMIN>(lds, wq, wqT, Wb, a), red + 6);
+    if constexpr (TANH)
+        for (int e = tid; e < (SHORT_TAB ? TANH_TAB_SHORT_N : QN_TANH_TAB64_N); e += BWG) tanh_tab[e] = qn_tanh_table64_g[e];
+    const bool w_bad = block_or(stage_bwd<NH, DP, LMIN, !TANH>(lds, wq, wqT, Wb, a), red + 6);
     if (w_bad) {                                                        // the float64 kernel recomputes the whole chain
         if (tid == 0) {
             flags[b * a.nsplit + split] = 1;
@@ -409,7 +420,7 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
 #pragma unroll
         for (int k = 0; k < DD; ++k) {
             xk[k] = xn[k];
-            bad_run |= !qn_bounded(xk[k]);
+            bad_run |= TANH ? !qn_bounded(xk[k]) : !bounded100(xk[k]);
         }
         const double yv = yn;
         if (it + 1 < a.iters) fetch(it + 1);
@@ -417,6 +428,28 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
         // ------------------------------------------------------------------ forward
         double act[NH][T][4];
         v4i Bd[NM][NS];
+        double rsrow = 1.0;                                             // relu / identity: 2^f_n, this row's scale of the forward B operand
+        // relu / identity: the row's 64 activations of layer `la` (16 in this lane) -> B operand with the row's own scale
+        auto slice_row = [&](int la) {
+            double m = 0.0;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmax(m, fabs(act[la][t][r]));
+            m = fmax(m, __shfl_xor(m, 16, 64));
+            m = fmax(m, __shfl_xor(m, 32, 64));
+            int E = (__double2hiint(m) >> 20) & 0x7ff;                  // |v| < 2^(E - 1022) for every v of the row
+            E = E < 122 ? 122 : E;
+            const double sl = __hiloint2double((2091 - E) << 20, 0);    // 2^(46 - f), f = E - 1022
+            rsrow = __hiloint2double((E + 1) << 20, 0);                 // 2^f
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                int S[NS];
+                slice4_scaled(act[la][t], sl, magicS, S);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) Bd[la][k][t] = S[k];
+            }
+        };
         {
             int top = 0;
 #pragma unroll
@@ -428,14 +461,20 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
                 for (int k = 0; k < DD; ++k)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) z[r] = fma(lds[(16 * t + 4 * q + r) * DP + k], xk[k], z[r]);
-                tanh_tab64_n<4, SHORT_TAB>(z, act[0][t], tanh_tab, magic52, cm13);
-                int S[NS];
-                slice4_scaled(act[0][t], 0x1p46, magicS, S);
+                if constexpr (TANH) {
+                    tanh_tab64_n<4, SHORT_TAB>(z, act[0][t], tanh_tab, magic52, cm13);
+                    int S[NS];
+                    slice4_scaled(act[0][t], 0x1p46, magicS, S);
 #pragma unroll
-                for (int k = 0; k < NS; ++k) Bd[0][k][t] = S[k];
-                top |= top_digits_large(S[NS - 1]);
+                    for (int k = 0; k < NS; ++k) Bd[0][k][t] = S[k];
+                    top |= top_digits_large(S[NS - 1]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) act[0][t][r] = ACT == QN_ACT_RELU ? fmax(z[r], 0.0) : z[r];
+                }
             }
-            bad_run |= !__any(top != 0);                                // all activations of the wave's rows tiny: see qn_i8_slice.h
+            if constexpr (TANH) bad_run |= !__any(top != 0);            // all activations of the wave's rows tiny: see qn_i8_slice.h
+            else slice_row(0);
         }
         QN_STAMP(1);
         // hidden layers: the products of tile t + 1 are issued BETWEEN the vector instructions of tile t's epilogue (one wave
@@ -459,24 +498,35 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
                     for (int r = 0; r < 4; ++r) sc[r] = *reinterpret_cast<const double2*>(sb + 32 * t + 2 * r);
                     recombine4<NLEV>(accs[t & 1], ts, c65536);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) z[r] = fma(ts[r], sc[r].x, sc[r].y);
-                    tanh_tab64_n<4, SHORT_TAB>(z, act[l][t], tanh_tab, magic52, cm13);
+                    for (int r = 0; r < 4; ++r) z[r] = TANH ? fma(ts[r], sc[r].x, sc[r].y) : fma(ts[r] * rsrow, sc[r].x, sc[r].y);
+                    if constexpr (TANH) {
+                        tanh_tab64_n<4, SHORT_TAB>(z, act[l][t], tanh_tab, magic52, cm13);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) act[l][t][r] = ACT == QN_ACT_RELU ? fmax(z[r], 0.0) : z[r];
+                    }
                     if (l == NM) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) pd = fma(lds[offWl + 16 * t + 4 * q + r], act[l][t][r], pd);
                     }
                 }
-                if (l < NM) {
-                    int S[NS];
-                    slice4_scaled(act[l][t], 0x1p46, magicS, S);
+                if constexpr (TANH) {
+                    if (l < NM) {
+                        int S[NS];
+                        slice4_scaled(act[l][t], 0x1p46, magicS, S);
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) Bd[l][k][t] = S[k];
-                    top |= top_digits_large(S[NS - 1]);
+                        for (int k = 0; k < NS; ++k) Bd[l][k][t] = S[k];
+                        top |= top_digits_large(S[NS - 1]);
+                    }
                 }
-                if (t + 1 < T) interleave_hint<NPROD, QN_BWD8_VPM_FWD>();
+                if (t + 1 < T) interleave_hint<NPROD, TANH ? QN_BWD8_VPM_FWD : 2>();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (l < NM) bad_run |= !__any(top != 0);
+            if constexpr (TANH) {
+                if (l < NM) bad_run |= !__any(top != 0);
+            } else {
+                if (l < NM) slice_row(l);                               // (this layer's products are done: rsrow may change)
+            }
         }
         QN_STAMP(2);
         // ------------------------------------------------------------------ last layer, residual
@@ -500,7 +550,8 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
             for (int r = 0; r < 4; ++r) {
                 const double av = act[NH - 1][t][r];
                 accWl[t][r] = fma(delta, av, accWl[t][r]);
-                dzb[0][t][r] = (lds[offWl + 16 * t + 4 * q + r] * delta) * fma(-av, av, 1.0);
+                dzb[0][t][r] = (lds[offWl + 16 * t + 4 * q + r] * delta) *
+                               (TANH ? fma(-av, av, 1.0) : ACT == QN_ACT_RELU ? (av > 0.0 ? 1.0 : 0.0) : 1.0);
             }
         if (q == 0) accBl += delta;
         QN_STAMP(3);
@@ -516,10 +567,19 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
                 for (int r = 0; r < 4; ++r) ex = max(ex, ((unsigned)__double2hiint(dz[t][r]) & 0x7fffffffu) >> 20);
             ex = wave_max_u32(ex);
             if (lane == 0) gx[wave] = (int)ex;
+            if constexpr (!TANH) {                                      // exponent maximum of the wave's a_l (dW operand: one scale per 64 rows)
+                unsigned exa = 0;
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) exa = max(exa, ((unsigned)__double2hiint(act[l - 1][t][r]) & 0x7fffffffu) >> 20);
+                exa = wave_max_u32(exa);
+                if (lane == 0) gx[4 + wave] = (int)exa;
+            }
             // the transposed digit words of a_l need nothing from the other waves: formed ahead of the barrier (where the
-            // wave would wait anyway), written behind it
+            // wave would wait anyway), written behind it  (tanh; relu / identity slice a_l behind the barrier, with the workgroup's scale)
             int At[NS * T];
-            {
+            if constexpr (TANH) {
                 int Ain[NS * T];
 #pragma unroll
                 for (int k = 0; k < NS; ++k)
@@ -534,6 +594,22 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
             E = E < 122 ? 122 : (E > 1600 ? 1600 : E);
             const double sl = __hiloint2double((2091 - E) << 20, 0);    // 2^(46 - G), G = E - 1022
             const double rs = __hiloint2double((E + 1) << 20, 0);       // 2^G
+            double rsa = 1.0;                                           // relu / identity: 2^Ga, the scale of the dW product's a_l operand
+            if constexpr (!TANH) {
+                int Ea = max(max(gx[4], gx[5]), max(gx[6], gx[7]));
+                Ea = Ea < 122 ? 122 : Ea;
+                const double sla = __hiloint2double((2091 - Ea) << 20, 0);
+                rsa = __hiloint2double((Ea + 1) << 20, 0);
+                int Ain[NS * T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    int S[NS];
+                    slice4_scaled(act[l - 1][t], sla, magicS, S);
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) Ain[k * T + t] = S[k];
+                }
+                quad_xpose_n<NS * T>(Ain, At, selA, selB);
+            }
 #pragma unroll
             for (int k = 0; k < NS; ++k)
 #pragma unroll
@@ -556,7 +632,8 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
             // ---- one pipeline of nine product groups: dW_l (4 column tiles: rows 16 wave .. + 15 of dZ x features of a_l, K = the
             // 64 data rows), db_l (the six products of dZ with the constant top digit of 1.0: row sums), dA = W_l^T dZ (4 tiles);
             // each group's products are issued between the vector instructions of the previous group's epilogue
-            const double sdw = rs * __hiloint2double((1023 + 8 * LMIN - 2 * QB) << 20, 0);      // digits at 2^-46 each, levels in units of 256^LMIN
+            const double sdb = rs * __hiloint2double((1023 + 8 * LMIN - 2 * QB) << 20, 0);      // digits at 2^-46 each, levels in units of 256^LMIN
+            const double sdw = sdb * rsa;                                                       // (the a_l operand's own scale; the row-sum operand "1.0" has none)
             const unsigned char* planeT = wqT + (l - 1) * LAYER_BYTES + lofs;
             const double* sT = lds + offsT + (l - 1) * H + 4 * q;
             v4i Az[NS], accs[2][NLEV], accb[NS];
@@ -581,7 +658,8 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
                 for (int r = 0; r < 4; ++r) g[r] = sT[16 * t + r] * rs;
                 recombine4<NLEV>(acc, ts, c65536);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g[r] *= fma(-act[l - 1][t][r], act[l - 1][t][r], 1.0);
+                for (int r = 0; r < 4; ++r)
+                    g[r] *= TANH ? fma(-act[l - 1][t][r], act[l - 1][t][r], 1.0) : ACT == QN_ACT_RELU ? (act[l - 1][t][r] > 0.0 ? 1.0 : 0.0) : 1.0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     dzn[t][r] = ts[r] * g[r];
@@ -610,7 +688,7 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
                     double ts = (double)(accb[4][r] + (accb[5][r] << 8));
                     ts = fma(ts, 65536.0, (double)(accb[2][r] + (accb[3][r] << 8)));
                     ts = fma(ts, 65536.0, (double)(accb[0][r] + (accb[1][r] << 8)));
-                    dbacc[l - 1][r] = fma(ts, sdw * (double)(1 << (8 * (5 - LMIN))), dbacc[l - 1][r]);
+                    dbacc[l - 1][r] = fma(ts, sdb * (double)(1 << (8 * (5 - LMIN))), dbacc[l - 1][r]);
                     pin(dbacc[l - 1][r]);
                 }
                 interleave_hint<NPROD, 2>();
@@ -715,13 +793,21 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
 
 // ---- what qn_fused.hip needs to dispatch to this kernel
 bool qn_fused_bwd_i8_applies(int Hh, int nhid, int act, int d, int o) {
-    return Hh == H && act == QN_ACT_TANH && (nhid == 2 || nhid == 3) && d >= 1 && d <= 4 && o == 1;
+#ifdef QN_I8_TANH_ONLY
+    if (act != QN_ACT_TANH) return false;                      // A/B builds: relu on the float64-MFMA kernel
+#endif
+    // (identity networks -- linear models -- keep the float64-MFMA kernel: not worth a third set of instances)
+    return Hh == H && (act == QN_ACT_TANH || act == QN_ACT_RELU) && (nhid == 2 || nhid == 3) && d >= 1 && d <= 4 && o == 1;
 }
 size_t qn_fused_bwd_i8_lds_bytes(int nhid, int d) { return bwd_lds_bytes(d <= 2 ? 2 : 4, nhid); }
-qn_bwd_i8_fn qn_fused_bwd_i8_kernel(int nhid, int d) {
-    if (d == 1) return nhid == 2 ? k_fused_bwd_i8<2, 1, QN_I8_LMIN> : k_fused_bwd_i8<3, 1, QN_I8_LMIN>;
-    if (d == 2) return nhid == 2 ? k_fused_bwd_i8<2, 2, QN_I8_LMIN> : k_fused_bwd_i8<3, 2, QN_I8_LMIN>;
-    if (d == 3) return nhid == 2 ? k_fused_bwd_i8<2, 3, QN_I8_LMIN> : k_fused_bwd_i8<3, 3, QN_I8_LMIN>;
-    return nhid == 2 ? k_fused_bwd_i8<2, 4, QN_I8_LMIN> : k_fused_bwd_i8<3, 4, QN_I8_LMIN>;
+template <int ACT>
+static qn_bwd_i8_fn pick_bwd_i8(int nhid, int d) {
+    if (d == 1) return nhid == 2 ? k_fused_bwd_i8<2, 1, QN_I8_LMIN, ACT> : k_fused_bwd_i8<3, 1, QN_I8_LMIN, ACT>;
+    if (d == 2) return nhid == 2 ? k_fused_bwd_i8<2, 2, QN_I8_LMIN, ACT> : k_fused_bwd_i8<3, 2, QN_I8_LMIN, ACT>;
+    if (d == 3) return nhid == 2 ? k_fused_bwd_i8<2, 3, QN_I8_LMIN, ACT> : k_fused_bwd_i8<3, 3, QN_I8_LMIN, ACT>;
+    return nhid == 2 ? k_fused_bwd_i8<2, 4, QN_I8_LMIN, ACT> : k_fused_bwd_i8<3, 4, QN_I8_LMIN, ACT>;
+}
+qn_bwd_i8_fn qn_fused_bwd_i8_kernel(int nhid, int d, int act) {
+    return act == QN_ACT_RELU ? pick_bwd_i8<QN_ACT_RELU>(nhid, d) : pick_bwd_i8<QN_ACT_TANH>(nhid, d);
 }
 static_assert(bwd_lds_bytes(4, 3) <= 160 * 1024 && bwd_lds_bytes(2, 3) <= 160 * 1024, "the LDS image of the three-hidden-layer kernel has to fit a CU");

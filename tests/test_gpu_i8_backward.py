@@ -1,4 +1,4 @@
-"""GPU: the sliced int8-product forward + BACKWARD kernel for 64-wide tanh networks (csrc/qn_fused_bwd_i8.hip; the gradient the
+"""GPU: the sliced int8-product forward + BACKWARD kernel for 64-wide tanh and relu networks (csrc/qn_fused_bwd_i8.hip; the gradient the
 reference gets from autograd, quinn/nns/nnwrap.py:128-150 through quinn/solvers/nn_mcmc.py:73-98) against the oracle, against
 the float64-MFMA fused kernel (QN_PATH_FUSED_DP) and against the layer-wise kernels (QN_PATH_GENERIC): SSE rtol 1e-11,
 gradient 1e-10 of max |g| (measured ~1e-13); chains outside the fast path's contract (flagged, recomputed by the float64 kernel);
@@ -51,12 +51,15 @@ def _three(op, W, row_idx=None):
                                              ((3, 40, 40, 40, 1), 257, 3, 0.7)],
                          ids=["cfg2", "2hid", "d2_bigw", "one_chain", "d2_2hid", "padded50", "many_chains", "d3", "d4_bigw", "d4_2hid",
                               "d3_padded40"])
-def test_gradient_matches_oracle_and_float64_kernels(dims, N, B, wscale):
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_gradient_matches_oracle_and_float64_kernels(dims, N, B, wscale, act):
     x, y = _data(N, dims[0])
-    arch = MLPArch(dims, "tanh")
+    arch = MLPArch(dims, act)
+    if act == "relu":
+        wscale = min(wscale, 0.5)
     W = _weights(arch, B, wscale, sum(dims) + N)
     op = BatchedMLP(arch, x, y)
-    assert op.path(B, N, True) == _lib.PATH_FUSED
+    assert op.path(B, N, True) == _lib.PATH_FUSED and op.arith(B, N, True) == _lib.ARITH_I8_FUSED
     (s8, g8), (sd, gd), (sg, gg) = _three(op, W)
     gmax = np.abs(gg).max(axis=1, keepdims=True)
     np.testing.assert_allclose(s8, sd, rtol=1e-11)
@@ -64,7 +67,7 @@ def test_gradient_matches_oracle_and_float64_kernels(dims, N, B, wscale):
     e8d, e8g, edg = (np.abs(g8 - gd) / gmax).max(), (np.abs(g8 - gg) / gmax).max(), (np.abs(gd - gg) / gmax).max()
     print(f"max |g - g_ref| / max|g|: int8 slices vs f64 MFMA {e8d:.2e}, vs layer-wise {e8g:.2e}; f64 MFMA vs layer-wise {edg:.2e}")
     assert e8d <= 1e-10 and e8g <= 1e-10
-    mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, "tanh"))
+    mod = mlp_ref.build_module(mlp_ref.MLPSpec(dims, act))
     yd = [v for v in y]
     for b in range(min(B, 3)):
         gref = -2.0 * mlp_ref.logpostgrad(mod, W[b], x, yd, 1.0)                     # d SSE / d w
@@ -72,10 +75,11 @@ def test_gradient_matches_oracle_and_float64_kernels(dims, N, B, wscale):
         assert abs(s8[b] / mlp_ref.sse(mod, W[b], x, y) - 1) <= 1e-11
 
 
-def test_row_subsets_ragged_tail_and_determinism():
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_row_subsets_ragged_tail_and_determinism(act):
     dims = (2, 64, 64, 64, 1)
     x, y = _data(777, 2, seed=3)
-    arch = MLPArch(dims, "tanh")
+    arch = MLPArch(dims, act)
     rs = np.random.RandomState(5)
     W = _weights(arch, 6, 0.4, 11)
     idx = rs.randint(0, 777, size=(6, 403))
@@ -89,11 +93,12 @@ def test_row_subsets_ragged_tail_and_determinism():
 
 @pytest.mark.parametrize("where", ["weight_nan", "weight_inf", "weight_huge", "weight_2e25", "bias_nan", "x_nan", "x_inf", "y_nan", "y_huge", "w0_inf", "tiny_weights"])
 @pytest.mark.parametrize("d", [1, 3])                                   # (3 inputs: the 4-column W0 image, the shorter tanh table)
-def test_chains_outside_the_contract_are_recomputed_in_float64(where, d):
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_chains_outside_the_contract_are_recomputed_in_float64(where, d, act):
     """One chain (or the data) breaks the fast path's contract: the flagged chains come from k_fused_bwd_f64 -- NaN / Inf
     pattern and finite values of the layer-wise kernels -- and the OTHER chains' results do not change by a bit."""
     dims = (d, 64, 64, 64, 1)
-    arch = MLPArch(dims, "tanh")
+    arch = MLPArch(dims, act)
     x, y = _data(200, d, seed=1)
     W = _weights(arch, 3, 0.3, 2)
     clean = BatchedMLP(arch, x, y)
