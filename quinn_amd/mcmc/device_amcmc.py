@@ -47,7 +47,7 @@ from ..ops import BatchedMLP
 class DeviceAMCMC:
     def __init__(self, op: BatchedMLP, sigma, gamma=0.1, t0=100, tadapt=1000, cov_ini=None, seed=0,
                  use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=True, groups=1, max_rows=4096,
-                 overlap_hist=True, hist_scale0=256.0):
+                 overlap_hist=True, hist_scale0=256.0, pause_gc=True):
         if op.dtype != "float64":
             raise NotImplementedError("the device AMCMC engine runs the float64 operator")
         self.op, self.sigma = op, float(sigma)
@@ -78,6 +78,10 @@ class DeviceAMCMC:
         # history rows are float16((x - ref) * S): S starts at `hist_scale0` (a power of two; rows saturate at |x - ref| =
         # 65504 / S) with ref = the start, and is re-chosen per chain -- together with ref -- at every compression of its history
         self.hist_scale0 = float(2.0 ** round(np.log2(hist_scale0)))
+        # run() pauses Python's cyclic garbage collector while it enqueues steps (gc.disable / gc.enable are process-wide and not
+        # meant to be toggled from several threads at once): pause_gc=False leaves the collector alone, at the price of an
+        # occasional 30 ms hole in the GPU's queue
+        self.pause_gc = bool(pause_gc)
         self.overlap_hist = bool(overlap_hist) and not os.environ.get("QUINN_AMD_NO_HIST_OVERLAP")
         self._side = None
         self._subs = None
@@ -146,8 +150,9 @@ class DeviceAMCMC:
         second and nothing it allocates per step is cyclic, but a full collection in the middle of a run is a 30 ms hole in
         the GPU's queue -- one 1000-step window at 6.3 k steps/s among windows at 7.7 k.  Restored on the way out.)"""
         import gc
-        was = gc.isenabled()
-        gc.disable()
+        was = self.pause_gc and gc.isenabled()
+        if was:
+            gc.disable()
         try:
             return self._run(nmcmc, param_ini, store_chain, verbose)
         finally:
@@ -415,8 +420,13 @@ class DeviceAMCMC:
         # history of distinct states: one row per accepted move at most -> nmcmc + 1 rows always suffice; capped at
         # max_rows (thinned when it could fill up before the next adaptation)
         kcap, pstride = self._kcap(nmcmc), (p + 3) // 4 * 4
-        if C * kcap * pstride * 2 > self.max_history_bytes:
-            raise MemoryError(f"state history {C} x {kcap} x {pstride} float16 exceeds max_history_bytes="
+        # (a bounded history also needs the compression's working set: per group of <= 16 chains the sketch / factor arrays
+        # [n, kcap, r] float32 x 4 and the compressed rows [n, r, p] float32, and prepare()'s dummy history of one group)
+        n_grp = min(16, max(1, -(-C // 6)))
+        r_cmp = max(8, kcap // 8)
+        extra = (n_grp * (4 * kcap * r_cmp * 4 + r_cmp * p * 4) + n_grp * kcap * pstride * 2) if kcap < nmcmc + 1 else 0
+        if C * kcap * pstride * 2 + extra > self.max_history_bytes:
+            raise MemoryError(f"state history {C} x {kcap} x {pstride} float16 (+ {extra >> 20} MiB of compression work space) exceeds max_history_bytes="
                               f"{self.max_history_bytes}: lower max_rows or raise the limit")
         # per-chain scalars the accept kernel maintains are double-buffered by step parity ([2, C]; slot `par` is current)
         s = {'cur': cur, 'cur_lp': torch.stack([cur_lp, cur_lp]), 'best': cur.clone(),
