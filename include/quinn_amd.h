@@ -97,6 +97,13 @@ int qn_mlp_arith(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
  * from the original weights (slow). */
 int qn_mlp_desc_set_path(qn_desc* desc, int path);
 
+/* The fused kernels give every chain ceil(512 / B) (gradient: 256 / B) workgroups, each summing its share of the data rows;
+ * the per-chain SSE / gradient adds those shares left to right, so its last bits depend on B.  batch > 0: split as a launch
+ * of max(B, batch) chains would -- a set of chains run as several smaller launches (the chain groups of the device samplers,
+ * quinn_amd/mcmc/device_amcmc.py: one group's accept kernel overlaps the other's forward) then reproduces the one-launch
+ * results bit for bit.  0 (default): by the launch's own B.  Returns the previous value. */
+int qn_mlp_desc_set_plan_batch(qn_desc* desc, int batch);
+
 /* sse_out[b] = sum_{n,o} (Y[r(b,n),o] - f_{W[b]}(X[r(b,n),:])[o])^2 for b < B.
  * Replaces the per-weight-vector loop over NN_MCMC.logpost -> NNWrap.calc_loss ->
  * NegLogPost.forward -> MLP.forward (quinn/solvers/nn_mcmc.py:45-71,

@@ -20,7 +20,7 @@ ARITH_PLAIN, ARITH_I8_FUSED, ARITH_I8_WIDE, ARITH_I8_LAYERS = 0, 1, 2, 3
 
 # every symbol include/quinn_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = ["qn_mlp_desc_create", "qn_rnet_desc_create", "qn_rnet_desc_set_uses", "qn_mlp_desc_destroy", "qn_mlp_num_params", "qn_workspace_bytes",
-           "qn_mlp_path", "qn_mlp_arith", "qn_mlp_desc_set_path", "qn_mlp_sse_fwd", "qn_mlp_sse_parts", "qn_mlp_sse_fwd_parts", "qn_mlp_sse_fwdbwd", "qn_vi_sample_kl",
+           "qn_mlp_path", "qn_mlp_arith", "qn_mlp_desc_set_path", "qn_mlp_desc_set_plan_batch", "qn_mlp_sse_fwd", "qn_mlp_sse_parts", "qn_mlp_sse_fwd_parts", "qn_mlp_sse_fwdbwd", "qn_vi_sample_kl",
            "qn_vi_grad", "qn_adam_batched", "qn_mcmc_propose", "qn_mcmc_propose_hist", "qn_mcmc_hist_block_steps", "qn_mcmc_hist_block_coef_bytes", "qn_mcmc_propose_hist_block",
            "qn_mcmc_apply_delta", "qn_mcmc_accept", "qn_mcmc_accept_propose", "qn_hmc_parts", "qn_hmc_begin", "qn_hmc_leap", "qn_hmc_accept", "qn_pred_moments", "qn_debug_tanh", "qn_debug_tanh_finite", "qn_debug_tanh_table", "qn_last_error",
            "qn_version"]
@@ -111,6 +111,8 @@ def lib():
     L.qn_workspace_bytes.restype = sz
     L.qn_mlp_path.argtypes = [vp, i32, i32, i32, i32]
     L.qn_mlp_path.restype = i32
+    L.qn_mlp_desc_set_plan_batch.argtypes = [vp, i32]
+    L.qn_mlp_desc_set_plan_batch.restype = i32
     L.qn_mlp_arith.argtypes = [vp, i32, i32, i32, i32]
     L.qn_mlp_arith.restype = i32
     L.qn_mlp_desc_set_path.argtypes = [vp, i32]

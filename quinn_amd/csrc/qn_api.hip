@@ -27,6 +27,16 @@ extern "C" int qn_mlp_desc_set_path(qn_desc* d, int path) {
     return old;
 }
 
+extern "C" int qn_mlp_desc_set_plan_batch(qn_desc* d, int batch) {
+    if (!d) return QN_EINVAL;
+    const int old = d->plan_batch;
+    if (batch >= 0) {
+        d->plan_batch = batch;
+        if (d->padded) d->padded->plan_batch = batch;
+    }
+    return old;
+}
+
 extern "C" int qn_mlp_desc_create(const int* dims, int ndims, int act, int has_bias, qn_desc** out) {
     if (!dims || !out || ndims < 2 || ndims > QN_MAX_LAYERS + 1) {
         qn_set_error("qn_mlp_desc_create: need 2 <= ndims <= %d", QN_MAX_LAYERS + 1);

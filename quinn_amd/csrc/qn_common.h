@@ -30,6 +30,9 @@ struct qn_desc {
     qn_desc* padded;
     // ---- kernel family forced on this descriptor (qn_mlp_desc_set_path; QN_PATH_AUTO = dispatch by shape)
     int path;
+    // ---- the fused kernels split a chain's rows as a launch of max(B, plan_batch) chains would (qn_mlp_desc_set_plan_batch):
+    // a batch run as several smaller launches then sums every chain's rows in the same order as the whole batch in one
+    int plan_batch;
 };
 enum { QN_KIND_MLP = 0, QN_KIND_RNET = 1 };
 

@@ -1190,7 +1190,8 @@ void plan(const qn_desc* d, int B, int Nb, int want_grad, FusedArgs* a) {
 #endif
     const int target = want_grad || stream ? QN_BWD_TARGET : QN_FWD_TARGET;
     const int max_split = (Nb + rows_it - 1) / rows_it;
-    int nsplit = (target + B - 1) / B;
+    const int Bp = d->plan_batch > B ? d->plan_batch : B;
+    int nsplit = (target + Bp - 1) / Bp;
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
     int rps = (Nb + nsplit - 1) / nsplit;

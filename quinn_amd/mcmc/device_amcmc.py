@@ -46,7 +46,7 @@ from ..ops import BatchedMLP
 
 class DeviceAMCMC:
     def __init__(self, op: BatchedMLP, sigma, gamma=0.1, t0=100, tadapt=1000, cov_ini=None, seed=0,
-                 use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=True, groups=1, max_rows=4096,
+                 use_graph=False, max_history_bytes=64 << 30, chain0=0, fuse_propose=True, groups=None, max_rows=4096,
                  overlap_hist=True, hist_scale0=256.0, pause_gc=True):
         if op.dtype != "float64":
             raise NotImplementedError("the device AMCMC engine runs the float64 operator")
@@ -68,9 +68,12 @@ class DeviceAMCMC:
         self.fuse_propose = bool(fuse_propose)
         self.chain0 = int(chain0)      # global id of this engine's first chain (random streams are keyed by it)
         # groups > 1: the chains are split into that many independent groups, each on its own HIP stream, enqueued
-        # block by block from this one host thread: a group's small kernels (accept, apply-delta, partial sums --
-        # a fifth of a step at cfg2, one workgroup per chain) overlap the other groups' forward kernels
-        self.groups = max(1, int(groups))
+        # block by block from this one host thread: a group's accept / propose kernel (a chain of memory round trips that
+        # leaves the GPU idle: 8.7 of a step's 84 us at cfg2) overlaps the other group's forward kernel.  The groups' launches
+        # split a chain's rows as the launch of all chains would (qn_mlp_desc_set_plan_batch): the chains do not depend on
+        # the number of groups, bit for bit.  None: 2 groups from 32 chains on (measured at cfg2: 11.9 -> 12.4 k steps/s
+        # before the first adaptation; 4 groups are bound by the enqueuing thread), else 1
+        self.groups = None if groups is None else max(1, int(groups))
         # the increments of the NEXT block of TB steps are formed on a second stream while the current block's steps run
         # (they depend on the frozen snapshot and the step numbers only): the history product streams the chains'
         # histories from HBM, the log-posterior kernel is bound by vector issue, and the accept kernels leave most of the
@@ -145,6 +148,11 @@ class DeviceAMCMC:
             s['step'].data_ptr(), s['par'], nparts, self._stream()), "qn_mcmc_accept")
         s['par'] ^= 1              # the kernel read slot `par` of the per-chain scalars / step counter and wrote the other
 
+    def _ngroups(self, C):
+        if self.groups is None:
+            return 2 if C >= 32 and self.cov_ini is None else 1
+        return min(self.groups, C)
+
     def run(self, nmcmc, param_ini, store_chain=True, verbose=False):
         """(The cyclic garbage collector is paused while the steps are enqueued: the enqueuing thread makes ~25 000 launches a
         second and nothing it allocates per step is cyclic, but a full collection in the middle of a run is a 30 ms hole in
@@ -162,7 +170,7 @@ class DeviceAMCMC:
     def _run(self, nmcmc, param_ini, store_chain=True, verbose=False):
         ini = torch.as_tensor(np.asarray(param_ini), dtype=torch.float64, device=self.dev).reshape(-1, self.op.p)
         C, p = ini.shape
-        G = min(self.groups, C)
+        G = self._ngroups(C)
         if G <= 1:
             gen = self._run_gen(nmcmc, ini, store_chain, verbose)
             while True:
@@ -181,7 +189,15 @@ class DeviceAMCMC:
             engs = [DeviceAMCMC(BatchedMLP(op.arch, op.X, op.Y, device=op.device, dtype=op.dtype), self.sigma, self.gamma,
                                 self.t0, self.tadapt, self.cov_ini, self.seed, self.use_graph, self.max_history_bytes,
                                 self.chain0 + bounds[g], self.fuse_propose, max_rows=self.max_rows,
-                                overlap_hist=self.overlap_hist, hist_scale0=self.hist_scale0) for g in range(G)]
+                                overlap_hist=self.overlap_hist, hist_scale0=self.hist_scale0, pause_gc=False)
+                    for g in range(G)]
+            for e in engs:
+                # a group's launches split every chain's rows as the launch of all C chains does: each chain's SSE is summed in
+                # the same order, so the chains are those of groups = 1 bit for bit (include/quinn_amd.h)
+                e.op.set_plan_batch(max(C, op.set_plan_batch(-1)))
+                path = op.set_path(_lib.PATH_AUTO)                            # (the kernel family forced on the parent, if any)
+                op.set_path(path)
+                e.op.set_path(path)
             self._subs = (engs, [torch.cuda.Stream(device=self.dev) for _ in range(G)])
         engs, streams = self._subs
         chain = torch.empty(C, nmcmc + 1, p, dtype=torch.float64, device=self.dev) if store_chain else None
@@ -203,6 +219,7 @@ class DeviceAMCMC:
             main.wait_stream(st)
         out = {k: torch.cat([r[k] for r in res]) for k in ('mapparams', 'maxpost', 'accrate', 'logpost', 'alphas')}
         out['chain'] = chain
+        self.last_state, self.last_states = None, [e.last_state for e in engs]      # (diagnostics: per group)
         return out
 
     @staticmethod

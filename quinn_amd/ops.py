@@ -295,6 +295,11 @@ class BatchedMLP:
         profiling); returns the previous setting.  Per descriptor: other operators are unaffected."""
         return int(self._L.qn_mlp_desc_set_path(self._desc, int(path)))
 
+    def set_plan_batch(self, batch):
+        """Split every chain's rows as a launch of max(B, batch) chains would (qn_mlp_desc_set_plan_batch): a batch evaluated
+        as several smaller launches then gives the one-launch results bit for bit.  Returns the previous setting."""
+        return int(self._L.qn_mlp_desc_set_plan_batch(self._desc, int(batch)))
+
     def use_exact_float64(self):
         """Plain float64 arithmetic for THIS operator: under `PATH_AUTO` the float64 operator of 64 / 128 / 256-wide tanh
         networks runs the sliced int8-product kernels (operands rounded to 2^-47 of their row / activation scale: a

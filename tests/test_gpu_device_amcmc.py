@@ -214,6 +214,41 @@ def test_chains_do_not_depend_on_how_they_are_split():
     assert nochain['chain'] is None and torch.equal(nochain['logpost'], whole['logpost'])
 
 
+def test_chain_groups_on_the_fused_kernels_are_bit_identical():
+    """The fused kernels give a chain ceil(512 / B) workgroups, so a chain's SSE is summed in an order that depends on the
+    launch's B; `qn_mlp_desc_set_plan_batch` makes a group's launch split as the launch of all the chains does.  With it the
+    two groups of `groups=2` (one group's accept kernel overlaps the other's forward: the default at >= 32 chains) follow the
+    chains of one group bit for bit, before and after adaptations -- and so does any subset of a batch, gradient included."""
+    from quinn_amd import _lib
+    from quinn_amd.mcmc.device_amcmc import DeviceAMCMC
+    from quinn_amd.ops import MLPArch, BatchedMLP
+    rs = np.random.RandomState(3)
+    N, C = 2048, 64
+    x = rs.rand(N, 1) * 2 - 1
+    y = np.sin(3 * x) + 0.1 * rs.randn(N, 1)
+    arch = MLPArch((1, 64, 64, 64, 1), "tanh")
+    op = BatchedMLP(arch, x, y)
+    assert op.arith(C) == _lib.ARITH_I8_FUSED
+    W = torch.as_tensor(0.3 * rs.randn(C, arch.nparams), device=op.device)
+    whole, gwhole = op.sse_grad(W)
+    sub = BatchedMLP(arch, x, y)
+    part, gpart = sub.sse_grad(W[:32])
+    assert not torch.equal(part, whole[:32])                       # (16 row shares per chain instead of 8)
+    assert sub.set_plan_batch(C) == 0
+    part, gpart = sub.sse_grad(W[:32])
+    assert torch.equal(part, whole[:32]) and torch.equal(gpart, gwhole[:32])
+    assert torch.equal(sub.sse(W[32:]), op.sse(W)[32:])
+    ini = np.stack([np.random.RandomState(900 + c).rand(arch.nparams) for c in range(C)])
+    kw = dict(gamma=0.05, t0=30, tadapt=60, seed=21)
+    one = DeviceAMCMC(op, 0.1, groups=1, **kw).run(200, ini)
+    two = DeviceAMCMC(op, 0.1, groups=2, **kw).run(200, ini)
+    auto = DeviceAMCMC(op, 0.1, **kw)
+    assert auto._ngroups(C) == 2 and auto._ngroups(8) == 1
+    for k in ('chain', 'logpost', 'alphas', 'accrate', 'mapparams', 'maxpost'):
+        assert torch.equal(one[k], two[k]), k
+    assert (one['accrate'] > 0).all() and (one['accrate'] < 1).all()
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_fused_next_proposal_is_bit_identical(graph):
     """qn_mcmc_accept_propose (next step's proposal written by the accept kernel) uses the same random numbers and

@@ -24,14 +24,18 @@ res["fuse_propose"] = FUSE
 MAXROWS = int(os.environ.get("MAX_ROWS", "4096"))       # bound on the stored history rows per chain (compressed beyond)
 STORE = os.environ.get("STORE_CHAIN", "1" if NMCMC <= 12000 else "0") == "1"     # 64 x 50001 x 8513 doubles do not fit
 res["max_rows"], res["store_chain"] = MAXROWS, STORE
-eng = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=1000, seed=1, use_graph=UG, fuse_propose=FUSE, max_rows=MAXROWS)
+GROUPS = int(os.environ.get("NGROUPS", "0")) or None   # chain groups on their own HIP streams (default: the engine's, 2 at 64 chains)
+eng = DeviceAMCMC(op, 0.02, gamma=0.01, t0=100, tadapt=1000, seed=1, use_graph=UG, fuse_propose=FUSE, max_rows=MAXROWS,
+                  groups=GROUPS)
 eng.run(20, ini, store_chain=True)                      # warm-up (first launches)
 # warm the caching allocator with the run's two large buffers (chain f64, state history f32): a fresh
 # hipMalloc of ~33 GB costs several hundred ms and is not part of the stepping rate
 _a = torch.empty(C, NMCMC + 1, arch.nparams, dtype=torch.float64, device=op.device) if STORE else None
 _b = torch.empty(C, min(NMCMC + 1, MAXROWS), (arch.nparams + 3) // 4 * 4, dtype=torch.float16, device=op.device)
 del _a, _b
-eng.prepare(NMCMC, C)                                  # adapted-phase buffers + first use of the solver paths (set-up, untimed)
+res["groups"] = NG = eng._ngroups(C)
+for e in (eng._subs[0] if NG > 1 else [eng]):          # adapted-phase buffers + first use of the solver paths (set-up, untimed)
+    e.prepare(NMCMC, C // NG)
 marks = []
 
 
@@ -66,5 +70,6 @@ lp = r["logpost"]
 res["logpost_start_mean"] = float(lp[:, 0].mean()); res["logpost_end_mean"] = float(lp[:, -1].mean())
 res["peak_mem_GB"] = torch.cuda.max_memory_allocated() / 1e9
 res["history_GB"] = C * min(NMCMC + 1, MAXROWS) * ((arch.nparams + 3) // 4 * 4) * 2 / 1e9
-res["rows_in_use_end"] = [int(v) + 1 for v in eng.last_state['kcur'][eng.last_state['par']].cpu().numpy()[:8]]
+_ls = eng.last_state or eng.last_states[0]
+res["rows_in_use_end"] = [int(v) + 1 for v in _ls['kcur'][_ls['par']].cpu().numpy()[:8]]
 print(json.dumps(res))
