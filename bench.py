@@ -178,9 +178,9 @@ def extras(op, arch, batches, args):
         rates = []
         for _ in range(3):
             t0 = time.perf_counter()
-            r = eng.run(600, ini, store_chain=True)
+            r = eng.run(900, ini, store_chain=True)                          # (900 < tadapt: initial proposal throughout)
             torch.cuda.synchronize(dev)
-            rates.append(600 / (time.perf_counter() - t0))
+            rates.append(900 / (time.perf_counter() - t0))
         out["amcmc_end_to_end_steps_per_s"] = float(np.median(rates))
         out["amcmc_end_to_end_logpost_evals_per_s"] = float(np.median(rates)) * nloc
         out["amcmc_accrate"] = float(r["accrate"].mean())

@@ -72,7 +72,7 @@ class DeviceAMCMC:
         # leaves the GPU idle: 8.7 of a step's 84 us at cfg2) overlaps the other group's forward kernel.  The groups' launches
         # split a chain's rows as the launch of all chains would (qn_mlp_desc_set_plan_batch): the chains do not depend on
         # the number of groups, bit for bit.  None: 2 groups from 32 chains on (measured at cfg2: 11.9 -> 12.4 k steps/s
-        # before the first adaptation; 4 groups are bound by the enqueuing thread), else 1
+        # before the first adaptation; 4 groups are bound by the enqueuing thread) when the fused kernels run the network, else 1
         self.groups = None if groups is None else max(1, int(groups))
         # the increments of the NEXT block of TB steps are formed on a second stream while the current block's steps run
         # (they depend on the frozen snapshot and the step numbers only): the history product streams the chains'
@@ -150,7 +150,7 @@ class DeviceAMCMC:
 
     def _ngroups(self, C):
         if self.groups is None:
-            return 2 if C >= 32 and self.cov_ini is None else 1
+            return 2 if C >= 32 and self.cov_ini is None and self.op.path(C) == _lib.PATH_FUSED else 1
         return min(self.groups, C)
 
     def run(self, nmcmc, param_ini, store_chain=True, verbose=False):

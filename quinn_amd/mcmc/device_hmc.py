@@ -27,10 +27,18 @@ from ..ops import BatchedMLP
 
 
 class DeviceHMC:
-    def __init__(self, op: BatchedMLP, sigma, epsilon=0.05, L=3, seed=0, chain0=0, use_graph=False):
+    def __init__(self, op: BatchedMLP, sigma, epsilon=0.05, L=3, seed=0, chain0=0, use_graph=False, groups=None):
         self.op, self.sigma, self.epsilon, self.L = op, float(sigma), float(epsilon), int(L)
         if self.L < 1:
             raise ValueError("HMC needs L >= 1 leapfrog steps")
+        # groups > 1: the chains run as that many independent groups on their own HIP streams, enqueued step by step from this
+        # one host thread; a group's gradient launch splits a chain's rows as the launch of all chains would
+        # (qn_mlp_desc_set_plan_batch), so the chains do not depend on the number of groups, bit for bit.  Default 1: unlike the
+        # AMCMC engine's forward (two workgroups per CU, a lone one runs 1.8 x faster) the gradient kernel puts ONE workgroup on a
+        # CU, so a group's launch cannot spread into the CUs the other group's small kernels leave idle -- measured at cfg2:
+        # 1418 -> 1427 steps/s (HMC, L = 3), 4094 -> 4100 (MALA)
+        self.groups = None if groups is None else max(1, int(groups))
+        self._subs = None
         self.dev = op.device
         self.seed = int(seed) & (2 ** 63 - 1)
         self.chain0 = int(chain0)          # global id of this engine's first chain (random streams are keyed by it)
@@ -65,9 +73,59 @@ class DeviceHMC:
             s['nacc'].data_ptr(), s['step'].data_ptr(), s['par'], st), "qn_hmc_accept")
         s['par'] ^= 1
 
+    def _ngroups(self, C):
+        if self.groups is None:
+            return 1
+        return min(self.groups, C)
+
     def run(self, nmcmc, param_ini, store_chain=True, verbose=False):
+        ini = torch.as_tensor(np.asarray(param_ini), dtype=torch.float64, device=self.dev).reshape(-1, self.op.p)
+        C, p = ini.shape
+        G = self._ngroups(C)
+        if G <= 1:
+            gen = self._run_gen(nmcmc, ini, store_chain, verbose)
+            while True:
+                try:
+                    next(gen)
+                except StopIteration as e:
+                    return e.value
+        bounds = [C * g // G for g in range(G + 1)]
+        if self._subs is None or [e.chain0 - self.chain0 for e in self._subs[0]] != bounds[:-1]:
+            op = self.op
+            engs = [DeviceHMC(BatchedMLP(op.arch, op.X, op.Y, device=op.device, dtype=op.dtype), self.sigma, self.epsilon,
+                              self.L, self.seed, self.chain0 + bounds[g], self.use_graph, groups=1) for g in range(G)]
+            for e in engs:
+                e.op.set_plan_batch(max(C, op.set_plan_batch(-1)))
+                path = op.set_path(_lib.PATH_AUTO)                            # (the kernel family forced on the parent, if any)
+                op.set_path(path)
+                e.op.set_path(path)
+            self._subs = (engs, [torch.cuda.Stream(device=self.dev) for _ in range(G)])
+        engs, streams = self._subs
+        chain = torch.empty(C, nmcmc + 1, p, dtype=torch.float64, device=self.dev) if store_chain else None
+        gens = [engs[g]._run_gen(nmcmc, ini[bounds[g]:bounds[g + 1]], store_chain, verbose and g == 0,
+                                 chain_out=None if chain is None else chain[bounds[g]:bounds[g + 1]]) for g in range(G)]
+        main = torch.cuda.current_stream(self.dev)
+        for st in streams:
+            st.wait_stream(main)
+        res, live = [None] * G, list(range(G))
+        while live:
+            for g in list(live):
+                with torch.cuda.stream(streams[g]):
+                    try:
+                        next(gens[g])
+                    except StopIteration as e:
+                        res[g] = e.value
+                        live.remove(g)
+        for st in streams:
+            main.wait_stream(st)
+        out = {k: torch.cat([r[k] for r in res]) for k in ('mapparams', 'maxpost', 'accrate', 'logpost', 'alphas')}
+        out['chain'] = chain
+        return out
+
+    def _run_gen(self, nmcmc, param_ini, store_chain=True, verbose=False, chain_out=None):
+        """The run as a generator: yields after every enqueued step (pair of steps under a graph); nothing is awaited."""
         dev, f64 = self.dev, torch.float64
-        cur = torch.as_tensor(np.asarray(param_ini), dtype=f64, device=dev).clone().reshape(-1, self.op.p)
+        cur = torch.as_tensor(param_ini, dtype=f64, device=dev).clone().reshape(-1, self.op.p)
         C, p = cur.shape
         nk = int(self._L.qn_hmc_parts(p))
         f32op = self.op.tdt != f64
@@ -80,7 +138,8 @@ class DeviceHMC:
              'qc': torch.empty(C, p, dtype=self.op.tdt, device=dev) if f32op else None,
              'g64': torch.empty(C, p, dtype=f64, device=dev) if f32op else None,
              'kcur': torch.empty(C, nk, dtype=f64, device=dev), 'kprop': torch.empty(C, nk, dtype=f64, device=dev),
-             'chain': torch.empty(C, nmcmc + 1, p, dtype=f64, device=dev) if store_chain else None,
+             'chain': (chain_out if chain_out is not None else torch.empty(C, nmcmc + 1, p, dtype=f64, device=dev))
+                      if store_chain else None,
              'lps': torch.empty(C, nmcmc + 1, dtype=f64, device=dev),
              'alphas': torch.zeros(C, nmcmc + 1, dtype=f64, device=dev),
              'nacc': torch.zeros(C, dtype=torch.int64, device=dev),
@@ -104,14 +163,17 @@ class DeviceHMC:
                 self._step(s, nmcmc)
             i += 2                                         # (capture does not run the kernels: replay once for steps 2, 3)
             graph.replay()
+            yield
             while i + 2 <= nmcmc:
                 graph.replay()
                 i += 2
+                yield
                 if verbose and nmcmc >= 10 and i % max(2, (nmcmc // 10) // 2 * 2) == 0:
                     print('%d / %d completed, acceptance rate %lg' % (i, nmcmc, float(s['nacc'].double().mean()) / i))
         while i < nmcmc:
             self._step(s, nmcmc)
             i += 1
+            yield
             if verbose and nmcmc >= 10 and (i + 1) % (nmcmc // 10) == 0:
                 print('%d / %d completed, acceptance rate %lg' % (i + 1, nmcmc, float(s['nacc'].double().mean()) / i))
         return {'chain': s['chain'], 'mapparams': s['best'], 'maxpost': s['best_lp'][s['par']].clone(),

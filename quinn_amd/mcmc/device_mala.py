@@ -19,7 +19,7 @@ from .device_hmc import DeviceHMC
 
 
 class DeviceMALA(DeviceHMC):
-    """Args as `MALA` (epsilon: step size, default 0.05) plus the engine's seed / chain0 / use_graph."""
+    """Args as `MALA` (epsilon: step size, default 0.05) plus the engine's seed / chain0 / use_graph / groups."""
 
-    def __init__(self, op, sigma, epsilon=0.05, seed=0, chain0=0, use_graph=False):
-        super().__init__(op, sigma, epsilon=epsilon, L=1, seed=seed, chain0=chain0, use_graph=use_graph)
+    def __init__(self, op, sigma, epsilon=0.05, seed=0, chain0=0, use_graph=False, groups=None):
+        super().__init__(op, sigma, epsilon=epsilon, L=1, seed=seed, chain0=chain0, use_graph=use_graph, groups=groups)

@@ -121,6 +121,33 @@ def test_chains_do_not_depend_on_how_they_are_split():
     assert 0.3 < whole['accrate'].mean().item() <= 1.0
 
 
+@pytest.mark.parametrize("engine", ["hmc", "mala"])
+def test_chain_groups_on_the_fused_kernels_are_bit_identical(engine):
+    """groups=2: two groups of chains on two HIP streams.  The groups' gradient launches split a chain's rows as the launch of all chains does
+    (qn_mlp_desc_set_plan_batch), so every chain is the one-group chain bit for bit -- on the int8-slice kernels."""
+    from quinn_amd import _lib
+    from quinn_amd.mcmc.device_mala import DeviceMALA
+    rs = np.random.RandomState(4)
+    N, C = 2048, 64
+    x = rs.rand(N, 1) * 2 - 1
+    y = np.sin(3 * x) + 0.1 * rs.randn(N, 1)
+    arch = MLPArch((1, 64, 64, 64, 1), "tanh")
+    op = BatchedMLP(arch, x, y)
+    assert op.arith(C, want_grad=True) == _lib.ARITH_I8_FUSED
+    ini = np.stack([0.3 * np.random.RandomState(60 + c).randn(arch.nparams) for c in range(C)])
+    mk = (lambda g, **kw: DeviceHMC(op, 0.1, epsilon=2e-4, L=3, seed=6, groups=g, **kw)) if engine == "hmc" else \
+         (lambda g, **kw: DeviceMALA(op, 0.1, epsilon=4e-4, seed=6, groups=g, **kw))
+    one = mk(1).run(25, ini)
+    two = mk(2).run(25, ini)
+    assert mk(None)._ngroups(C) == 1
+    for k in ('chain', 'logpost', 'alphas', 'accrate', 'mapparams', 'maxpost'):
+        assert torch.equal(one[k], two[k]), k
+    acc = one['accrate'].mean().item()
+    assert 0.05 < acc < 1.0, acc
+    graph = mk(2, use_graph=True).run(25, ini, store_chain=False)
+    assert graph['chain'] is None and torch.equal(graph['logpost'], one['logpost'])
+
+
 def test_graph_replay_equals_direct_launches_bit_for_bit():
     x, y = _problem(N=64)
     arch = MLPArch((1, 16, 16, 1), "tanh")

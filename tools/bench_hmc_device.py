@@ -17,8 +17,9 @@ def data(N):
     x = rs.rand(N, 1) * 2 * np.pi - np.pi
     return x, 0.02 * rs.randn(N, 1) + np.sin(x)
 
-out = {}
-for name, dims, N, C, L, nsteps in [("cfg2", (1, 64, 64, 64, 1), 4096, 64, 3, 300), ("cfg5", (1, 256, 256, 256, 256, 1), 32768, 256, 10, 2)]:
+NG = int(os.environ.get("NGROUPS", "0")) or None          # chain groups on their own HIP streams (default: the engines')
+out = {"groups": NG}
+for name, dims, N, C, L, nsteps in [("cfg2", (1, 64, 64, 64, 1), 4096, 64, 3, 300), ("cfg5", (1, 256, 256, 256, 256, 1), 32768, 256, 10, 2)][:1 if os.environ.get("CFG2_ONLY") else 2]:
     arch = MLPArch(dims, "tanh")
     x, y = data(N)
     op = BatchedMLP(arch, x, y)
@@ -33,7 +34,7 @@ for name, dims, N, C, L, nsteps in [("cfg2", (1, 64, 64, 64, 1), 4096, 64, 3, 30
             acc = float(DeviceHMC(op, 0.02, epsilon=eps, L=L, seed=1).run(150, ini, store_chain=False)["accrate"].mean())
             if 0.3 < acc < 0.85:
                 break
-    eng = DeviceHMC(op, 0.02, epsilon=eps, L=L, seed=1)
+    eng = DeviceHMC(op, 0.02, epsilon=eps, L=L, seed=1, groups=NG)
     eng.run(60 if name == "cfg2" else 1, ini, store_chain=False)           # (warm-up; cfg2: lets the clock settle as well)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     r = eng.run(nsteps, ini, store_chain=False)
@@ -46,7 +47,7 @@ for name, dims, N, C, L, nsteps in [("cfg2", (1, 64, 64, 64, 1), 4096, 64, 3, 30
             acc = float(DeviceMALA(op, 0.02, epsilon=epm, seed=1).run(300, ini, store_chain=False)["accrate"].mean())
             if 0.3 < acc < 0.85:
                 break
-        em = DeviceMALA(op, 0.02, epsilon=epm, seed=1)
+        em = DeviceMALA(op, 0.02, epsilon=epm, seed=1, groups=NG)
         em.run(60, ini, store_chain=False)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         rm = em.run(3 * nsteps, ini, store_chain=False)
