@@ -607,5 +607,49 @@ def g12():
          eps_loss=np.concatenate(drawn[n_first:]).reshape(S, -1), loss=loss.item(), dmu=dmu, drho=drho, torch_seed=120)
 
 
+def g13():
+    """The reference's DEFAULT activation (quinn/nns/mlp.py:23 `activ='relu'`) on the shapes the build's int8-slice kernels take
+    since round 4 (per-row activation scales, k_fused_fwd_i8<.., relu> / k_fused_bwd_i8<.., relu>): HMC (L = 3), MALA and adaptive
+    Metropolis before its first adaptation on MLP(1,1,(40,40),'relu') (p = 1761: the reference draws every proposal through an SVD
+    of the p x p covariance, ~1 s per step there and minutes at p = 8513; the build runs the 40-wide network as its zero-padded
+    64-wide twin).  Step sizes chosen so that acceptances AND rejections occur."""
+    import contextlib
+    import io
+    d, o, hls, act, N, sigma = 1, 1, (64, 64, 64), "relu", 96, 0.2
+    x, y = data(N, d, o, 0.05, 210)
+    for name, kind, eps, L, nmcmc, seed in [("g13_relu_hmc.npz", "hmc", float(sys.argv[2]) if len(sys.argv) > 2 else 0.004, 3, 80, 21),
+                                            ("g13_relu_mala.npz", "mala", float(sys.argv[3]) if len(sys.argv) > 3 else 0.004, 1, 80, 22),
+                                            ("g13_relu_amcmc.npz", "amcmc", 0.0, 0, 50, 23)]:
+        if len(sys.argv) > 4 and sys.argv[4] not in name:
+            continue
+        torch.manual_seed(seed)
+        if kind == "amcmc":
+            hls, N = (40, 40), 80
+            x, y = data(N, d, o, 0.05, 211)
+        solver = NN_MCMC(MLP(d, o, hls, activ=act), verbose=False)
+        solver.lpinfo = {"model": nn_p, "xd": x, "yd": [yy for yy in y], "ltype": "classical", "lparams": {"sigma": sigma}}
+        ini = 0.2 * (np.random.RandomState(seed + 1000).rand(solver.pdim) - 0.3)
+        np.random.seed(seed)
+        drawn, orig = _record_uniforms()
+        mc = HMC(epsilon=eps, L=L) if kind == "hmc" else MALA(epsilon=eps) if kind == "mala" else \
+            AMCMC(cov_ini=1e-5 * np.eye(solver.pdim), gamma=0.1, t0=100, tadapt=1000)
+        mc.setLogPost(solver.logpost, solver.logpostgrad if kind != "amcmc" else None, lpinfo=solver.lpinfo)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = mc.run(param_ini=ini, nmcmc=nmcmc)
+        finally:
+            np.random.random_sample = orig
+        acc = (res["chain"][1:] != res["chain"][:-1]).any(axis=1)
+        print(name, "acceptance", acc.mean(), flush=True)
+        assert 0.15 < acc.mean() < 0.95, acc.mean()
+        cols = np.arange(0, solver.pdim, 34)[:256]
+        save(name, dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y, sigma=sigma, seed=seed, nmcmc=nmcmc, L=L,
+             epsilon=eps, param_ini=ini, accepted=acc, cols=cols, chain_cols=res["chain"][:, cols], chain_mid=res["chain"][nmcmc // 2],
+             chain_final=res["chain"][-1], logpost=res["logpost"], alphas=res["alphas"], accrate=res["accrate"],
+             mapparams=res["mapparams"], maxpost=res["maxpost"], uniforms=np.array(drawn), gamma=0.1, t0=100, tadapt=1000, cov_ini_diag=1e-5)
+
+
 if __name__ == "__main__" and "g12" in sys.argv[1:]:
     g12()
+if __name__ == "__main__" and "g13" in sys.argv[1:2]:
+    g13()

@@ -34,9 +34,11 @@ def _assert_arith(solver, want, grad):
 
 
 @pytest.mark.parametrize("kernels,arith", ARMS)
-@pytest.mark.parametrize("name", ["g12_hmc_0.npz", "g12_hmc_1.npz", "g12_mala.npz"])
+@pytest.mark.parametrize("name", ["g12_hmc_0.npz", "g12_hmc_1.npz", "g12_mala.npz", "g13_relu_hmc.npz", "g13_relu_mala.npz"])
 def test_g12_gradient_chains_on_3x64(name, kernels, arith):
+    """(g13_relu_*: the reference's default activation; int8 slices with per-row activation scales since round 4)"""
     g = load_golden(name)
+    assert str(g["activ"]) == ("relu" if "relu" in name else "tanh")
     assert tuple(int(v) for v in g["dims"]) == (1, 64, 64, 64, 1)
     solver = NN_MCMC(_net(g), verbose=False, kernels=kernels)
     sampler = "mala" if "mala" in name else "hmc"
@@ -125,6 +127,30 @@ def test_g12_amcmc_on_padded_40_wide(kernels, arith):
     np.testing.assert_allclose(solver.mcmc_results["logpost"][0][:upto], g["logpost"][:upto], rtol=1e-9)
     if upto == n + 1:
         assert solver.mcmc_results["accrate"][0] == float(g["accrate"])
+
+
+@pytest.mark.parametrize("kernels,arith", ARMS)
+def test_g13_relu_amcmc_on_padded_40_wide(kernels, arith):
+    """Adaptive Metropolis before its first adaptation on MLP(1,1,(40,40),'relu') (zero-padded 64-wide twin; relu on the
+    int8-slice forward): cov_ini is a multiple of the identity, so the proposals are host-independent -- acceptance indices
+    bit-exact against the reference's fixture, states bit for bit (they are the proposals), log-posteriors 1e-9."""
+    g = load_golden("g13_relu_amcmc.npz")
+    spec = spec_of(g)
+    assert spec.dims == (1, 40, 40, 1) and str(g["activ"]) == "relu"
+    n = int(g["nmcmc"])
+    solver = NN_MCMC(_net(g), verbose=False, kernels=kernels)
+    solver.fit(g["x"], g["y"], zflag=False, datanoise=float(g["sigma"]), nmcmc=n, sampler='amcmc', param_ini=g["param_ini"],
+               seeds=[int(g["seed"])], sampler_params={'cov_ini': float(g["cov_ini_diag"]) * np.eye(spec.nparams),
+                                                       'gamma': float(g["gamma"]), 't0': int(g["t0"]), 'tadapt': int(g["tadapt"])})
+    _assert_arith(solver, arith, grad=False)
+    chain = solver.samples[0]
+    acc = (chain[1:] != chain[:-1]).any(axis=1)
+    assert 0 < g["accepted"].sum() < n
+    assert np.array_equal(acc, g["accepted"]), np.flatnonzero(acc != g["accepted"])
+    assert solver.mcmc_results["accrate"][0] == float(g["accrate"])
+    np.testing.assert_allclose(chain[:, g["cols"]], g["chain_cols"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(chain[-1], g["chain_final"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(solver.mcmc_results["logpost"][0], g["logpost"], rtol=1e-9)
 
 
 def test_g12_viloss_on_2x128():

@@ -226,11 +226,12 @@ def _check_g12_chain(res, g):
     np.testing.assert_allclose(res["alphas"][fin], g["alphas"][fin], rtol=1e-6, atol=1e-300)
 
 
-@pytest.mark.parametrize("name", ["g12_hmc_0.npz", "g12_hmc_1.npz", "g12_mala.npz"])
+@pytest.mark.parametrize("name", ["g12_hmc_0.npz", "g12_hmc_1.npz", "g12_mala.npz", "g13_relu_hmc.npz", "g13_relu_mala.npz"])
 def test_g12_gradient_chains_3x64_bitwise(name):
+    """(G13: the same on the reference's default activation, relu -- tests/golden/gen_golden.py::g13)"""
     g = load_golden(name)
     spec, lp, lg = _closures(g)
-    assert spec.dims == (1, 64, 64, 64, 1)
+    assert spec.dims == (1, 64, 64, 64, 1) and spec.activ == ("relu" if "relu" in name else "tanh")
     rng = np.random.RandomState(int(g["seed"]))
     prop = mcmc_ref.MalaState(epsilon=float(g["epsilon"])) if "mala" in name else \
         mcmc_ref.HmcState(epsilon=float(g["epsilon"]), L=int(g["L"]))
@@ -267,6 +268,18 @@ def test_g12_amcmc_p1761_adaptation_fires():
         assert np.array_equal(res["chain"][:upto], g["chain"][:upto]) or np.allclose(res["chain"][:upto], g["chain"][:upto], rtol=1e-9, atol=1e-11)
         assert np.array_equal(res["accepted"][:upto - 1], acc[:upto - 1])
         np.testing.assert_allclose(res["logpost"][:upto], g["logpost"][:upto], rtol=1e-12)
+
+
+def test_g13_relu_amcmc_p1761_before_adaptation():
+    """Adaptive Metropolis on MLP(1,1,(40,40),'relu') with cov_ini = 1e-5 I, 50 steps, no adaptation (t0 = 100): bit for bit."""
+    g = load_golden("g13_relu_amcmc.npz")
+    spec, lp, _ = _closures(g)
+    assert spec.dims == (1, 40, 40, 1) and spec.activ == "relu"
+    prop = mcmc_ref.AmcmcState(cov_ini=float(g["cov_ini_diag"]) * np.eye(spec.nparams), gamma=float(g["gamma"]),
+                               t0=int(g["t0"]), tadapt=int(g["tadapt"]))
+    res = mcmc_ref.run_chain(lp, prop, int(g["nmcmc"]), g["param_ini"], np.random.RandomState(int(g["seed"])), record_uniforms=True)
+    assert 0 < res["accepted"].sum() < len(res["accepted"])
+    _check_g12_chain(res, g)
 
 
 def test_g12_viloss_2x128():
