@@ -691,7 +691,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
             if (gemm_layer(d, l)) {
                 GemmArgs g = gargs(l);
                 const int tiles = (g.h_in / 64) * (g.h_out / 64);
-                const int ks = dw_ksplit(B, tiles, Nb, wide_bwd ? QN_DW_I8_TARGET_WGS : 4096);
+                const int ks = dw_ksplit(B, tiles, Nb, wide_bwd && d->act == QN_ACT_TANH ? QN_DW_I8_TARGET_WGS : 4096);
                 // weights and (if any) the bias block behind them: contiguous in the flat layout and in a slab
                 const int64_t nW = (int64_t)g.h_in * g.h_out + (d->has_bias ? g.h_out : 0);
                 g.ksplit = ks;
@@ -702,7 +702,9 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                 bool dw_done = false;
                 if constexpr (std::is_same<T, double>::value) {
 #ifndef QN_NO_I8_DW
-                    if (wide_bwd) {          // (sliced int8 products, qn_dw_i8.hip; K-slabs in whole 64-row chunks)
+                    // (sliced int8 products, qn_dw_i8.hip; K-slabs in whole 64-row chunks.  Its `a` operand is sliced with the
+                    // fixed scale of tanh outputs: relu / identity networks take the float64-MFMA product below)
+                    if (wide_bwd && d->act == QN_ACT_TANH) {
                         const int kc64 = ((Nb + ks - 1) / ks + 63) / 64 * 64;
                         if (int rc = qn_i8_dw(g.h_in, g.h_out, d->has_bias, dz, act[l - 1], B, Nb, dst, g.out_stride_b,
                                               g.out_stride_k, ks, kc64, st))

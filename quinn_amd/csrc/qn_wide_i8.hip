@@ -78,12 +78,19 @@ __device__ __forceinline__ v4i to_acc(v4i v) {
 // The workgroup's rows of one iteration in plain float64 from the ORIGINAL weights (rare: unbounded weights / inputs).
 // A wave takes its 16 rows one at a time, lane j owns features j, j + 64, ...; the previous layer's activations are
 // broadcast through `scr` (2 x h doubles per wave).  Returns the wave's SSE share in lane 0.
+__device__ __forceinline__ double wide_actf(double z, int act) {      // (torch semantics: relu(NaN) = NaN)
+    return act == QN_ACT_TANH ? qn_tanh_f64(z) : act == QN_ACT_RELU ? qn_relu<double>(z) : z;
+}
+// (x times the activation's derivative from the activation's VALUE: qn_act_bwd of qn_math.h -- relu is the SELECT of torch's
+// threshold_backward, a <= 0 ? 0 : x, so that Inf x 0 never forms and a NaN output lets the gradient pass)
+__device__ __forceinline__ double wide_dmul(double x, double av, int act) { return qn_act_bwd<double>(x, av, act); }
 template <int KC>
 __device__ __noinline__ double wide_slow_rows(int Nb, int d, int nhid, int has_bias, int64_t act_stride,
                                               const double* __restrict__ Wb, const double* __restrict__ X,
                                               const double* __restrict__ Y, const int32_t* __restrict__ row_idx, int nbase,
                                               int b, double* __restrict__ scr, double* __restrict__ act0,
-                                              double* __restrict__ dz_last, double* __restrict__ pred_out) {
+                                              double* __restrict__ dz_last, double* __restrict__ pred_out,
+                                              int actk = QN_ACT_TANH) {
     constexpr int HID = 64 * KC;
     const int lane = threadIdx.x & 63, nb = has_bias ? 1 : 0;
     const int64_t gb0 = (int64_t)HID * d, gHH = gb0 + nb * HID, blk = (int64_t)HID * HID + nb * HID;
@@ -97,7 +104,7 @@ __device__ __noinline__ double wide_slow_rows(int Nb, int d, int nhid, int has_b
             const int f = lane + 64 * m;
             double z = nb ? Wb[gb0 + f] : 0.0;
             for (int k = 0; k < d; ++k) z = fma(Wb[(int64_t)f * d + k], X[rr * d + k], z);
-            act[m] = qn_tanh_f64(z);
+            act[m] = wide_actf(z, actk);
             if (act0) act0[((int64_t)b * HID + f) * Nb + n] = act[m];
         }
         for (int layer = 1; layer < nhid; ++layer) {
@@ -111,7 +118,7 @@ __device__ __noinline__ double wide_slow_rows(int Nb, int d, int nhid, int has_b
                 const int f = lane + 64 * m;
                 double z = nb ? Wg[(int64_t)HID * HID + f] : 0.0;
                 for (int i = 0; i < HID; ++i) z = fma(Wg[(int64_t)f * HID + i], cur[i], z);
-                act[m] = qn_tanh_f64(z);
+                act[m] = wide_actf(z, actk);
                 if (act0) act0[layer * act_stride + ((int64_t)b * HID + f) * Nb + n] = act[m];
             }
         }
@@ -536,6 +543,9 @@ __device__ __forceinline__ double to_acc_d(double v) {
 __device__ __forceinline__ bool qn_bounded100(double v) {              // |v| < 2^100 (and not NaN)
     return (unsigned)(__double2hiint(v) & 0x7fffffff) < 0x46300000u;
 }
+__device__ __forceinline__ bool qn_bounded20(double v) {               // |v| < 2^20 (and not NaN)
+    return (unsigned)(__double2hiint(v) & 0x7fffffff) < 0x41300000u;
+}
 // four float64 values times `scale` (a power of two that brings them into (-1, 1) x 2^46) -> six digit words
 __device__ __forceinline__ void slice4s(const double (&a)[4], double scale, int (&S)[NS]) {
     int lo[4], hi[4];
@@ -627,7 +637,7 @@ template <int KC>
 __device__ __noinline__ void wide_slow_bwd_rows(int Nb, int d, int nhid, int has_bias, int64_t act_stride, int64_t dz_stride,
                                                 const double* __restrict__ Wb, int nbase, int b, double* __restrict__ scr,
                                                 const double* __restrict__ act0, const double* __restrict__ dz_last,
-                                                double* __restrict__ dz0, double* __restrict__ dwl_acc) {
+                                                double* __restrict__ dz0, double* __restrict__ dwl_acc, int actk = QN_ACT_TANH) {
     constexpr int HID = 64 * KC;
     const int lane = threadIdx.x & 63, nb = has_bias ? 1 : 0;
     const int64_t gHH = (int64_t)HID * d + nb * HID, blk = (int64_t)HID * HID + nb * HID, gWl = gHH + (int64_t)(nhid - 1) * blk;
@@ -639,7 +649,7 @@ __device__ __noinline__ void wide_slow_bwd_rows(int Nb, int d, int nhid, int has
         for (int m = 0; m < KC; ++m) {
             const int64_t idx = ((int64_t)b * HID + lane + 64 * m) * Nb + n;
             const double av = act0[(nhid - 1) * act_stride + idx];
-            g[m] = (Wb[gWl + lane + 64 * m] * dzl) * (1.0 - av * av);
+            g[m] = wide_dmul(Wb[gWl + lane + 64 * m] * dzl, av, actk);
             dz0[(nhid - 1) * dz_stride + idx] = g[m];
             if (dwl_acc) dwl_acc[lane + 64 * m] = fma(dzl, av, dwl_acc[lane + 64 * m]);
         }
@@ -656,19 +666,24 @@ __device__ __noinline__ void wide_slow_bwd_rows(int Nb, int d, int nhid, int has
                 for (int j = 0; j < HID; ++j) acc = fma(Wg[(int64_t)j * HID + i], cur[j], acc);
                 const int64_t idx = ((int64_t)b * HID + i) * Nb + n;
                 const double av = act0[li * act_stride + idx];
-                g[m] = acc * (1.0 - av * av);
+                g[m] = wide_dmul(acc, av, actk);
                 dz0[li * dz_stride + idx] = g[m];
             }
         }
     }
 }
 
-template <int KC, int DP, int LMIN>
+// TANH = false (round 4): relu / identity networks (`actk`, uniform) -- the derivative is a select on the stashed activation.
+template <int KC, int DP, int LMIN, bool TANH = true>
 __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const double* __restrict__ W, const double* __restrict__ X,
                                                        const int32_t* __restrict__ row_idx, const unsigned char* __restrict__ WdT,
                                                        const double* __restrict__ scT, const int* __restrict__ flags,
                                                        const double* __restrict__ act0, const double* __restrict__ dz_last,
-                                                       double* __restrict__ dz0, double* __restrict__ dump, double* __restrict__ dwl_out) {
+                                                       double* __restrict__ dz0, double* __restrict__ dump, double* __restrict__ dwl_out,
+                                                       int actk) {
+    // derivative of the activation from its value: tanh 1 - a^2; relu (a > 0); identity 1 (dsel: 0 for relu, -inf for identity)
+    const double dsel = actk == QN_ACT_RELU ? 0.0 : -__builtin_inf();
+    auto dact = [&](double av) { return TANH ? fma(-av, av, 1.0) : (av > dsel ? 1.0 : 0.0); };
     constexpr int HID = 64 * KC, TL = 4 * KC, TILE_B = KC * NS * 1024, PLANE = HID * HID, LAYERB = NS * PLANE;
     constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN), NPT = NPROD * KC;
     extern __shared__ __attribute__((aligned(16))) char smemb[];
@@ -762,7 +777,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
         if (exceptional) {
             wide_slow_bwd_rows<KC>(a.Nb, d, NH, a.has_bias, a.act_stride, a.dz_stride, Wb,
                                    split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave, act0, dz_last, dz0,
-                                   fold ? slow_acc + (HID + 8) * wave : nullptr);
+                                   fold ? slow_acc + (HID + 8) * wave : nullptr, TANH ? QN_ACT_TANH : actk);
             // (flat loads / stores in there complete out of order: drain them before the counted vmcnt waits resume)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             continue;
@@ -803,7 +818,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
                         const int T_ = 4 * bi + t;
                         const double av = abuf[bi & 1][4 * t + r];
                         if constexpr (FOLD) dwl[T_][r] = fma(dze, av, dwl[T_][r]);
-                        const double v = (lds[16 * T_ + 4 * q + r] * dzl) * fma(-av, av, 1.0);
+                        const double v = (lds[16 * T_ + 4 * q + r] * dzl) * dact(av);
                         (live ? zp + (int64_t)(16 * T_) * a.Nb : dmp)[(int64_t)r * a.Nb] = v;
                         amax = fmax(amax, fabs(v));
                         V[T_][r] = to_acc_d(v);
@@ -918,7 +933,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
                     } else if constexpr (st < NLEV) {
                         { const double cv_ = (double)acc[NLEV - 1 - st][r]; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(ts[r]) : "v"(ts[r]), "s"(256.0), "v"(cv_)); }
                     } else if constexpr (st == NLEV) {
-                        g[r] = fma(-ac[r], ac[r], 1.0) * rs;
+                        g[r] = dact(ac[r]) * rs;
                     } else if constexpr (st == NLEV + 1) {
                         v[r] = (ts[r] * sct[16 * Tt_ + r]) * g[r];
                     } else {
@@ -980,6 +995,292 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
     }
 }
 
+// =====================================================================================================================
+// FORWARD for relu / identity networks (round 4; the reference's DEFAULT activation is relu, quinn/nns/mlp.py:23).
+// Their activations are not bounded by 1, so -- as for the gradients dZ of k_i8_wide_bwd, whose organisation this kernel
+// shares -- every data row n gets its own scale 2^f_n > max_j |a_l[j, n]| per layer: a layer's outputs stay float64 in
+// AccVGPRs (h/4 values per lane) until its last tile is done (row maximum in-lane over the tiles, then across the 4 lane
+// groups), are sliced then, and the next layer's integer sums are multiplied by 2^f_n.  No tanh table, no tiny-activation
+// rule (the row maximum itself sets the scale).  Chains with a weight or bias >= 2^20 and rows with an input >= 2^100 take the
+// plain float64 loop: below those bounds no product or sum overflows for up to 15 layers (2^(100 + 15 x 28)).
+template <int KC, int DP, int LMIN, bool STASH>
+__global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd_u(WideArgs a, const double* __restrict__ W, const double* __restrict__ X,
+                                                         const double* __restrict__ Y, const int32_t* __restrict__ row_idx,
+                                                         const unsigned char* __restrict__ Wd, const double* __restrict__ sbg,
+                                                         const int* __restrict__ flags, double* __restrict__ act0,
+                                                         double* __restrict__ dz_last, double* __restrict__ pred_out,
+                                                         double* __restrict__ partial, double* __restrict__ dump, int actk) {
+    constexpr int HID = 64 * KC, TL = 4 * KC, TILE_B = KC * NS * 1024, PLANE = HID * HID, LAYERB = NS * PLANE;
+    constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN), NPT = NPROD * KC;
+    extern __shared__ __attribute__((aligned(16))) char smemu[];
+    double* lds = reinterpret_cast<double*>(smemu);
+    int b, split;
+    if (!qn_fused_wg(a.nsplit, a.B, &b, &split)) return;
+    const int NH = a.nhid, NHH = NH - 1, d = a.d, nb = a.has_bias ? 1 : 0;
+    // (the LDS layout of k_i8_wide_fwd; its tanh-table area stays unused)
+    const int offb0 = HID * DP, offWl = offb0 + HID, offbl = offWl + HID, offred = offbl + 2, offsb = wide_thin(HID, DP);
+    double* scratch = lds + ((offsb + NHH * 2 * HID + 1) & ~1) + ((TANH_TAB + 1) & ~1);
+    unsigned char* ring = reinterpret_cast<unsigned char*>(lds + wide_head(HID, DP, NH));
+    double* red = lds + offred;
+    const double* Wb = W + (int64_t)b * a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c = lane & 15;
+    const double alo = actk == QN_ACT_RELU ? 0.0 : -__builtin_inf();    // a = max(z, alo): relu / identity (z is finite here)
+
+    // ---- the weight-tile stream (as in k_i8_wide_fwd)
+    const unsigned char* wbase = Wd + (int64_t)b * NHH * LAYERB;
+    const unsigned ring_addr = lds_addr_of(ring);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned dma_off[KC * NS / 4];
+#pragma unroll
+    for (int u = 0; u < KC * NS / 4; ++u) {
+        const int i = wave_u + 4 * u, kc = i / NS, wi = i - kc * NS;
+        dma_off[u] = (unsigned)((lane >> 2) * HID + 16 * (lane & 3) + wi * PLANE + 64 * kc);
+    }
+    int pf_li = 0, pf_T = 0, pf_slot = 0;
+    auto dma_next = [&]() {
+        const unsigned char* src = wbase + (int64_t)pf_li * LAYERB + (int64_t)(16 * pf_T) * HID;
+        const unsigned dst = ring_addr + pf_slot * TILE_B;
+#pragma unroll
+        for (int u = 0; u < KC * NS / 4; ++u) wglds16s(dma_off[u], src, dst + (wave_u + 4 * u) * 1024);
+        if (++pf_T == TL) {
+            pf_T = 0;
+            if (++pf_li == NHH) pf_li = 0;
+        }
+        pf_slot = pf_slot + 1 == WNBUF ? 0 : pf_slot + 1;
+    };
+    dma_next();
+    dma_next();
+    int rd_slot = 0;
+    // (the youngest tile's DMA instructions + one epilogue's 4 activation stores may stay in flight: see k_i8_wide_fwd)
+    auto sync_tile = [&]() {
+        if constexpr (STASH) {
+            if constexpr (KC == 4) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
+        } else {
+            if constexpr (KC == 4) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+        }
+        dma_next();
+    };
+
+    // ---- resident pieces
+    int bad = flags[b];
+    {
+        auto chk = [&](double v) { bad |= !qn_bounded20(v); return v; };
+        const int64_t gb0 = (int64_t)HID * d, gHH = gb0 + nb * HID, blk = (int64_t)HID * HID + nb * HID;
+        const int64_t gWl = gHH + (int64_t)NHH * blk, gbl = gWl + HID;
+        for (int e = tid; e < HID * DP; e += WWG) {
+            const int j = e / DP, k = e % DP;
+            lds[e] = k < d ? chk(Wb[(int64_t)j * d + k]) : 0.0;
+        }
+        for (int e = tid; e < HID; e += WWG) {
+            lds[offb0 + e] = nb ? chk(Wb[gb0 + e]) : 0.0;
+            lds[offWl + e] = chk(Wb[gWl + e]);
+        }
+        if (tid == 0) lds[offbl] = nb ? chk(Wb[gbl]) : 0.0;
+        const double* sbs = sbg + (int64_t)b * NHH * 2 * HID;
+        for (int e = tid; e < NHH * 2 * HID; e += WWG) {
+            const double v = sbs[e];
+            if (e & 1) bad |= !qn_bounded20(v);                        // (the hidden layers' biases; their weights: k_i8_slice_w)
+            lds[offsb + e] = v;
+        }
+    }
+    const bool w_bad = block_or(bad, red + 6);
+
+    const int lofs = c * 64 + 16 * (q ^ slot_swz(c));
+    double sse = 0.0;
+    double xn[DP], yn;
+    int nrow_n, xbad_n;
+    auto fetch = [&](int it) {
+        xbad_n = 0;
+        const int n = split * a.rows_per_split + (it * 4 + wave) * 16 + c;
+        nrow_n = n;
+        const int nn = n < a.Nb ? n : 0;
+        const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            xn[k] = k < d ? X[rr * d + k] : 0.0;
+            xbad_n |= !qn_bounded100(xn[k]);
+        }
+        yn = Y[rr];
+    };
+    fetch(0);
+    for (int it = 0; it < a.iters; ++it) {
+        double xk[DP];
+#pragma unroll
+        for (int k = 0; k < DP; ++k) xk[k] = xn[k];
+        const double yk = yn;
+        const int nrow = nrow_n;
+        const bool live = nrow < a.Nb;
+        const bool exceptional = block_or(w_bad | xbad_n, red + 6);     // (workgroup-uniform: the tile barriers need all four waves)
+        if (it + 1 < a.iters) fetch(it + 1);
+        if (exceptional) {
+            sse += wide_slow_rows<KC>(a.Nb, d, NH, a.has_bias, a.act_stride, Wb, X, Y, row_idx,
+                                      split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave,
+                                      STASH ? act0 : nullptr, dz_last, pred_out, actk);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            continue;
+        }
+        const int64_t srow = ((int64_t)b * HID + 4 * q) * a.Nb + (live ? nrow : 0);
+        double* const dmp = dump + lane;
+
+        // ---- first layer (VALU): a_1 = act(W0 x + b0), kept as float64 until the row maximum is known
+        double V[TL][4];
+        double amax = 0.0;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 64 * kc + 16 * t + 4 * q + r;
+                    double z = lds[offb0 + j];
+#pragma unroll
+                    for (int k = 0; k < DP; ++k) z = fma(lds[j * DP + k], xk[k], z);
+                    const double av = fmax(z, alo);
+                    if constexpr (STASH) (live ? act0 + srow + (int64_t)(64 * kc + 16 * t) * a.Nb : dmp)[(int64_t)r * a.Nb] = av;
+                    amax = fmax(amax, fabs(av));
+                    V[4 * kc + t][r] = to_acc_d(av);
+                }
+        v4i Bin[KC][NS];
+        double rs = 0.0;                                           // 2^f_n: this row's scale of the current B operand
+        auto slice_rows = [&]() {                                  // (as in k_i8_wide_bwd)
+            double m = amax;
+            m = fmax(m, __shfl_xor(m, 16, 64));
+            m = fmax(m, __shfl_xor(m, 32, 64));
+            int E = (__double2hiint(m) >> 20) & 0x7ff;             // |v| < 2^(E - 1022) for every v of the row
+            E = E < 122 ? 122 : E;
+            const double sl = __hiloint2double((2091 - E) << 20, 0);        // 2^(46 - f), f = E - 1022
+            rs = __hiloint2double((E + 1) << 20, 0);                        // 2^f
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                v4i Bcur[NS];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    double vv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[r] = V[4 * kc + t][r];
+                    int S[NS];
+                    slice4s(vv, sl, S);
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) Bcur[k][t] = S[k];
+                }
+#pragma unroll
+                for (int k = 0; k < NS; ++k) Bin[kc][k] = to_acc(Bcur[k]);
+            }
+            amax = 0.0;
+        };
+        slice_rows();
+
+        // ---- hidden -> hidden layers
+        double prt = 0.0;
+        auto load_frags = [&](v4i (&Af)[NS], const unsigned char* blk) {
+#pragma unroll
+            for (int wi = 0; wi < NS; ++wi) Af[wi] = *reinterpret_cast<const v4i*>(blk + wi * 1024);
+        };
+        auto burst = [&](v4i (&acc)[NLEV], const unsigned char* tile) {
+            v4i Af[2][NS];
+            load_frags(Af[0], tile);
+            for_each_stage([&](auto k_tag) {
+                constexpr int k = decltype(k_tag)::value, kc = k / NPROD, kk = k - kc * NPROD;
+                if constexpr (kk == 0 && kc + 1 < KC) load_frags(Af[(kc + 1) & 1], tile + (kc + 1) * NS * 1024);
+                issue_product_c<LMIN, NLEV, kc == 0, kk>(acc, Af[kc & 1], Bin[kc]);
+            }, std::make_integer_sequence<int, NPT>{});
+        };
+        // epilogue of tile T (pinned micro-steps, the next tile's MFMAs dealt out between them): recombine the levels,
+        // z = (sum 2^f_n) x scale_j + bias_j, a = max(z, alo); the last hidden layer feeds the output layer's dot instead of V
+        auto epilogue = [&](auto last_tag, auto next_tag, auto t_tag, const v4i (&acc)[NLEV], v4i (&accn)[NLEV],
+                            const unsigned char* tile_next, const double* sbt, const double* wlt, double* (&sp)[4], int64_t sstride) {
+            constexpr bool LAST = decltype(last_tag)::value, NEXT = decltype(next_tag)::value;
+            constexpr int Tt_ = decltype(t_tag)::value;
+            constexpr int NST = NLEV + 2, NMICRO = NST * 4, LEAD = 2;
+            v4i Af[2][NS];
+            double2 sc[4];
+            double ts[4], z[4];
+            auto micro = [&](auto id_tag) {
+                constexpr int id = decltype(id_tag)::value;
+                if constexpr (id == 0 && NEXT) load_frags(Af[0], tile_next);
+                if constexpr (NEXT && id >= LEAD) {
+                    constexpr int from = ((id - LEAD) * NPT + (NMICRO - LEAD) - 1) / (NMICRO - LEAD);
+                    constexpr int upto = ((id - LEAD + 1) * NPT + (NMICRO - LEAD) - 1) / (NMICRO - LEAD);
+                    for_each_stage([&](auto k_tag) {
+                        constexpr int k = from + decltype(k_tag)::value, kc = k / NPROD, kk = k - kc * NPROD;
+                        if constexpr (kk == 0 && kc + 1 < KC) load_frags(Af[(kc + 1) & 1], tile_next + (kc + 1) * NS * 1024);
+                        issue_product_c<LMIN, NLEV, kc == 0, kk>(accn, Af[kc & 1], Bin[kc]);
+                    }, std::make_integer_sequence<int, upto - from>{});
+                }
+                constexpr int st = id >> 2, r = id & 3;
+                if constexpr (st == 0) {
+                    sc[r] = *reinterpret_cast<const double2*>(sbt + 2 * r);
+                    ts[r] = (double)acc[NLEV - 1][r];
+                } else if constexpr (st < NLEV) {
+                    { const double cv_ = (double)acc[NLEV - 1 - st][r]; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(ts[r]) : "v"(ts[r]), "s"(256.0), "v"(cv_)); }
+                } else if constexpr (st == NLEV) {
+                    z[r] = fma(ts[r] * rs, sc[r].x, sc[r].y);
+                } else {
+                    const double av = fmax(z[r], alo);
+                    if constexpr (STASH) { *sp[r] = av; sp[r] += sstride; }
+                    if constexpr (LAST) {
+                        prt = fma(wlt[r], av, prt);
+                    } else {
+                        amax = fmax(amax, fabs(av));
+                        V[Tt_][r] = to_acc_d(av);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            for_each_stage(micro, std::make_integer_sequence<int, NMICRO>{});
+        };
+        auto hidden_layer = [&](auto last_tag, int li) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            const double* sb = lds + offsb + li * 2 * HID + 2 * 4 * q;       // this lane group's features 16 T + 4 q + r
+            const double* wl = lds + offWl + 4 * q;
+            double* stl = STASH ? act0 + (int64_t)(li + 1) * a.act_stride + srow : nullptr;
+            double* sp[4];
+            int64_t sstride = live ? (int64_t)16 * a.Nb : 0;
+            asm volatile("" : "+v"(sstride));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sp[r] = STASH ? (live ? stl : dmp) + (int64_t)r * a.Nb : nullptr;
+            v4i accA[NLEV], accB[NLEV];
+            sync_tile();
+            burst(accA, ring + rd_slot * TILE_B + lofs);
+            auto tile = [&](auto t_tag) {
+                constexpr int Tt_ = decltype(t_tag)::value;
+                rd_slot = rd_slot + 1 == WNBUF ? 0 : rd_slot + 1;            // (now the slot of tile Tt_ + 1)
+                const unsigned char* nxt = ring + rd_slot * TILE_B + lofs;
+                if constexpr (Tt_ + 1 < TL) {
+                    sync_tile();
+                    if constexpr (Tt_ & 1) epilogue(last_tag, std::true_type{}, t_tag, accB, accA, nxt, sb + 32 * Tt_, wl + 16 * Tt_, sp, sstride);
+                    else epilogue(last_tag, std::true_type{}, t_tag, accA, accB, nxt, sb + 32 * Tt_, wl + 16 * Tt_, sp, sstride);
+                } else {
+                    if constexpr (Tt_ & 1) epilogue(last_tag, std::false_type{}, t_tag, accB, accA, nxt, sb + 32 * Tt_, wl + 16 * Tt_, sp, sstride);
+                    else epilogue(last_tag, std::false_type{}, t_tag, accA, accB, nxt, sb + 32 * Tt_, wl + 16 * Tt_, sp, sstride);
+                }
+            };
+            for_each_stage(tile, std::make_integer_sequence<int, TL>{});
+            if constexpr (!LAST) slice_rows();
+        };
+        for (int li = 0; li < NHH - 1; ++li) hidden_layer(std::false_type{}, li);
+        hidden_layer(std::true_type{}, NHH - 1);
+
+        // ---- last layer: finish the dot over the four lane groups, residual, SSE
+        double pq = prt;
+        pq += __shfl_xor(pq, 16, 64);
+        pq += __shfl_xor(pq, 32, 64);
+        const double pr = pq + lds[offbl];
+        const double res = pr - yk;
+        if (live && q == 0) {
+            sse += res * res;
+            if (pred_out) pred_out[(int64_t)b * a.Nb + nrow] = pr;
+            if (dz_last) dz_last[(int64_t)b * a.Nb + nrow] = 2.0 * res;
+        }
+    }
+    sse = wave_sum(sse);
+    if (lane == 0) red[wave] = sse;
+    __syncthreads();                                     // (vmcnt(0): the two tiles fetched ahead have landed too)
+    if (tid == 0) partial[(int64_t)b * a.nsplit + split] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // gradW[b][offW + f] = sum over the row splits of the output layer's partial weight gradients (entry h: the bias)
 __global__ void k_wide_dwl_sum(const double* __restrict__ slab, int nsplit, int h, int has_bias, int64_t p, int64_t offW, int64_t offB,
                                double* __restrict__ gradW) {
@@ -1036,7 +1337,10 @@ int wide_arm(const void* fn, size_t bytes) {
 
 bool qn_i8_wide_applies(const qn_desc* d) {
     const int L = d->nlayers;
-    if (d->kind != QN_KIND_MLP || d->act != QN_ACT_TANH || L < 3 || d->dims[0] > 4 || d->dims[L] != 1) return false;
+    if (d->kind != QN_KIND_MLP || L < 3 || d->dims[0] > 4 || d->dims[L] != 1) return false;
+#ifdef QN_WIDE_TANH_ONLY                                            // (A/B: relu / identity on the layer-wise float64 kernels, as until round 4)
+    if (d->act != QN_ACT_TANH) return false;
+#endif
     const int h = d->dims[1];
     if (h != 128 && h != 256) return false;
     for (int l = 1; l < L; ++l)
@@ -1102,9 +1406,24 @@ int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const
     else
         kern = h == 128 ? (dp == 2 ? k_i8_wide_fwd<2, 2, QN_I8_LMIN, false> : k_i8_wide_fwd<2, 4, QN_I8_LMIN, false>)
                         : (dp == 2 ? k_i8_wide_fwd<4, 2, QN_I8_LMIN, false> : k_i8_wide_fwd<4, 4, QN_I8_LMIN, false>);
-    if (int rc = wide_arm(reinterpret_cast<const void*>(kern), lds)) return rc;
-    hipLaunchKernelGGL(kern, dim3(qn_fused_grid(a.nsplit, B)), dim3(WWG), lds, st, a, W, X, Y, row_idx,
-                       (const unsigned char*)Wd, (const double*)sb, (const int*)flags, act0, dz_last, pred, partial, dump);
+    if (d->act != QN_ACT_TANH) {                                    // relu / identity: per-row activation scales
+        using ufn = void (*)(WideArgs, const double*, const double*, const double*, const int32_t*, const unsigned char*,
+                             const double*, const int*, double*, double*, double*, double*, double*, int);
+        ufn ku;
+        if (act0)
+            ku = h == 128 ? (dp == 2 ? k_i8_wide_fwd_u<2, 2, QN_I8_LMIN, true> : k_i8_wide_fwd_u<2, 4, QN_I8_LMIN, true>)
+                          : (dp == 2 ? k_i8_wide_fwd_u<4, 2, QN_I8_LMIN, true> : k_i8_wide_fwd_u<4, 4, QN_I8_LMIN, true>);
+        else
+            ku = h == 128 ? (dp == 2 ? k_i8_wide_fwd_u<2, 2, QN_I8_LMIN, false> : k_i8_wide_fwd_u<2, 4, QN_I8_LMIN, false>)
+                          : (dp == 2 ? k_i8_wide_fwd_u<4, 2, QN_I8_LMIN, false> : k_i8_wide_fwd_u<4, 4, QN_I8_LMIN, false>);
+        if (int rc = wide_arm(reinterpret_cast<const void*>(ku), lds)) return rc;
+        hipLaunchKernelGGL(ku, dim3(qn_fused_grid(a.nsplit, B)), dim3(WWG), lds, st, a, W, X, Y, row_idx,
+                           (const unsigned char*)Wd, (const double*)sb, (const int*)flags, act0, dz_last, pred, partial, dump, d->act);
+    } else {
+        if (int rc = wide_arm(reinterpret_cast<const void*>(kern), lds)) return rc;
+        hipLaunchKernelGGL(kern, dim3(qn_fused_grid(a.nsplit, B)), dim3(WWG), lds, st, a, W, X, Y, row_idx,
+                           (const unsigned char*)Wd, (const double*)sb, (const int*)flags, act0, dz_last, pred, partial, dump);
+    }
     hipLaunchKernelGGL(k_wide_sum, dim3((B + 63) / 64), dim3(64), 0, st, (const double*)partial, a.nsplit, B, sse);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
@@ -1154,12 +1473,18 @@ int qn_i8_wide_backward(const qn_desc* d, const double* W, const double* X, cons
     const int dp = a.d <= 2 ? 2 : 4;
     const size_t lds = wideb_lds_bytes(h / 64, a.nhid);
     using kfn = void (*)(WideBwdArgs, const double*, const double*, const int32_t*, const unsigned char*, const double*,
-                         const int*, const double*, const double*, double*, double*, double*);
-    kfn kern = h == 128 ? (dp == 2 ? k_i8_wide_bwd<2, 2, QN_I8_LMIN> : k_i8_wide_bwd<2, 4, QN_I8_LMIN>)
-                        : (dp == 2 ? k_i8_wide_bwd<4, 2, QN_I8_LMIN> : k_i8_wide_bwd<4, 4, QN_I8_LMIN>);
+                         const int*, const double*, const double*, double*, double*, double*, int);
+    kfn kern;
+    if (d->act == QN_ACT_TANH)
+        kern = h == 128 ? (dp == 2 ? k_i8_wide_bwd<2, 2, QN_I8_LMIN, true> : k_i8_wide_bwd<2, 4, QN_I8_LMIN, true>)
+                        : (dp == 2 ? k_i8_wide_bwd<4, 2, QN_I8_LMIN, true> : k_i8_wide_bwd<4, 4, QN_I8_LMIN, true>);
+    else
+        kern = h == 128 ? (dp == 2 ? k_i8_wide_bwd<2, 2, QN_I8_LMIN, false> : k_i8_wide_bwd<2, 4, QN_I8_LMIN, false>)
+                        : (dp == 2 ? k_i8_wide_bwd<4, 2, QN_I8_LMIN, false> : k_i8_wide_bwd<4, 4, QN_I8_LMIN, false>);
     if (int rc = wide_arm(reinterpret_cast<const void*>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(qn_fused_grid(a.nsplit, B)), dim3(WWG), lds, st, a, W, X, row_idx, (const unsigned char*)WdT,
-                       (const double*)scT, (const int*)flags, act0, dz_last, dz0, dump, fold_last ? dwl_slab : (double*)nullptr);
+                       (const double*)scT, (const int*)flags, act0, dz_last, dz0, dump, fold_last ? dwl_slab : (double*)nullptr,
+                       d->act);
     if (fold_last) {
         const int L = d->nlayers;
         hipLaunchKernelGGL(k_wide_dwl_sum, dim3(B), dim3(192), 0, st, (const double*)dwl_slab, a.nsplit, h, d->has_bias, d->p,
