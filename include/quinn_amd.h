@@ -71,9 +71,9 @@ size_t qn_workspace_bytes(const qn_desc* desc, int B, int Nb, int want_grad, int
 /* Which kernel family the next call with these sizes would run (QN_PATH_GENERIC/FUSED). */
 int qn_mlp_path(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
 /* Which ARITHMETIC the next call with these sizes would form the hidden-layer products in: QN_ARITH_PLAIN -- the arithmetic
- * of `dtype` throughout; QN_ARITH_I8_FUSED -- sliced exact int8 products in the one-launch kernels of 64-wide tanh networks
+ * of `dtype` throughout; QN_ARITH_I8_FUSED -- sliced exact int8 products in the one-launch kernels of 64-wide networks
  * (qn_fused_i8.hip / qn_fused_bwd_i8.hip; also a narrower network's zero-padded 64-wide twin); QN_ARITH_I8_WIDE -- the
- * int8-slice kernels of 128 / 256-wide tanh networks (qn_wide_i8.hip, qn_dw_i8.hip); QN_ARITH_I8_LAYERS -- the layer-wise
+ * int8-slice kernels of 128 / 256-wide networks (qn_wide_i8.hip; tanh also qn_dw_i8.hip); QN_ARITH_I8_LAYERS -- the layer-wise
  * int8-slice forward of other tanh networks whose widths are multiples of 64.  (The reference has one arithmetic, torch
  * float64: quinn/nns/tchutils.py:9; tests use this query to prove which kernels a parity case exercised.) */
 enum { QN_ARITH_PLAIN = 0, QN_ARITH_I8_FUSED = 1, QN_ARITH_I8_WIDE = 2, QN_ARITH_I8_LAYERS = 3 };
@@ -85,9 +85,10 @@ int qn_mlp_arith(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
  * unpadded network's).  QN_PATH_FUSED_DP is QN_PATH_FUSED restricted to the kernels that use the float64 matrix
  * instructions: it excludes the forward kernel that forms the 64-wide hidden layers as sliced exact int8 products
  * (same results to ~1e-14 relative; kept selectable as the second implementation the tests compare it with).  Under
- * QN_PATH_AUTO the float64 tanh networks with hidden widths all 128 or all 256 (one output, <= 4 inputs) take the layer-wise
- * family with their hidden layers -- forward, activation gradient, weight gradient -- as sliced exact int8 products
- * (~1e-13 relative); QN_PATH_GENERIC is the all-float64 reference of that family as well.
+ * QN_PATH_AUTO the float64 networks with hidden widths all 128 or all 256 (one output, <= 4 inputs) take the layer-wise
+ * family with their hidden layers -- forward, activation gradient and, for tanh, weight gradient -- as sliced exact int8
+ * products (~1e-13 relative; relu / identity: one activation scale per data row and layer, and every weight and bias below
+ * 2^20, inputs below 2^100); QN_PATH_GENERIC is the all-float64 reference of that family as well.
  * Accuracy of the int8-slice kernels: operands are rounded to 2^-47 of (1 x the weight row's maximum), the products are
  * exact -- a norm-wise bound, 47-bit against float64's 53; rows whose activations are all below ~2^-5 and chains with a
  * hidden-matrix weight >= 2^20 (or not finite) are computed in plain float64 instead.

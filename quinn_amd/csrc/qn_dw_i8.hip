@@ -44,7 +44,7 @@ struct DwArgs {
 
 template <int LMIN>
 __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __restrict__ dz, const double* __restrict__ ap,
-                                                 double* __restrict__ out) {
+                                                 double* __restrict__ out, const double* /*rowsc: k_i8_dw_g only*/) {
     constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN);
     static_assert(NLEV == 7 || NLEV == 6, "level recombination below is written for LMIN = 4 / 5");
     extern __shared__ __attribute__((aligned(16))) char smemd[];
@@ -343,9 +343,13 @@ constexpr int DWG_RING = 2 * 64 * (int)sizeof(double);                // scales 
 constexpr int DWG_FACC = 4 * 16 * 64 * (int)sizeof(double);           // float64 accumulators of the four matrix waves: 32 KB
 constexpr int DWG_LDS = 2 * DWG_BUF + DWG_RING + DWG_FACC + 16;
 
-template <int LMIN, int GC>
+// UNB (round 4: relu / identity networks, whose activations are not bounded by 1): `rowsc` [B][Nb] holds the scale 2^f_n > every
+// |a[.][n]| of data row n that the forward sliced the row with (k_i8_wide_fwd_u).  The contraction runs over n, so the scale
+// moves to the other operand: a[i][n] 2^-f_n (in (-1, 1): the fixed scale of the tanh case) against dZ[j][n] 2^f_n (whose feature /
+// group scales are found from the scaled values); powers of two, the product is unchanged.  Bias sums use the raw dZ.
+template <int LMIN, int GC, bool UNB = false>
 __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __restrict__ dz, const double* __restrict__ ap,
-                                                   double* __restrict__ out) {
+                                                   double* __restrict__ out, const double* __restrict__ rowsc) {
     constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN);
     static_assert(GC >= 2 && (GC & (GC - 1)) == 0 && GC <= 64, "chunks per scale group: a power of two (int32 level sums: GC * 6 * 2^20)");
     extern __shared__ __attribute__((aligned(16))) char smemd[];
@@ -373,6 +377,13 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __re
     }
     double magic = kMagic;                                            // (opaque register pair: see slice4_scaled, qn_fused_bwd_i8.hip)
     asm volatile("" : "+v"(magic));
+    const double* RS = UNB ? rowsc + (int64_t)b * Nb : nullptr;
+    // the row scales of a lane's 4 rows of chunk ch (rows {2 q, 2 q + 1, 32 + 2 q, 33 + 2 q}: as load_block)
+    auto load_rs = [&](int ch, int q16_, double (&r)[4]) {
+        const double2* sp = reinterpret_cast<const double2*>(RS + kbeg + 64 * ch + 2 * q16_);
+        const double2 v01 = sp[0], v23 = sp[16];
+        r[0] = v01.x; r[1] = v01.y; r[2] = v23.x; r[3] = v23.y;
+    };
 
     // (items and rows of a lane: as in k_i8_dw; the host sends only whole, 16-byte aligned chunks here: Nb % 64 == 0)
     auto load_block = [&](const double* base, int ch, int q16_, int fl_, double (&v)[4][4]) {
@@ -411,11 +422,14 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __re
         int bad = 0;
         unsigned pmax[4] = {0u, 0u, 0u, 0u};                             // largest |dZ| high word seen in the group being read ahead
         double dn[4] = {0.0, 0.0, 0.0, 0.0};                             // 2^(46 - e) of the group being sliced
+        double rsc[4] = {1.0, 1.0, 1.0, 1.0}, rsp[4] = {1.0, 1.0, 1.0, 1.0};     // UNB: row scales of the chunk being sliced / read ahead
         auto fold = [&](const double (&pz)[4][4]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if constexpr (UNB) pmax[u] = max(pmax[u], (unsigned)__double2hiint(pz[u][r] * rsp[r]) & 0x7fffffffu);   // (0 x 2^f = 0)
+                    else
                     pmax[u] = max(pmax[u], (unsigned)__double2hiint(pz[u][r]) & 0x7fffffffu);
                     // (the low words count as used until here: dead on arrival, the allocator hands them out as scratch
                     // registers while the load is still in flight, and every such write waits for ALL outstanding loads)
@@ -449,7 +463,15 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __re
             for (int u = 0; u < 4; ++u) {
                 const int f = 16 * u + fl;
                 int S[NS];
-                slice_item(vz[u], dn[u], S);
+                if constexpr (UNB) {
+                    // (dZ 2^f_n first: 0 stays 0 whatever the scales; the product with 2^(46 - e) is the one rounding)
+                    double vs[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vs[r] = vz[u][r] * rsc[r];
+                    slice_item(vs, dn[u], S);
+                } else {
+                    slice_item(vz[u], dn[u], S);
+                }
                 const int ofs = f * 64 + 16 * (g4 ^ slot_swz(f)) + 4 * m4;
 #pragma unroll
                 for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(pa + k * 4096 + ofs) = S[k];
@@ -461,16 +483,25 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __re
         auto slice_chunk_a = [&](int ch, const double (&va)[4][4]) {
             unsigned char* pbn = reinterpret_cast<unsigned char*>(smemd + (ch & 1) * DWG_BUF) + DW_OPER;
             const double p46 = 0x1p46;
+            double ainv[4];                                              // UNB: 2^-f_n of the lane's 4 rows (exponent arithmetic)
+            if constexpr (UNB) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ainv[r] = __hiloint2double((2046 << 20) - __double2hiint(rsc[r]), 0);
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int f = 16 * u + fl;
                 unsigned exa = 0;
+                double vn[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) exa = max(exa, (unsigned)__double2hiint(va[u][r]) & 0x7fffffffu);
+                for (int r = 0; r < 4; ++r) {
+                    vn[r] = UNB ? va[u][r] * ainv[r] : va[u][r];         // (exact: a power of two; |vn| < 1 by the forward's choice of f_n)
+                    exa = max(exa, (unsigned)__double2hiint(vn[r]) & 0x7fffffffu);
+                }
                 bad |= exa >= 0x40000000u;                               // |a| >= 2 or not finite
                 amaxa = max(amaxa, exa);
                 int S[NS];
-                slice_item(va[u], p46, S);
+                slice_item(vn, p46, S);
                 const int ofs = f * 64 + 16 * (g4 ^ slot_swz(f)) + 4 * m4;
 #pragma unroll
                 for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(pbn + k * 4096 + ofs) = S[k];
@@ -496,7 +527,13 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __re
             for (int u = 0; u < 4; ++u) ring[64 + 16 * u + fl] = 0.0;     // (slot 1 is read beside group 0's first chunk: 0 x 0)
         }
 #pragma unroll
-        for (int c = 0; c < GC; ++c) { load_block(Z, min(c, lastc), q16, fl, pz); fold(pz); }      // group 0's exponents
+        for (int c = 0; c < GC; ++c) {                                                            // group 0's exponents
+            if constexpr (UNB) load_rs(min(c, lastc), q16, rsp);
+            load_block(Z, min(c, lastc), q16, fl, pz);
+            fold(pz);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (UNB) { load_rs(0, q16, rsc); load_rs(min(GC, lastc), q16, rsp); }
         __builtin_amdgcn_sched_barrier(0);
         // (in the order and number the loop leaves them outstanding at its head: the compiler's wait counts at the head are
         // the worst case over the two ways in, and with another order there it waited for EVERYTHING in every other step)
@@ -535,6 +572,7 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __re
             __builtin_amdgcn_sched_barrier(0);
             load_block(A, min(ch + 2, lastc), q16, fl, va);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (UNB) { load_rs(min(ch + 1, lastc), q16, rsc); __builtin_amdgcn_sched_barrier(0); }   // (both slicings of chunk ch are done)
 #ifdef QN_DW_STAMPS
             { const long long t_ = __builtin_amdgcn_s_memtime(); __syncthreads(); tsg_bar += __builtin_amdgcn_s_memtime() - t_; }
 #else
@@ -545,6 +583,7 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __re
 #endif
             fold(pz);                 // (exponents of chunk ch + GC, requested a step ago)
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (UNB) load_rs(min(ch + 1 + GC, lastc), q16, rsp);
             load_block(Z, min(ch + 1 + GC, lastc), q16, fl, pz);
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -708,8 +747,9 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __re
 // dst + b * out_stride_b + slab * out_stride_k receives [h_out x h_in] weights (+ h_out bias sums behind them): the
 // conventions of k_gemm64<DW> (qn_generic.hip), whose split-K slabs and reduction kernel the caller keeps
 int qn_i8_dw(int h_in, int h_out, int has_bias, const double* dz, const double* a_prev, int B, int Nb, double* dst,
-             int64_t out_stride_b, int64_t out_stride_k, int ksplit, int kchunk, hipStream_t st) {
+             int64_t out_stride_b, int64_t out_stride_k, int ksplit, int kchunk, const double* rowsc, hipStream_t st) {
     if (h_in % 64 || h_out % 64) return QN_EUNSUPPORTED;
+    if (rowsc && (QN_DW_GROUP < 2 || Nb % 64 || kchunk % 64)) return QN_EUNSUPPORTED;      // (row scales: the group-scale kernel only)
     DwArgs g;
     g.out_stride_b = out_stride_b; g.out_stride_k = out_stride_k; g.h_in = h_in; g.h_out = h_out; g.Nb = Nb;
     g.has_bias = has_bias; g.kchunk = kchunk;
@@ -717,14 +757,18 @@ int qn_i8_dw(int h_in, int h_out, int has_bias, const double* dz, const double* 
     const unsigned grid = (unsigned)(((g.outer_total + 7) / 8) * 8 * g.inner);
     // group scales (k_i8_dw_g) for row counts in whole chunks; the per-chunk kernel (partial chunks, odd row counts) otherwise
     size_t lds = 2 * (size_t)DW_BUF + 16;
-    void (*kern)(DwArgs, const double*, const double*, double*) = k_i8_dw<QN_I8_LMIN>;
+    void (*kern)(DwArgs, const double*, const double*, double*, const double*) = k_i8_dw<QN_I8_LMIN>;
     int which = 0;
 #if QN_DW_GROUP >= 2
-    if (Nb % 64 == 0 && kchunk % 64 == 0) { lds = (size_t)DWG_LDS; kern = k_i8_dw_g<QN_I8_LMIN, QN_DW_GROUP>; which = 1; }
+    if (Nb % 64 == 0 && kchunk % 64 == 0) {
+        lds = (size_t)DWG_LDS;
+        if (rowsc) { kern = k_i8_dw_g<QN_I8_LMIN, QN_DW_GROUP, true>; which = 2; }
+        else { kern = k_i8_dw_g<QN_I8_LMIN, QN_DW_GROUP, false>; which = 1; }
+    }
 #endif
     {   // raise the dynamic-LDS limit once per device (not per launch: the launch path stays capturable into a HIP graph)
         static std::mutex mu;
-        static unsigned long long armed[2] = {0, 0};                     // per kernel: bit = device ordinal
+        static unsigned long long armed[3] = {0, 0, 0};                  // per kernel: bit = device ordinal
         int dev = 0;
         QN_HIP_CHECK(hipGetDevice(&dev));
         std::lock_guard<std::mutex> lock(mu);
@@ -734,7 +778,7 @@ int qn_i8_dw(int h_in, int h_out, int has_bias, const double* dz, const double* 
             armed[which] |= 1ull << dev;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(DWT), lds, st, g, dz, a_prev, dst);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(DWT), lds, st, g, dz, a_prev, dst, rowsc);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }

@@ -128,5 +128,10 @@ int qn_i8_wide_backward(const qn_desc* d, const double* W, const double* X, cons
                         const double* act0, int64_t act_stride, const double* dz_last, double* dz0, int64_t dz_stride, void* ws,
                         double* gradW, int* last_done, hipStream_t st);
 // weight gradient of a hidden->hidden layer as sliced int8 products (qn_dw_i8.hip): output conventions of k_gemm64<DW>
+// rowsc (may be null: tanh, activations in [-1, 1]): [B][Nb] scales 2^f_n > every |a_prev[.][n]| of data row n, as the forward
+// of a relu / identity network leaves them (qn_i8_wide_rowscale); with it, row counts in whole 64-row chunks only
 int qn_i8_dw(int h_in, int h_out, int has_bias, const double* dz, const double* a_prev, int B, int Nb, double* dst,
-             int64_t out_stride_b, int64_t out_stride_k, int ksplit, int kchunk, hipStream_t st);
+             int64_t out_stride_b, int64_t out_stride_k, int ksplit, int kchunk, const double* rowsc, hipStream_t st);
+// relu / identity networks, gradient calls: the forward's per-row activation scales [L-2 layers][B][Nb] inside its workspace
+// (layer l = the scales of act0 + l * act_stride); null for tanh networks / forward-only workspaces
+double* qn_i8_wide_rowscale(const qn_desc* d, int B, int Nb, int want_grad, void* ws);

@@ -684,6 +684,19 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                     return rc;
             }
         }
+        // the hidden matrices' weight gradient as sliced int8 products (qn_dw_i8.hip): tanh networks; relu / identity ones through
+        // the forward's row scales, for row counts in whole 64-row chunks (else the float64-MFMA product below)
+        const double* rowsc = nullptr;
+        bool i8_dw_ok = false;
+        if constexpr (std::is_same<T, double>::value) {
+            if (wide_bwd) {
+                rowsc = qn_i8_wide_rowscale(d, B, Nb, 1, wide_ws);
+                i8_dw_ok = d->act == QN_ACT_TANH || (rowsc != nullptr && Nb % 64 == 0);
+#ifdef QN_DW_UNB_OFF
+                i8_dw_ok = d->act == QN_ACT_TANH;                        // (A/B)
+#endif
+            }
+        }
         for (int l = L - 1; l >= 0; --l) {
             LayerArgs a = largs(l);
             if (wide_bwd && l < L - 1) dz = dzbuf[0] + (int64_t)l * dz_stride;
@@ -691,7 +704,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
             if (gemm_layer(d, l)) {
                 GemmArgs g = gargs(l);
                 const int tiles = (g.h_in / 64) * (g.h_out / 64);
-                const int ks = dw_ksplit(B, tiles, Nb, wide_bwd && d->act == QN_ACT_TANH ? QN_DW_I8_TARGET_WGS : 4096);
+                const int ks = dw_ksplit(B, tiles, Nb, wide_bwd && i8_dw_ok ? QN_DW_I8_TARGET_WGS : 4096);
                 // weights and (if any) the bias block behind them: contiguous in the flat layout and in a slab
                 const int64_t nW = (int64_t)g.h_in * g.h_out + (d->has_bias ? g.h_out : 0);
                 g.ksplit = ks;
@@ -702,12 +715,11 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                 bool dw_done = false;
                 if constexpr (std::is_same<T, double>::value) {
 #ifndef QN_NO_I8_DW
-                    // (sliced int8 products, qn_dw_i8.hip; K-slabs in whole 64-row chunks.  Its `a` operand is sliced with the
-                    // fixed scale of tanh outputs: relu / identity networks take the float64-MFMA product below)
-                    if (wide_bwd && d->act == QN_ACT_TANH) {
+                    // (sliced int8 products, qn_dw_i8.hip; K-slabs in whole 64-row chunks)
+                    if (wide_bwd && i8_dw_ok) {
                         const int kc64 = ((Nb + ks - 1) / ks + 63) / 64 * 64;
                         if (int rc = qn_i8_dw(g.h_in, g.h_out, d->has_bias, dz, act[l - 1], B, Nb, dst, g.out_stride_b,
-                                              g.out_stride_k, ks, kc64, st))
+                                              g.out_stride_k, ks, kc64, rowsc ? rowsc + (int64_t)(l - 1) * B * Nb : nullptr, st))
                             return rc;
                         dw_done = true;
                     }

@@ -90,7 +90,7 @@ __device__ __noinline__ double wide_slow_rows(int Nb, int d, int nhid, int has_b
                                               const double* __restrict__ Y, const int32_t* __restrict__ row_idx, int nbase,
                                               int b, double* __restrict__ scr, double* __restrict__ act0,
                                               double* __restrict__ dz_last, double* __restrict__ pred_out,
-                                              int actk = QN_ACT_TANH) {
+                                              int actk = QN_ACT_TANH, double* __restrict__ rowsc = nullptr, int64_t rs_stride = 0) {
     constexpr int HID = 64 * KC;
     const int lane = threadIdx.x & 63, nb = has_bias ? 1 : 0;
     const int64_t gb0 = (int64_t)HID * d, gHH = gb0 + nb * HID, blk = (int64_t)HID * HID + nb * HID;
@@ -107,6 +107,17 @@ __device__ __noinline__ double wide_slow_rows(int Nb, int d, int nhid, int has_b
             act[m] = wide_actf(z, actk);
             if (act0) act0[((int64_t)b * HID + f) * Nb + n] = act[m];
         }
+        // (relu / identity gradient calls: the row's scale 2^f > every |a| of the layer, what the fast rows leave for the
+        // weight-gradient kernel; a row that is not finite gets exponent 2046 and is caught there)
+        auto put_scale = [&](int layer) {
+            unsigned ex = 0;
+#pragma unroll
+            for (int m = 0; m < KC; ++m) ex = max(ex, ((unsigned)__double2hiint(act[m]) & 0x7fffffffu) >> 20);
+            ex = wave_max_u32(ex);
+            ex = ex < 122u ? 122u : (ex > 2045u ? 2045u : ex);
+            if (lane == 0) rowsc[layer * rs_stride + (int64_t)b * Nb + n] = __hiloint2double((int)((ex + 1) << 20), 0);
+        };
+        if (rowsc && nhid > 1) put_scale(0);
         for (int layer = 1; layer < nhid; ++layer) {
             double* cur = scr + HID * (layer & 1);
 #pragma unroll
@@ -121,6 +132,7 @@ __device__ __noinline__ double wide_slow_rows(int Nb, int d, int nhid, int has_b
                 act[m] = wide_actf(z, actk);
                 if (act0) act0[layer * act_stride + ((int64_t)b * HID + f) * Nb + n] = act[m];
             }
+            if (rowsc && layer + 1 < nhid) put_scale(layer);
         }
         double pp = 0.0;
 #pragma unroll
@@ -1009,7 +1021,8 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd_u(WideArgs a, const doub
                                                          const unsigned char* __restrict__ Wd, const double* __restrict__ sbg,
                                                          const int* __restrict__ flags, double* __restrict__ act0,
                                                          double* __restrict__ dz_last, double* __restrict__ pred_out,
-                                                         double* __restrict__ partial, double* __restrict__ dump, int actk) {
+                                                         double* __restrict__ partial, double* __restrict__ dump, int actk,
+                                                         double* __restrict__ rowsc, int64_t rs_stride) {
     constexpr int HID = 64 * KC, TL = 4 * KC, TILE_B = KC * NS * 1024, PLANE = HID * HID, LAYERB = NS * PLANE;
     constexpr int NLEV = 2 * (NS - 1) - LMIN + 1, NPROD = nprod(LMIN), NPT = NPROD * KC;
     extern __shared__ __attribute__((aligned(16))) char smemu[];
@@ -1117,7 +1130,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd_u(WideArgs a, const doub
         if (exceptional) {
             sse += wide_slow_rows<KC>(a.Nb, d, NH, a.has_bias, a.act_stride, Wb, X, Y, row_idx,
                                       split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave,
-                                      STASH ? act0 : nullptr, dz_last, pred_out, actk);
+                                      STASH ? act0 : nullptr, dz_last, pred_out, actk, STASH ? rowsc : nullptr, rs_stride);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             continue;
         }
@@ -1144,7 +1157,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd_u(WideArgs a, const doub
                 }
         v4i Bin[KC][NS];
         double rs = 0.0;                                           // 2^f_n: this row's scale of the current B operand
-        auto slice_rows = [&]() {                                  // (as in k_i8_wide_bwd)
+        auto slice_rows = [&](int layer) {                         // (as in k_i8_wide_bwd)
             double m = amax;
             m = fmax(m, __shfl_xor(m, 16, 64));
             m = fmax(m, __shfl_xor(m, 32, 64));
@@ -1152,6 +1165,11 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd_u(WideArgs a, const doub
             E = E < 122 ? 122 : E;
             const double sl = __hiloint2double((2091 - E) << 20, 0);        // 2^(46 - f), f = E - 1022
             rs = __hiloint2double((E + 1) << 20, 0);                        // 2^f
+            // gradient calls: the weight-gradient kernel slices a 2^-f_n against dZ 2^f_n (one store per row and layer; rows
+            // beyond Nb to the dump area: the counted waits of the tile stream want the same stores from every lane group 0)
+            if constexpr (STASH) {
+                if (rowsc != nullptr && q == 0) (live ? rowsc + layer * rs_stride + (int64_t)b * a.Nb + nrow : dmp)[0] = rs;
+            }
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
                 v4i Bcur[NS];
@@ -1170,7 +1188,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd_u(WideArgs a, const doub
             }
             amax = 0.0;
         };
-        slice_rows();
+        slice_rows(0);
 
         // ---- hidden -> hidden layers
         double prt = 0.0;
@@ -1258,7 +1276,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd_u(WideArgs a, const doub
                 }
             };
             for_each_stage(tile, std::make_integer_sequence<int, TL>{});
-            if constexpr (!LAST) slice_rows();
+            if constexpr (!LAST) slice_rows(li + 1);
         };
         for (int li = 0; li < NHH - 1; ++li) hidden_layer(std::false_type{}, li);
         hidden_layer(std::true_type{}, NHH - 1);
@@ -1361,7 +1379,15 @@ size_t qn_i8_wide_workspace(const qn_desc* d, int B, int Nb, int want_grad) {
     if (want_grad)
         tot += qn_align((size_t)B * nhh * NS * h * h) + qn_align((size_t)B * nhh * h * sizeof(double)) + qn_align((size_t)B * sizeof(int)) +
                qn_align((size_t)B * a.nsplit * (h + 1) * sizeof(double));
+    // relu / identity: ... | the forward's per-row activation scales [nhh][B][Nb] for the weight-gradient kernel
+    if (want_grad && d->act != QN_ACT_TANH) tot += qn_align((size_t)nhh * B * Nb * sizeof(double));
     return tot;
+}
+double* qn_i8_wide_rowscale(const qn_desc* d, int B, int Nb, int want_grad, void* ws) {
+    if (!ws || !want_grad || !qn_i8_wide_applies(d) || d->act == QN_ACT_TANH) return nullptr;
+    const int nhh = d->nlayers - 2;
+    return reinterpret_cast<double*>(static_cast<char*>(ws) + qn_i8_wide_workspace(d, B, Nb, 1) -
+                                     qn_align((size_t)nhh * B * Nb * sizeof(double)));
 }
 // One launch: sse [B] (+ pred [B][Nb], dz_last [B][Nb] = 2 (pred - y), hidden activations act0 + l * act_stride
 // [B][h][Nb] for l = 0 .. L-2, each optional)
@@ -1408,7 +1434,7 @@ int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const
                         : (dp == 2 ? k_i8_wide_fwd<4, 2, QN_I8_LMIN, false> : k_i8_wide_fwd<4, 4, QN_I8_LMIN, false>);
     if (d->act != QN_ACT_TANH) {                                    // relu / identity: per-row activation scales
         using ufn = void (*)(WideArgs, const double*, const double*, const double*, const int32_t*, const unsigned char*,
-                             const double*, const int*, double*, double*, double*, double*, double*, int);
+                             const double*, const int*, double*, double*, double*, double*, double*, int, double*, int64_t);
         ufn ku;
         if (act0)
             ku = h == 128 ? (dp == 2 ? k_i8_wide_fwd_u<2, 2, QN_I8_LMIN, true> : k_i8_wide_fwd_u<2, 4, QN_I8_LMIN, true>)
@@ -1418,7 +1444,8 @@ int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const
                           : (dp == 2 ? k_i8_wide_fwd_u<4, 2, QN_I8_LMIN, false> : k_i8_wide_fwd_u<4, 4, QN_I8_LMIN, false>);
         if (int rc = wide_arm(reinterpret_cast<const void*>(ku), lds)) return rc;
         hipLaunchKernelGGL(ku, dim3(qn_fused_grid(a.nsplit, B)), dim3(WWG), lds, st, a, W, X, Y, row_idx,
-                           (const unsigned char*)Wd, (const double*)sb, (const int*)flags, act0, dz_last, pred, partial, dump, d->act);
+                           (const unsigned char*)Wd, (const double*)sb, (const int*)flags, act0, dz_last, pred, partial, dump, d->act,
+                           act0 ? qn_i8_wide_rowscale(d, B, Nb, 1, ws) : (double*)nullptr, (int64_t)B * Nb);
     } else {
         if (int rc = wide_arm(reinterpret_cast<const void*>(kern), lds)) return rc;
         hipLaunchKernelGGL(kern, dim3(qn_fused_grid(a.nsplit, B)), dim3(WWG), lds, st, a, W, X, Y, row_idx,
