@@ -583,10 +583,14 @@ def g12():
          cov_ini_diag=1e-5, param_ini=ini, chain=res["chain"], logpost=res["logpost"], alphas=res["alphas"],
          accrate=res["accrate"], mapparams=res["mapparams"], maxpost=res["maxpost"], uniforms=np.array(drawn), **sp)
     # viloss + gradients on a 128-wide network (the wide int8-slice kernels), S = 3
+    _viloss_fixture("g12_viloss.npz", act, 120, 202)
+
+
+def _viloss_fixture(name, act, torch_seed, data_seed):
     d, o, hls, N, S, prior = 2, 1, (128, 128), 200, 3, (0.5, 1.0, 1.0)
-    torch.manual_seed(120)
+    torch.manual_seed(torch_seed)
     net = MLP(d, o, hls, activ=act)
-    x, y = data(N, d, o, 0.05, 202)
+    x, y = data(N, d, o, 0.05, data_seed)
     bm = BNet(net, pi=prior[0], sigma1=prior[1], sigma2=prior[2])
     mu, rho = _bnet_flat(bm)
     datanoise, nb = 0.1, 2
@@ -601,10 +605,10 @@ def g12():
         torch.distributions.Normal.sample = orig
     loss.backward()
     dmu, drho = _bnet_grads(bm)
-    save("g12_viloss.npz", dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y, mu=mu, rho=rho, nsam=S,
+    save(name, dims=np.array((d,) + hls + (o,)), activ=np.array(act), x=x, y=y, mu=mu, rho=rho, nsam=S,
          datanoise=datanoise, num_batches=nb, prior=np.array(prior), eps_elbo=np.concatenate(drawn[:n_first]).reshape(S, -1),
          elbo_log_prior=lp.item(), elbo_log_q=lq.item(), elbo_nll=nll.item(),
-         eps_loss=np.concatenate(drawn[n_first:]).reshape(S, -1), loss=loss.item(), dmu=dmu, drho=drho, torch_seed=120)
+         eps_loss=np.concatenate(drawn[n_first:]).reshape(S, -1), loss=loss.item(), dmu=dmu, drho=drho, torch_seed=torch_seed)
 
 
 def g13():
@@ -618,7 +622,7 @@ def g13():
     d, o, hls, act, N, sigma = 1, 1, (64, 64, 64), "relu", 96, 0.2
     x, y = data(N, d, o, 0.05, 210)
     for name, kind, eps, L, nmcmc, seed in [("g13_relu_hmc.npz", "hmc", float(sys.argv[2]) if len(sys.argv) > 2 else 0.004, 3, 80, 21),
-                                            ("g13_relu_mala.npz", "mala", float(sys.argv[3]) if len(sys.argv) > 3 else 0.004, 1, 80, 22),
+                                            ("g13_relu_mala.npz", "mala", float(sys.argv[3]) if len(sys.argv) > 3 else 0.005, 1, 80, 22),
                                             ("g13_relu_amcmc.npz", "amcmc", 0.0, 0, 50, 23)]:
         if len(sys.argv) > 4 and sys.argv[4] not in name:
             continue
@@ -653,3 +657,5 @@ if __name__ == "__main__" and "g12" in sys.argv[1:]:
     g12()
 if __name__ == "__main__" and "g13" in sys.argv[1:2]:
     g13()
+if __name__ == "__main__" and "g13_viloss" in sys.argv[1:2]:
+    _viloss_fixture("g13_relu_viloss.npz", "relu", 130, 212)     # (the wide int8-slice kernels with per-row activation scales)

@@ -153,10 +153,12 @@ def test_g13_relu_amcmc_on_padded_40_wide(kernels, arith):
     np.testing.assert_allclose(solver.mcmc_results["logpost"][0], g["logpost"], rtol=1e-9)
 
 
-def test_g12_viloss_on_2x128():
+@pytest.mark.parametrize("name", ["g12_viloss.npz", "g13_relu_viloss.npz"])
+def test_g12_viloss_on_2x128(name):
     import torch
     from quinn_amd.vi.bnet import BNet
-    g = load_golden("g12_viloss.npz")
+    g = load_golden(name)
+    assert str(g["activ"]) == ("relu" if "relu" in name else "tanh")
     for kernels, want in (("auto", _lib.ARITH_I8_WIDE), ("float64", _lib.ARITH_PLAIN)):
         bm = BNet(_net(g), pi=float(g["prior"][0]), sigma1=float(g["prior"][1]), sigma2=float(g["prior"][2]))
         with torch.no_grad():
@@ -179,7 +181,7 @@ def test_g12_viloss_on_2x128():
         p = bm.p
         sc = max(np.abs(g["dmu"]).max(), np.abs(g["drho"]).max())
         e = max(np.abs(gr[:p] - g["dmu"]).max(), np.abs(gr[p:] - g["drho"]).max()) / sc
-        print(f"g12_viloss kernels={kernels}: max gradient error / max|g| = {e:.2e}")
+        print(f"{name} kernels={kernels}: max gradient error / max|g| = {e:.2e}")
         assert e <= 1e-10
 
 

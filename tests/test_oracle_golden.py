@@ -282,8 +282,9 @@ def test_g13_relu_amcmc_p1761_before_adaptation():
     _check_g12_chain(res, g)
 
 
-def test_g12_viloss_2x128():
-    g = load_golden("g12_viloss.npz")
+@pytest.mark.parametrize("name", ["g12_viloss.npz", "g13_relu_viloss.npz"])
+def test_g12_viloss_2x128(name):
+    g = load_golden(name)
     spec = spec_of(g)
     pr = dict(pi=float(g["prior"][0]), sigma1=float(g["prior"][1]), sigma2=float(g["prior"][2]))
     r = vi_ref.viloss(spec, g["mu"], g["rho"], g["eps_elbo"], g["x"], g["y"], float(g["datanoise"]), int(g["num_batches"]),
