@@ -126,9 +126,12 @@ def graph_rate(fn, dev, settle_ms=300.0, regions=5, min_region_ms=20.0):
 
 
 # the other BASELINE configurations at the sizes of tools/bench_configs.py (parity-test cases, not bench lines)
-EXTRA_CFGS = (("cfg3_3x128_N8192_S128", (2, 128, 128, 128, 1), 8192, 128),
-              ("cfg4_4x256_N16384_M64", (1, 256, 256, 256, 256, 1), 16384, 64),
-              ("cfg5_4x256_N32768_C32", (1, 256, 256, 256, 256, 1), 32768, 32))
+EXTRA_CFGS = (("cfg3_3x128_N8192_S128", (2, 128, 128, 128, 1), 8192, 128, "tanh"),
+              ("cfg4_4x256_N16384_M64", (1, 256, 256, 256, 256, 1), 16384, 64, "tanh"),
+              ("cfg5_4x256_N32768_C32", (1, 256, 256, 256, 256, 1), 32768, 32, "tanh"),
+              # the reference's DEFAULT activation (quinn/nns/mlp.py:23) at the cfg2 / cfg3 shapes: int8 slices with per-row scales
+              ("relu_3x64_N4096_C64", (1, 64, 64, 64, 1), 4096, 64, "relu"),
+              ("relu_3x128_N8192_S128", (2, 128, 128, 128, 1), 8192, 128, "relu"))
 
 
 def extras(op, arch, batches, args):
@@ -197,8 +200,8 @@ def extras(op, arch, batches, args):
         out["amcmc_adapting_accrate"] = float(r["accrate"].mean())
         del eng, r
         torch.cuda.empty_cache()
-        for name, dims, n_rows, nb in EXTRA_CFGS:
-            a2 = MLPArch(dims, "tanh")
+        for name, dims, n_rows, nb, act2 in EXTRA_CFGS:
+            a2 = MLPArch(dims, act2)
             x2, y2 = synthetic(n_rows, dims[0])
             op2 = BatchedMLP(a2, x2, y2, device=dev)
             W2 = op2.weights(0.1 * np.random.RandomState(7).randn(nb, a2.nparams))

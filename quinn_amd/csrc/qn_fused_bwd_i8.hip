@@ -41,6 +41,21 @@
 
 namespace {
 
+// Slot swizzle of this kernel's digit planes AND transposition stashes: slot_swz (qn_i8_slice.h: rows of equal R & 3 in distinct
+// slots -> conflict-free ds_read_b128 fragments), optionally with one more bit, R >> 1 & 1 (QN_BWD_STASH_SWZ = 1).
+// Where this kernel's 12.6 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE come from (rounds 3 and 4 could not place them): a ds_write_b32
+// is banked (a / 4) % 32 within each 32-lane half (every ds_write; the b128 reads: % 64 per 16-lane group), and under slot_swz
+// alone the stash rows R and R + 2 of a half-wave meet on one bank -- 2-way on EVERY transposed stash write (1.57 M writes x 2 extra
+// cycles = the 3.1 M conflict cycles per launch above the forward kernel's 0.24 M of tanh-table lookups).  The extra bit removes them
+// (measured: 3.38 M -> 0.237 M, 12.6 % -> 1.0 %; it is constant over the rows a staging half-wave writes and over each read group's
+// rows of equal R & 3, so those stay conflict-free) -- and the launch gets 0.6 % SLOWER in the same call (219.4 -> 220.7 us, twice,
+// tools/ab_bwd_stash_swz.sh): the LDS is not what this kernel waits for (vector issue is), and the writes' second cycle was hidden.
+// Kept as an A/B switch, default off.
+#ifndef QN_BWD_STASH_SWZ
+#define QN_BWD_STASH_SWZ 0
+#endif
+__device__ __forceinline__ int bwd_swz(int row) { return slot_swz(row) ^ (QN_BWD_STASH_SWZ ? (row >> 1) & 1 : 0); }
+
 constexpr int BWG = 256;
 
 #ifdef QN_BWD8_STAMPS
@@ -286,7 +301,7 @@ __device__ __forceinline__ int stage_bwd(double* __restrict__ lds, unsigned char
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int row = 16 * u + 4 * wave + (lane >> 4);
-                unsigned char* dst = plane + row * H + 16 * (g4 ^ slot_swz(row)) + 4 * m4;
+                unsigned char* dst = plane + row * H + 16 * (g4 ^ bwd_swz(row)) + 4 * m4;
 #pragma unroll
                 for (int k = 0; k < NS; ++k) *reinterpret_cast<int*>(dst + k * SLICE_BYTES) = S[u][k];
                 if (q16 == 0) {
@@ -364,9 +379,9 @@ __global__ __launch_bounds__(BWG, 1) void k_fused_bwd_i8(FusedArgs a, const doub
         return;
     }
     QN_STAMP(10);
-    const int lofs = c * H + 16 * (q ^ slot_swz(c));                    // this lane's 16 bytes inside a 16-row tile of a plane
+    const int lofs = c * H + 16 * (q ^ bwd_swz(c));                     // this lane's 16 bytes inside a 16-row tile of a plane / stash
     // stash write: this lane's transposed word = feature 16 t + 4 q + (c & 3) of rows 16 wave + 4 (c >> 2) .. + 3
-    const int wofs = (4 * q + (c & 3)) * H + 16 * (wave ^ slot_swz(4 * q)) + 4 * (c >> 2);
+    const int wofs = (4 * q + (c & 3)) * H + 16 * (wave ^ bwd_swz(4 * q + (c & 3))) + 4 * (c >> 2);
     const int selA = (c & 1) ? 0x03070105 : 0x06020400, selB = (c & 2) ? 0x03020706 : 0x05040100;
     int bad_run = 0;
     double sse = 0.0;
