@@ -43,7 +43,9 @@ class Tick:
     """wall-clock at every 1000 steps (the engine prints there when verbose)"""
     def write(self, s):
         if "completed" in s:
-            torch.cuda.synchronize(); marks.append(time.perf_counter())
+            # (the engine prints from the thread that enqueues chain group 0, inside that group's stream context: wait for THAT
+            # stream only -- a device-wide wait would also wait for whatever the other group's thread keeps enqueuing)
+            torch.cuda.current_stream().synchronize(); marks.append(time.perf_counter())
     def flush(self):
         pass
 
