@@ -719,10 +719,10 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                     // (sliced int8 products, qn_dw_i8.hip; K-slabs in whole 64-row chunks)
                     if (wide_bwd && i8_dw_ok) {
                         const int kc64 = ((Nb + ks - 1) / ks + 63) / 64 * 64;
-                        if (int rc = qn_i8_dw(g.h_in, g.h_out, d->has_bias, dz, act[l - 1], B, Nb, dst, g.out_stride_b,
-                                              g.out_stride_k, ks, kc64, rowsc ? rowsc + (int64_t)(l - 1) * B * Nb : nullptr, st))
-                            return rc;
-                        dw_done = true;
+                        const int rc = qn_i8_dw(g.h_in, g.h_out, d->has_bias, dz, act[l - 1], B, Nb, dst, g.out_stride_b,
+                                                g.out_stride_k, ks, kc64, rowsc ? rowsc + (int64_t)(l - 1) * B * Nb : nullptr, st);
+                        if (rc == QN_OK) dw_done = true;
+                        else if (!(rc == QN_EUNSUPPORTED && rowsc)) return rc;      // (row scales in a build without the group-scale kernel: the float64 product below)
                     }
 #endif
                 }
