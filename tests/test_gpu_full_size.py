@@ -40,7 +40,7 @@ def _check(arch, N, B, d, spot=1):
     sp = op.sse(W[:1] + e * v).item(); sm = op.sse(W[:1] - e * v).item()
     fd, an = (sp - sm) / (2 * e), float(g1[0].cpu().numpy() @ v)
     assert abs(fd - an) <= 1e-5 * max(1.0, abs(an))
-    mod = mlp_ref.build_module(mlp_ref.MLPSpec(arch.dims, "tanh"))
+    mod = mlp_ref.build_module(mlp_ref.MLPSpec(arch.dims, arch.activ))
     for b in range(spot):
         ref = mlp_ref.sse(mod, W[b], x, y)
         assert abs(s1[b].item() - ref) <= 1e-11 * ref
@@ -48,6 +48,18 @@ def _check(arch, N, B, d, spot=1):
 
 def test_cfg3_vi_shape_full_size():        # 128 MC samples, 3x128, N=8192, d=2
     _check(MLPArch((2, 128, 128, 128, 1), "tanh"), 8192, 128, 2)
+
+
+def test_cfg3_shape_full_size_relu():      # the reference's default activation on the same shape (row-scale int8 kernels, round 4)
+    from quinn_amd import _lib
+    arch = MLPArch((2, 128, 128, 128, 1), "relu")
+    x, y = mlp_ref.synthetic_data(64, 2, 0.02, seed=0)
+    assert BatchedMLP(arch, x, y).arith(128, 8192, True) == _lib.ARITH_I8_WIDE
+    _check(arch, 8192, 128, 2)
+
+
+def test_cfg2_shape_full_size_relu():      # 64 chains, 3x64, N=4096: the fused int8-slice kernels with row scales
+    _check(MLPArch((1, 64, 64, 64, 1), "relu"), 4096, 64, 1, spot=2)
 
 
 def test_cfg4_ensemble_shape_full_size():  # 512 members, 4x256, N=16384 (workspace is chunked over members)
