@@ -132,6 +132,9 @@ int qn_i8_wide_backward(const qn_desc* d, const double* W, const double* X, cons
 // of a relu / identity network leaves them (qn_i8_wide_rowscale); with it, row counts in whole 64-row chunks only
 int qn_i8_dw(int h_in, int h_out, int has_bias, const double* dz, const double* a_prev, int B, int Nb, double* dst,
              int64_t out_stride_b, int64_t out_stride_k, int ksplit, int kchunk, const double* rowsc, hipStream_t st);
+// the last Nb % 64 rows of the same product in float64, added to the finished gradient block (after the split-K reduction)
+int qn_i8_dw_tail(int h_in, int h_out, int has_bias, const double* dz, const double* a_prev, int B, int Nb, double* G, int64_t p,
+                  hipStream_t st);
 // relu / identity networks, gradient calls: the forward's per-row activation scales [L-2 layers][B][Nb] inside its workspace
 // (layer l = the scales of act0 + l * act_stride); null for tanh networks / forward-only workspaces
 double* qn_i8_wide_rowscale(const qn_desc* d, int B, int Nb, int want_grad, void* ws);

@@ -692,7 +692,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         if constexpr (std::is_same<T, double>::value) {
             if (wide_bwd) {
                 rowsc = qn_i8_wide_rowscale(d, B, Nb, 1, wide_ws);
-                i8_dw_ok = d->act == QN_ACT_TANH || (rowsc != nullptr && Nb % 64 == 0);
+                i8_dw_ok = d->act == QN_ACT_TANH || (rowsc != nullptr && Nb >= 64);
 #ifdef QN_DW_UNB_OFF
                 i8_dw_ok = d->act == QN_ACT_TANH;                        // (A/B)
 #endif
@@ -734,6 +734,11 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                     if (gx > 64) gx = 64;
                     hipLaunchKernelGGL(k_slab_reduce<T>, dim3(gx, B), dim3(BLK), 0, st, (const T*)dwslab, ks, nW, d->p,
                                        d->offW[l], gradW);
+                }
+                if constexpr (std::is_same<T, double>::value) {
+                    if (dw_done)            // (the int8 kernel took the whole 64-row chunks: the last Nb % 64 rows in float64)
+                        if (int rc = qn_i8_dw_tail(g.h_in, g.h_out, d->has_bias, dz, act[l - 1], B, Nb, gradW + d->offW[l], d->p, st))
+                            return rc;
                 }
                 if (wide_bwd) continue;
                 T* dzp = dzbuf[l & 1];

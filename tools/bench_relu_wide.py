@@ -9,7 +9,8 @@ import bench
 from quinn_amd import _lib
 from quinn_amd.ops import MLPArch, BatchedMLP
 dev = torch.device("cuda")
-for dims, N, B in (((2, 128, 128, 128, 1), 8192, 128), ((1, 256, 256, 256, 256, 1), 16384, 64)):
+RAGGED = int(os.environ.get("RAGGED", "0"))        # rows taken off each size: an odd / ragged row count (the int8 weight gradient + float64 tail)
+for dims, N, B in (((2, 128, 128, 128, 1), 8192 - RAGGED, 128), ((1, 256, 256, 256, 256, 1), 16384 - RAGGED, 64)):
     x, y = bench.synthetic(N, dims[0])
     for act in ("tanh", "relu", "identity"):
         arch = MLPArch(dims, act)
