@@ -39,6 +39,7 @@ constexpr int DW_BUF = 2 * DW_OPER + 64 * (int)sizeof(double);      // + the chu
 struct DwArgs {
     int64_t out_stride_b, out_stride_k;
     int h_in, h_out, Nb, has_bias, kchunk;                // kchunk: rows per K-slab
+    int Ns;                                               // row stride of both operands [B][h][Ns] (>= Nb)
     int nmain;                                            // k_i8_dw_g: rows it covers = Nb rounded down to whole 64-row chunks (the rest: k_dw_tail)
     int inner, outer_total, per_b;                        // XCD-aware 1-D grid as gemm_grid() of qn_generic.hip
 };
@@ -58,8 +59,9 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
     const int j0 = (inner_i / tiles_i) * 64, i0 = (inner_i % tiles_i) * 64;
     const int Nb = g.Nb, kbeg = slab * g.kchunk, kend = kbeg + g.kchunk < Nb ? kbeg + g.kchunk : Nb;
     const int nchunks = (kend - kbeg + 63) / 64;
-    const double* Z = dz + ((int64_t)b * g.h_out + j0) * Nb;
-    const double* A = ap + ((int64_t)b * g.h_in + i0) * Nb;
+    const int64_t Ns = g.Ns;
+    const double* Z = dz + ((int64_t)b * g.h_out + j0) * Ns;
+    const double* A = ap + ((int64_t)b * g.h_in + i0) * Ns;
     double* O = out + (int64_t)b * g.out_stride_b + (int64_t)slab * g.out_stride_k;
     int* badflag = reinterpret_cast<int*>(smemd + 2 * DW_BUF);
     if (tid == 0) *badflag = 0;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
             typedef double d2u_ __attribute__((ext_vector_type(2), aligned(8)));
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const d2u_* sp = reinterpret_cast<const d2u_*>(base + (int64_t)(16 * u + fl_) * Nb + c0 + 2 * q16_);
+                const d2u_* sp = reinterpret_cast<const d2u_*>(base + (int64_t)(16 * u + fl_) * Ns + c0 + 2 * q16_);
                 const d2u_ v01 = sp[0], v23 = sp[16];
                 v[u][0] = v01.x; v[u][1] = v01.y; v[u][2] = v23.x; v[u][3] = v23.y;
             }
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = c0 + 32 * (r >> 1) + 2 * q16_ + (r & 1);
-                    v[u][r] = n < kend ? base[(int64_t)(16 * u + fl_) * Nb + n] : 0.0;
+                    v[u][r] = n < kend ? base[(int64_t)(16 * u + fl_) * Ns + n] : 0.0;
                 }
         }
     };
@@ -308,10 +310,10 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw(DwArgs g, const double* __rest
         const int jl = tid >> 3, ib = (tid & 7) * 8;
         double s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb = 0.0;
         for (int n = kbeg; n < kend; ++n) {
-            const double zv = Z[(int64_t)jl * Nb + n];
+            const double zv = Z[(int64_t)jl * Ns + n];
             sb += zv;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s[u] = fma(zv, A[(int64_t)(ib + u) * Nb + n], s[u]);
+            for (int u = 0; u < 8; ++u) s[u] = fma(zv, A[(int64_t)(ib + u) * Ns + n], s[u]);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) O[(int64_t)(j0 + jl) * g.h_in + i0 + ib + u] = s[u];
@@ -363,8 +365,9 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __re
     const int j0 = (inner_i / tiles_i) * 64, i0 = (inner_i % tiles_i) * 64;
     const int Nb = g.Nb, kbeg = slab * g.kchunk, kend = kbeg + g.kchunk < g.nmain ? kbeg + g.kchunk : g.nmain;     // (Nb: the row stride)
     const int nchunks = (kend - kbeg + 63) / 64, npad = (nchunks + GC - 1) / GC * GC;
-    const double* Z = dz + ((int64_t)b * g.h_out + j0) * Nb;
-    const double* A = ap + ((int64_t)b * g.h_in + i0) * Nb;
+    const int64_t Ns = g.Ns;
+    const double* Z = dz + ((int64_t)b * g.h_out + j0) * Ns;
+    const double* A = ap + ((int64_t)b * g.h_in + i0) * Ns;
     double* O = out + (int64_t)b * g.out_stride_b + (int64_t)slab * g.out_stride_k;
     double* ring = reinterpret_cast<double*>(smemd + 2 * DWG_BUF);
     double* faccs = reinterpret_cast<double*>(smemd + 2 * DWG_BUF + DWG_RING);
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __re
         const int c0 = kbeg + 64 * ch;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const d2u_* sp = reinterpret_cast<const d2u_*>(base + (int64_t)(16 * u + fl_) * Nb + c0 + 2 * q16_);
+            const d2u_* sp = reinterpret_cast<const d2u_*>(base + (int64_t)(16 * u + fl_) * Ns + c0 + 2 * q16_);
             const d2u_ v01 = sp[0], v23 = sp[16];
             v[u][0] = v01.x; v[u][1] = v01.y; v[u][2] = v23.x; v[u][3] = v23.y;
         }
@@ -735,10 +738,10 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __re
         const int jl = tid >> 3, ib = (tid & 7) * 8;
         double s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb = 0.0;
         for (int n = kbeg; n < kend; ++n) {
-            const double zv = Z[(int64_t)jl * Nb + n];
+            const double zv = Z[(int64_t)jl * Ns + n];
             sb += zv;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s[u] = fma(zv, A[(int64_t)(ib + u) * Nb + n], s[u]);
+            for (int u = 0; u < 8; ++u) s[u] = fma(zv, A[(int64_t)(ib + u) * Ns + n], s[u]);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) O[(int64_t)(j0 + jl) * g.h_in + i0 + ib + u] = s[u];
@@ -749,14 +752,14 @@ __global__ __launch_bounds__(DWT, 1) void k_i8_dw_g(DwArgs g, const double* __re
 // The last Nb % 64 rows, which k_i8_dw_g leaves out, in plain float64, ADDED to the finished gradient block of the layer
 // (G + b * p: [h_out x h_in] weights, h_out bias sums behind them): workgroup = one 64 x 64 tile of one chain, both operands' tail
 // rows through LDS, thread (jl, ig) = outputs (jl, 16 ig .. 16 ig + 15).  r <= 63 rows: ~10 us at the cfg3 shape.
-__global__ __launch_bounds__(256) void k_dw_tail(int h_in, int h_out, int Nb, int n0, int has_bias, const double* __restrict__ dz,
+__global__ __launch_bounds__(256) void k_dw_tail(int h_in, int h_out, int Nb, int Ns, int n0, int has_bias, const double* __restrict__ dz,
                                                  const double* __restrict__ ap, double* __restrict__ G, int64_t p) {
     __shared__ double zt[64][65], at[64][65];
     const int b = blockIdx.z, j0 = blockIdx.y * 64, i0 = blockIdx.x * 64, r = Nb - n0, tid = threadIdx.x;
     for (int e = tid; e < 64 * r; e += 256) {
         const int f = e / r, n = e - f * r;
-        zt[f][n] = dz[((int64_t)b * h_out + j0 + f) * Nb + n0 + n];
-        at[f][n] = ap[((int64_t)b * h_in + i0 + f) * Nb + n0 + n];
+        zt[f][n] = dz[((int64_t)b * h_out + j0 + f) * Ns + n0 + n];
+        at[f][n] = ap[((int64_t)b * h_in + i0 + f) * Ns + n0 + n];
     }
     __syncthreads();
     const int jl = tid >> 2, ig = tid & 3;
@@ -779,28 +782,28 @@ __global__ __launch_bounds__(256) void k_dw_tail(int h_in, int h_out, int Nb, in
 
 // The rows k_i8_dw_g left out of a layer's weight gradient (Nb % 64 of them), added to the finished block G [B][p] + offset:
 // call it AFTER the split-K reduction of the layer.  Returns QN_OK (also when there is nothing to do).
-int qn_i8_dw_tail(int h_in, int h_out, int has_bias, const double* dz, const double* a_prev, int B, int Nb, double* G, int64_t p,
+int qn_i8_dw_tail(int h_in, int h_out, int has_bias, const double* dz, const double* a_prev, int B, int Nb, int Ns, double* G, int64_t p,
                   hipStream_t st) {
-    if (h_in % 64 || h_out % 64) return QN_EUNSUPPORTED;
+    if (h_in % 64 || h_out % 64 || Ns < Nb) return QN_EUNSUPPORTED;
     const int n0 = Nb - Nb % 64;
     if (Nb < 64 || n0 == Nb) return QN_OK;                   // (fewer than 64 rows: k_i8_dw took them all)
 #ifdef QN_DW_RAGGED_OLD                                      // (A/B: ragged row counts on the per-chunk kernel k_i8_dw, as until round 4)
     return QN_OK;
 #endif
-    hipLaunchKernelGGL(k_dw_tail, dim3(h_in / 64, h_out / 64, B), dim3(256), 0, st, h_in, h_out, Nb, n0, has_bias, dz, a_prev, G, p);
+    hipLaunchKernelGGL(k_dw_tail, dim3(h_in / 64, h_out / 64, B), dim3(256), 0, st, h_in, h_out, Nb, Ns, n0, has_bias, dz, a_prev, G, p);
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }
 
 // dst + b * out_stride_b + slab * out_stride_k receives [h_out x h_in] weights (+ h_out bias sums behind them): the
 // conventions of k_gemm64<DW> (qn_generic.hip), whose split-K slabs and reduction kernel the caller keeps
-int qn_i8_dw(int h_in, int h_out, int has_bias, const double* dz, const double* a_prev, int B, int Nb, double* dst,
+int qn_i8_dw(int h_in, int h_out, int has_bias, const double* dz, const double* a_prev, int B, int Nb, int Ns, double* dst,
              int64_t out_stride_b, int64_t out_stride_k, int ksplit, int kchunk, const double* rowsc, hipStream_t st) {
-    if (h_in % 64 || h_out % 64) return QN_EUNSUPPORTED;
+    if (h_in % 64 || h_out % 64 || Ns < Nb) return QN_EUNSUPPORTED;
     if (rowsc && (QN_DW_GROUP < 2 || Nb < 64 || kchunk % 64)) return QN_EUNSUPPORTED;      // (row scales: the group-scale kernel only)
     DwArgs g;
     g.out_stride_b = out_stride_b; g.out_stride_k = out_stride_k; g.h_in = h_in; g.h_out = h_out; g.Nb = Nb;
-    g.has_bias = has_bias; g.kchunk = kchunk; g.nmain = Nb - Nb % 64;
+    g.has_bias = has_bias; g.kchunk = kchunk; g.nmain = Nb - Nb % 64; g.Ns = Ns;
     g.inner = (h_in / 64) * (h_out / 64); g.per_b = ksplit; g.outer_total = ksplit * B;
     const unsigned grid = (unsigned)(((g.outer_total + 7) / 8) * 8 * g.inner);
     // group scales (k_i8_dw_g) for row counts in whole chunks; the per-chunk kernel (partial chunks, odd row counts) otherwise

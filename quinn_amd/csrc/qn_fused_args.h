@@ -119,21 +119,23 @@ int qn_i8_layers_forward(const qn_desc* d, const double* W, const double* X, con
 // whole forward pass (sse, optional pred / dz_last = 2 (pred - y) / float64 hidden activations act0 + l * act_stride)
 bool qn_i8_wide_applies(const qn_desc* d);
 size_t qn_i8_wide_workspace(const qn_desc* d, int B, int Nb, int want_grad);
+// (Ns >= Nb: the row stride of the stashes [B][h][Ns] -- activations here, dZ in the backward: qn_generic.hip pads it to whole
+// 128-byte lines)
 int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const double* Y, const int32_t* row_idx, int B,
-                       int Nb, double* act0, int64_t act_stride, double* dz_last, double* pred, double* sse, void* ws,
+                       int Nb, double* act0, int64_t act_stride, int Ns, double* dz_last, double* pred, double* sse, void* ws,
                        hipStream_t st);
 // the backward pass through the hidden layers of the same networks: dZ_l (float64 [B][h][Nb] at dz0 + l * dz_stride,
 // l = 0 .. L-2) from the stashed activations and dz_last; same workspace as the forward call of the evaluation
 int qn_i8_wide_backward(const qn_desc* d, const double* W, const double* X, const int32_t* row_idx, int B, int Nb,
-                        const double* act0, int64_t act_stride, const double* dz_last, double* dz0, int64_t dz_stride, void* ws,
+                        const double* act0, int64_t act_stride, int Ns, const double* dz_last, double* dz0, int64_t dz_stride, void* ws,
                         double* gradW, int* last_done, hipStream_t st);
 // weight gradient of a hidden->hidden layer as sliced int8 products (qn_dw_i8.hip): output conventions of k_gemm64<DW>
 // rowsc (may be null: tanh, activations in [-1, 1]): [B][Nb] scales 2^f_n > every |a_prev[.][n]| of data row n, as the forward
 // of a relu / identity network leaves them (qn_i8_wide_rowscale); with it, row counts in whole 64-row chunks only
-int qn_i8_dw(int h_in, int h_out, int has_bias, const double* dz, const double* a_prev, int B, int Nb, double* dst,
+int qn_i8_dw(int h_in, int h_out, int has_bias, const double* dz, const double* a_prev, int B, int Nb, int Ns, double* dst,
              int64_t out_stride_b, int64_t out_stride_k, int ksplit, int kchunk, const double* rowsc, hipStream_t st);
 // the last Nb % 64 rows of the same product in float64, added to the finished gradient block (after the split-K reduction)
-int qn_i8_dw_tail(int h_in, int h_out, int has_bias, const double* dz, const double* a_prev, int B, int Nb, double* G, int64_t p,
+int qn_i8_dw_tail(int h_in, int h_out, int has_bias, const double* dz, const double* a_prev, int B, int Nb, int Ns, double* G, int64_t p,
                   hipStream_t st);
 // relu / identity networks, gradient calls: the forward's per-row activation scales [L-2 layers][B][Nb] inside its workspace
 // (layer l = the scales of act0 + l * act_stride); null for tanh networks / forward-only workspaces

@@ -40,6 +40,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 struct LayerArgs {
     int64_t p, offW, offB;
     int has_bias, h_in, h_out, act, Nb, first, d, o;
+    int Nsz, Nsa;   // k_dW: row strides of dz [B][h_out][Nsz] and a_prev [B][h_in][Nsa] (= Nb except for the padded stashes of the wide int8 path)
     int eye;        // the layer is the identity map (a residual network without pre / post layer): COPY the input -- a product
                     // with an identity matrix turns an infinite input into NaN (0 . Inf) where the reference passes it on
 };
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(BLK) void k_dW(LayerArgs a, const T* __restrict__ d
         T g[TJ], v[TK];
 #pragma unroll
         for (int jj = 0; jj < TJ; ++jj)
-            g[jj] = (j0 + jj < a.h_out) ? dz[((int64_t)b * a.h_out + j0 + jj) * a.Nb + n] : T(0);
+            g[jj] = (j0 + jj < a.h_out) ? dz[((int64_t)b * a.h_out + j0 + jj) * a.Nsz + n] : T(0);
         if (a.first) {
             int64_t row = n;
             if (row_idx) row = row_idx[(int64_t)b * a.Nb + n];
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(BLK) void k_dW(LayerArgs a, const T* __restrict__ d
         } else {
 #pragma unroll
             for (int kk = 0; kk < TK; ++kk)
-                v[kk] = (k0 + kk < a.h_in) ? a_prev[((int64_t)b * a.h_in + k0 + kk) * a.Nb + n] : T(0);
+                v[kk] = (k0 + kk < a.h_in) ? a_prev[((int64_t)b * a.h_in + k0 + kk) * a.Nsa + n] : T(0);
         }
 #pragma unroll
         for (int jj = 0; jj < TJ; ++jj) {
@@ -539,6 +540,10 @@ __global__ __launch_bounds__(BLK) void k_slab_reduce(const T* __restrict__ slab,
     }
 }
 
+#if defined(QN_NO_I8_WIDE) || defined(QN_NO_I8_WIDE_BWD) || defined(QN_NO_I8_DW) || defined(QN_DW_UNB_OFF)
+#define QN_NO_STASH_PAD               // (A/B builds that send part of the wide gradient through the layer-wise kernels: those take no stride)
+#endif
+inline int wide_stash_stride(int Nb) { return (Nb + 15) / 16 * 16; }
 inline bool gemm_layer(const qn_desc* d, int l) {
     return l >= 1 && l + 1 < d->nlayers && d->dims[l] % 64 == 0 && d->dims[l + 1] % 64 == 0;
 }
@@ -573,18 +578,28 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
     const bool grad = gradW != nullptr;
     (void)hipGetLastError();   // drop any stale error of this thread before our launches
     Carve c{static_cast<char*>(ws), 0, ws_bytes};
+    // Row stride of the activation / dZ stashes [B][h][Ns].  The gradient of the wide int8 path (qn_wide_i8.hip, qn_dw_i8.hip: every
+    // kernel that touches them takes the stride) pads it to a multiple of 16 rows: a feature's rows then start on a 128-byte line
+    // whatever the row count -- an unpadded odd count cost those kernels ~12 %, one that is not a multiple of 16 ~5 %
+    // (profiles/r04_ragged_rows_dw_ab.txt).  From 64 rows on, where the hidden matrices' weight gradient is the int8 kernel's.
+    int Ns = Nb;
+    if constexpr (std::is_same<T, double>::value) {
+#ifndef QN_NO_STASH_PAD
+        if (grad && Nb >= 64 && d->path == QN_PATH_AUTO && qn_i8_wide_applies(d)) Ns = wide_stash_stride(Nb);
+#endif
+    }
     std::vector<T*> act(L, nullptr);            // act[l] = output of layer l (l < L-1)
-    for (int l = 0; l + 1 < L; ++l) act[l] = c.take<T>((size_t)B * d->dims[l + 1] * Nb);
+    for (int l = 0; l + 1 < L; ++l) act[l] = c.take<T>((size_t)B * d->dims[l + 1] * Ns);
     T* dz_last = grad ? c.take<T>((size_t)B * d->dims[L] * Nb) : nullptr;
     T* dzbuf[2] = {nullptr, nullptr};
     if (grad && L > 1) {
-        dzbuf[0] = c.take<T>((size_t)B * d->hmax * Nb);
-        dzbuf[1] = c.take<T>((size_t)B * d->hmax * Nb);
+        dzbuf[0] = c.take<T>((size_t)B * d->hmax * Ns);
+        dzbuf[1] = c.take<T>((size_t)B * d->hmax * Ns);
         // the fused int8-slice backward writes dZ of EVERY hidden layer before the weight-gradient kernels run: L - 1
         // consecutive buffers, the two above being the first
         if constexpr (std::is_same<T, double>::value)
             if (qn_i8_wide_applies(d))
-                for (int l = 2; l < L - 1; ++l) c.take<T>((size_t)B * d->hmax * Nb);
+                for (int l = 2; l < L - 1; ++l) c.take<T>((size_t)B * d->hmax * Ns);
     }
     const int nblk = (Nb + BLK - 1) / BLK;
     double* partial = c.take<double>((size_t)B * nblk);
@@ -628,7 +643,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         LayerArgs a;
         a.p = d->p; a.offW = d->offW[l]; a.offB = d->offB[l]; a.has_bias = d->has_bias;
         a.h_in = d->dims[l]; a.h_out = d->dims[l + 1]; a.act = d->act; a.Nb = Nb; a.first = (l == 0);
-        a.d = d->dims[0]; a.o = d->dims[L]; a.eye = 0;
+        a.d = d->dims[0]; a.o = d->dims[L]; a.eye = 0; a.Nsz = Nb; a.Nsa = Nb;
         return a;
     };
     auto gargs = [&](int l) {
@@ -641,7 +656,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
     if constexpr (std::is_same<T, double>::value) {
         if (wide) {
             // activations are written only for the backward pass; act[l] are consecutive, equally sized blocks
-            if (int rc = qn_i8_wide_forward(d, W, X, Y, row_idx, B, Nb, grad ? act[0] : nullptr, act[1] - act[0], dz_last,
+            if (int rc = qn_i8_wide_forward(d, W, X, Y, row_idx, B, Nb, grad ? act[0] : nullptr, act[1] - act[0], Ns, dz_last,
                                             pred, sse, wide_ws, st))
                 return rc;
         } else if (i8_fwd) {
@@ -674,19 +689,19 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         // fused int8-slice backward through the hidden layers (qn_wide_i8.hip): dZ_l of every hidden layer in one launch
         bool wide_bwd = false;
         int last_done = 0;                                   // the output layer's weight gradient came out of the fused backward (h = 128)
-        const int64_t dz_stride = (int64_t)(qn_align((size_t)B * d->hmax * Nb * sizeof(T)) / sizeof(T));
+        const int64_t dz_stride = (int64_t)(qn_align((size_t)B * d->hmax * Ns * sizeof(T)) / sizeof(T));
         if constexpr (std::is_same<T, double>::value) {
 #ifndef QN_NO_I8_WIDE_BWD
             wide_bwd = wide;
 #endif
             if (wide_bwd) {
-                if (int rc = qn_i8_wide_backward(d, W, X, row_idx, B, Nb, act[0], act[1] - act[0], dz_last, dzbuf[0], dz_stride,
+                if (int rc = qn_i8_wide_backward(d, W, X, row_idx, B, Nb, act[0], act[1] - act[0], Ns, dz_last, dzbuf[0], dz_stride,
                                                  wide_ws, gradW, &last_done, st))
                     return rc;
             }
         }
         // the hidden matrices' weight gradient as sliced int8 products (qn_dw_i8.hip): tanh networks; relu / identity ones through
-        // the forward's row scales, for row counts in whole 64-row chunks (else the float64-MFMA product below)
+        // the forward's row scales, from 64 rows on (else the float64-MFMA product below)
         const double* rowsc = nullptr;
         bool i8_dw_ok = false;
         if constexpr (std::is_same<T, double>::value) {
@@ -701,6 +716,10 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
         for (int l = L - 1; l >= 0; --l) {
             LayerArgs a = largs(l);
             if (wide_bwd && l < L - 1) dz = dzbuf[0] + (int64_t)l * dz_stride;
+            if (wide_bwd) {                                      // (k_dW of the thin layers: the stashes' row stride; dz_last is [B][o][Nb])
+                a.Nsa = Ns;
+                if (l < L - 1) a.Nsz = Ns;
+            }
             if (l == L - 1 && last_done) continue;
             if (gemm_layer(d, l)) {
                 GemmArgs g = gargs(l);
@@ -719,10 +738,10 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                     // (sliced int8 products, qn_dw_i8.hip; K-slabs in whole 64-row chunks)
                     if (wide_bwd && i8_dw_ok) {
                         const int kc64 = ((Nb + ks - 1) / ks + 63) / 64 * 64;
-                        const int rc = qn_i8_dw(g.h_in, g.h_out, d->has_bias, dz, act[l - 1], B, Nb, dst, g.out_stride_b,
+                        const int rc = qn_i8_dw(g.h_in, g.h_out, d->has_bias, dz, act[l - 1], B, Nb, Ns, dst, g.out_stride_b,
                                                 g.out_stride_k, ks, kc64, rowsc ? rowsc + (int64_t)(l - 1) * B * Nb : nullptr, st);
                         if (rc == QN_OK) dw_done = true;
-                        else if (!(rc == QN_EUNSUPPORTED && rowsc)) return rc;      // (row scales in a build without the group-scale kernel: the float64 product below)
+                        else if (!(rc == QN_EUNSUPPORTED && rowsc && Ns == Nb)) return rc;   // (row scales in a build without the group-scale kernel: the float64 product below, which knows no padded stride)
                     }
 #endif
                 }
@@ -737,7 +756,7 @@ int run_generic(const qn_desc* d, const T* W, const T* X, const T* Y, const int3
                 }
                 if constexpr (std::is_same<T, double>::value) {
                     if (dw_done)            // (the int8 kernel took the whole 64-row chunks: the last Nb % 64 rows in float64)
-                        if (int rc = qn_i8_dw_tail(g.h_in, g.h_out, d->has_bias, dz, act[l - 1], B, Nb, gradW + d->offW[l], d->p, st))
+                        if (int rc = qn_i8_dw_tail(g.h_in, g.h_out, d->has_bias, dz, act[l - 1], B, Nb, Ns, gradW + d->offW[l], d->p, st))
                             return rc;
                 }
                 if (wide_bwd) continue;
@@ -885,7 +904,7 @@ int run_rnet(const qn_desc* d, const T* W, const T* X, const T* Y, const int32_t
     auto base = [&]() {
         LayerArgs a;
         a.p = d->p; a.offW = 0; a.offB = 0; a.has_bias = d->has_bias; a.h_in = r; a.h_out = r; a.act = d->act;
-        a.Nb = Nb; a.first = 0; a.d = din; a.o = o; a.eye = 0;
+        a.Nb = Nb; a.first = 0; a.d = din; a.o = o; a.eye = 0; a.Nsz = Nb; a.Nsa = Nb;
         return a;
     };
     LayerArgs apre = base();     // x -> OUT_0
@@ -970,12 +989,14 @@ size_t qn_generic_workspace(const qn_desc* d, int B, int Nb, int want_grad, int 
     const size_t e = dtype == QN_F64 ? 8 : 4;
     const int L = d->nlayers;
     size_t tot = 0;
-    for (int l = 0; l + 1 < L; ++l) tot += qn_align((size_t)B * d->dims[l + 1] * Nb * e);
+    // (the wide int8 gradient path pads the stashes' row stride: sized for it whatever path the descriptor is forced to)
+    const int Ns = (dtype == QN_F64 && want_grad && qn_i8_wide_applies(d)) ? wide_stash_stride(Nb) : Nb;
+    for (int l = 0; l + 1 < L; ++l) tot += qn_align((size_t)B * d->dims[l + 1] * Ns * e);
     if (want_grad) {
         tot += qn_align((size_t)B * d->dims[L] * Nb * e);
-        if (L > 1) tot += 2 * qn_align((size_t)B * d->hmax * Nb * e);
+        if (L > 1) tot += 2 * qn_align((size_t)B * d->hmax * Ns * e);
         if (dtype == QN_F64 && qn_i8_wide_applies(d))
-            for (int l = 2; l < L - 1; ++l) tot += qn_align((size_t)B * d->hmax * Nb * e);
+            for (int l = 2; l < L - 1; ++l) tot += qn_align((size_t)B * d->hmax * Ns * e);
     }
     tot += qn_align((size_t)B * ((Nb + BLK - 1) / BLK) * sizeof(double));
     if (want_grad) {

@@ -39,6 +39,7 @@ constexpr int WWG = 256;                    // threads per workgroup
 struct WideArgs {
     int64_t p, act_stride;                  // act_stride: doubles between the stashed activations of consecutive layers
     int B, Nb, d, nhid, has_bias;
+    int Ns;                                 // row stride of the stash [B][h][Ns] (>= Nb: a multiple of 16 rows keeps every feature's rows on whole 128-byte lines)
     int nsplit, rows_per_split, iters;
 };
 
@@ -85,7 +86,7 @@ __device__ __forceinline__ double wide_actf(double z, int act) {      // (torch 
 // threshold_backward, a <= 0 ? 0 : x, so that Inf x 0 never forms and a NaN output lets the gradient pass)
 __device__ __forceinline__ double wide_dmul(double x, double av, int act) { return qn_act_bwd<double>(x, av, act); }
 template <int KC>
-__device__ __noinline__ double wide_slow_rows(int Nb, int d, int nhid, int has_bias, int64_t act_stride,
+__device__ __noinline__ double wide_slow_rows(int Nb, int Ns, int d, int nhid, int has_bias, int64_t act_stride,
                                               const double* __restrict__ Wb, const double* __restrict__ X,
                                               const double* __restrict__ Y, const int32_t* __restrict__ row_idx, int nbase,
                                               int b, double* __restrict__ scr, double* __restrict__ act0,
@@ -105,7 +106,7 @@ __device__ __noinline__ double wide_slow_rows(int Nb, int d, int nhid, int has_b
             double z = nb ? Wb[gb0 + f] : 0.0;
             for (int k = 0; k < d; ++k) z = fma(Wb[(int64_t)f * d + k], X[rr * d + k], z);
             act[m] = wide_actf(z, actk);
-            if (act0) act0[((int64_t)b * HID + f) * Nb + n] = act[m];
+            if (act0) act0[((int64_t)b * HID + f) * Ns + n] = act[m];
         }
         // (relu / identity gradient calls: the row's scale 2^f > every |a| of the layer, what the fast rows leave for the
         // weight-gradient kernel; a row that is not finite gets exponent 2046 and is caught there)
@@ -130,7 +131,7 @@ __device__ __noinline__ double wide_slow_rows(int Nb, int d, int nhid, int has_b
                 double z = nb ? Wg[(int64_t)HID * HID + f] : 0.0;
                 for (int i = 0; i < HID; ++i) z = fma(Wg[(int64_t)f * HID + i], cur[i], z);
                 act[m] = wide_actf(z, actk);
-                if (act0) act0[layer * act_stride + ((int64_t)b * HID + f) * Nb + n] = act[m];
+                if (act0) act0[layer * act_stride + ((int64_t)b * HID + f) * Ns + n] = act[m];
             }
             if (rowsc && layer + 1 < nhid) put_scale(layer);
         }
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
         const bool exceptional = block_or(w_bad | xbad_n, red + 6);
         if (it + 1 < a.iters) fetch(it + 1);
         if (exceptional) {
-            sse += wide_slow_rows<KC>(a.Nb, d, NH, a.has_bias, a.act_stride, Wb, X, Y, row_idx,
+            sse += wide_slow_rows<KC>(a.Nb, a.Ns, d, NH, a.has_bias, a.act_stride, Wb, X, Y, row_idx,
                                       split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave,
                                       STASH ? act0 : nullptr, dz_last, pred_out);
             // (the plain-float64 rows use flat loads / stores, which complete out of order: drain them before the counted
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
         }
         // stash: feature 4 q of this lane's row; rows beyond Nb write to a dump area (no branch in the epilogue: it has
         // to stay one scheduling region, and every epilogue really issues its 4 stores: sync_tile counts on them)
-        const int64_t srow = ((int64_t)b * HID + 4 * q) * a.Nb + (live ? nrow : 0);
+        const int64_t srow = ((int64_t)b * HID + 4 * q) * a.Ns + (live ? nrow : 0);
         double* const dmp = dump + lane;
 
         // ---- first layer (VALU): a_1 = tanh(W0 x + b0), sliced into the B operand of the first hidden layer
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
 #pragma unroll
                     for (int k = 0; k < DP; ++k) z = fma(lds[j * DP + k], xk[k], z);
                     av[r] = qn_tanh_f64_tab64(z, tanh_tab);
-                    if constexpr (STASH) (live ? act0 + srow + (int64_t)(64 * kc + 16 * t) * a.Nb : dmp)[(int64_t)r * a.Nb] = av[r];
+                    if constexpr (STASH) (live ? act0 + srow + (int64_t)(64 * kc + 16 * t) * a.Ns : dmp)[(int64_t)r * a.Ns] = av[r];
                 }
                 int S[NS];
                 slice4(av, S);
@@ -447,10 +448,10 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
             // the stash pointers of a tile's four elements advance by 16 features per tile (rows beyond Nb: the dump area, no
             // advance): recomputed from the layer's base for every store they cost four 64-bit vector adds per element
             double* sp[4];
-            int64_t sstride = live ? (int64_t)16 * a.Nb : 0;
+            int64_t sstride = live ? (int64_t)16 * a.Ns : 0;
             asm volatile("" : "+v"(sstride));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sp[r] = STASH ? (live ? stl : dmp) + (int64_t)r * a.Nb : nullptr;
+            for (int r = 0; r < 4; ++r) sp[r] = STASH ? (live ? stl : dmp) + (int64_t)r * a.Ns : nullptr;
             v4i Bout[KC][NS];
             v4i Bcur[NS];
             v4i accA[NLEV], accB[NLEV];
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
         const double res = pr - yk;
         if (redo) {                                                  // wave-uniform, rare: the wave's 16 rows again, exactly
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the stash stores above land before their rewrites)
-            sse += wide_slow_rows<KC>(a.Nb, d, NH, a.has_bias, a.act_stride, Wb, X, Y, row_idx,
+            sse += wide_slow_rows<KC>(a.Nb, a.Ns, d, NH, a.has_bias, a.act_stride, Wb, X, Y, row_idx,
                                       split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave,
                                       STASH ? act0 : nullptr, dz_last, pred_out);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -539,6 +540,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd(WideArgs a, const double
 struct WideBwdArgs {
     int64_t p, act_stride, dz_stride;
     int B, Nb, d, nhid, has_bias;
+    int Ns;                                 // row stride of the activation / dZ stashes [B][h][Ns]
     int nsplit, rows_per_split, iters;
 };
 __host__ __device__ constexpr int wideb_head(int hid, int nhid) {       // Wl [h] | red [8] | scales (nhid-1) x [h] | scratch 4 x 2 h | dWl of plain-float64 rows 4 x (h + 8)
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(256) void k_i8_slice_wT(I8Net net, const double* __
 
 // the workgroup's rows of one iteration in plain float64 (rare); lane j owns features j, j + 64, ...
 template <int KC>
-__device__ __noinline__ void wide_slow_bwd_rows(int Nb, int d, int nhid, int has_bias, int64_t act_stride, int64_t dz_stride,
+__device__ __noinline__ void wide_slow_bwd_rows(int Nb, int Ns, int d, int nhid, int has_bias, int64_t act_stride, int64_t dz_stride,
                                                 const double* __restrict__ Wb, int nbase, int b, double* __restrict__ scr,
                                                 const double* __restrict__ act0, const double* __restrict__ dz_last,
                                                 double* __restrict__ dz0, double* __restrict__ dwl_acc, int actk = QN_ACT_TANH) {
@@ -659,7 +661,7 @@ __device__ __noinline__ void wide_slow_bwd_rows(int Nb, int d, int nhid, int has
         if (dwl_acc && lane == 0) dwl_acc[HID] += dzl;                 // (this wave's LDS slots: lane j owns entries j, j + 64, ...)
 #pragma unroll
         for (int m = 0; m < KC; ++m) {
-            const int64_t idx = ((int64_t)b * HID + lane + 64 * m) * Nb + n;
+            const int64_t idx = ((int64_t)b * HID + lane + 64 * m) * Ns + n;
             const double av = act0[(nhid - 1) * act_stride + idx];
             g[m] = wide_dmul(Wb[gWl + lane + 64 * m] * dzl, av, actk);
             dz0[(nhid - 1) * dz_stride + idx] = g[m];
@@ -676,7 +678,7 @@ __device__ __noinline__ void wide_slow_bwd_rows(int Nb, int d, int nhid, int has
                 const int i = lane + 64 * m;
                 double acc = 0.0;
                 for (int j = 0; j < HID; ++j) acc = fma(Wg[(int64_t)j * HID + i], cur[j], acc);
-                const int64_t idx = ((int64_t)b * HID + i) * Nb + n;
+                const int64_t idx = ((int64_t)b * HID + i) * Ns + n;
                 const double av = act0[li * act_stride + idx];
                 g[m] = wide_dmul(acc, av, actk);
                 dz0[li * dz_stride + idx] = g[m];
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
             if (k < d) xbad |= !qn_bounded(X[rr * d + k]);
         const bool exceptional = block_or(w_bad | xbad, red + 6);
         if (exceptional) {
-            wide_slow_bwd_rows<KC>(a.Nb, d, NH, a.has_bias, a.act_stride, a.dz_stride, Wb,
+            wide_slow_bwd_rows<KC>(a.Nb, a.Ns, d, NH, a.has_bias, a.act_stride, a.dz_stride, Wb,
                                    split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave, act0, dz_last, dz0,
                                    fold ? slow_acc + (HID + 8) * wave : nullptr, TANH ? QN_ACT_TANH : actk);
             // (flat loads / stores in there complete out of order: drain them before the counted vmcnt waits resume)
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
             continue;
         }
         // element (feature 4 q [+ 16 T + r], this lane's row); rows beyond Nb read row 0 and write to the dump area
-        const int64_t erow = ((int64_t)b * HID + 4 * q) * a.Nb + nn;
+        const int64_t erow = ((int64_t)b * HID + 4 * q) * a.Ns + nn;
         double* const dmp = dump + lane;
 
         // ---- top: dZ_{nhid-1} = (1 - a^2) wl dz_last (VALU), kept as float64 until the row maximum is known
@@ -817,7 +819,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[4 * t + r] = ap[(int64_t)(16 * (4 * bi + t) + r) * a.Nb];
+                    for (int r = 0; r < 4; ++r) dst[4 * t + r] = ap[(int64_t)(16 * (4 * bi + t) + r) * a.Ns];
             };
             load_batch(0, abuf[0]);
 #pragma unroll
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
                         const double av = abuf[bi & 1][4 * t + r];
                         if constexpr (FOLD) dwl[T_][r] = fma(dze, av, dwl[T_][r]);
                         const double v = (lds[16 * T_ + 4 * q + r] * dzl) * dact(av);
-                        (live ? zp + (int64_t)(16 * T_) * a.Nb : dmp)[(int64_t)r * a.Nb] = v;
+                        (live ? zp + (int64_t)(16 * T_) * a.Ns : dmp)[(int64_t)r * a.Ns] = v;
                         amax = fmax(amax, fabs(v));
                         V[T_][r] = to_acc_d(v);
                     }
@@ -892,20 +894,20 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
             double ab[3][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                ab[0][r] = apl[(int64_t)r * a.Nb];
-                ab[1][r] = apl[(int64_t)(16 + r) * a.Nb];
+                ab[0][r] = apl[(int64_t)r * a.Ns];
+                ab[1][r] = apl[(int64_t)(16 + r) * a.Ns];
             }
             // running pointers of a tile's four elements (activation loads two tiles ahead, dZ stores): 16 features per
             // tile; recomputed from the layer's base for every access they cost four to five 64-bit vector adds per element.
             // Rows beyond Nb store to the dump area and do not advance.
             const double* lp[4];
             double* sp[4];
-            int64_t lstride = (int64_t)16 * a.Nb, sstride = live ? (int64_t)16 * a.Nb : 0;
+            int64_t lstride = (int64_t)16 * a.Ns, sstride = live ? (int64_t)16 * a.Ns : 0;
             asm volatile("" : "+v"(lstride), "+v"(sstride));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                lp[r] = apl + (int64_t)((TL > 2 ? 32 : 16 * (TL - 1)) + r) * a.Nb;
-                sp[r] = (live ? zpl : dmp) + (int64_t)r * a.Nb;
+                lp[r] = apl + (int64_t)((TL > 2 ? 32 : 16 * (TL - 1)) + r) * a.Ns;
+                sp[r] = (live ? zpl : dmp) + (int64_t)r * a.Ns;
             }
             v4i accA[NLEV], accB[NLEV];
             int topl = 0;
@@ -1128,13 +1130,13 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd_u(WideArgs a, const doub
         const bool exceptional = block_or(w_bad | xbad_n, red + 6);     // (workgroup-uniform: the tile barriers need all four waves)
         if (it + 1 < a.iters) fetch(it + 1);
         if (exceptional) {
-            sse += wide_slow_rows<KC>(a.Nb, d, NH, a.has_bias, a.act_stride, Wb, X, Y, row_idx,
+            sse += wide_slow_rows<KC>(a.Nb, a.Ns, d, NH, a.has_bias, a.act_stride, Wb, X, Y, row_idx,
                                       split * a.rows_per_split + (it * 4 + wave) * 16, b, scratch + 2 * HID * wave,
                                       STASH ? act0 : nullptr, dz_last, pred_out, actk, STASH ? rowsc : nullptr, rs_stride);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             continue;
         }
-        const int64_t srow = ((int64_t)b * HID + 4 * q) * a.Nb + (live ? nrow : 0);
+        const int64_t srow = ((int64_t)b * HID + 4 * q) * a.Ns + (live ? nrow : 0);
         double* const dmp = dump + lane;
 
         // ---- first layer (VALU): a_1 = act(W0 x + b0), kept as float64 until the row maximum is known
@@ -1151,7 +1153,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd_u(WideArgs a, const doub
 #pragma unroll
                     for (int k = 0; k < DP; ++k) z = fma(lds[j * DP + k], xk[k], z);
                     const double av = fmax(z, alo);
-                    if constexpr (STASH) (live ? act0 + srow + (int64_t)(64 * kc + 16 * t) * a.Nb : dmp)[(int64_t)r * a.Nb] = av;
+                    if constexpr (STASH) (live ? act0 + srow + (int64_t)(64 * kc + 16 * t) * a.Ns : dmp)[(int64_t)r * a.Ns] = av;
                     amax = fmax(amax, fabs(av));
                     V[4 * kc + t][r] = to_acc_d(av);
                 }
@@ -1255,10 +1257,10 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_fwd_u(WideArgs a, const doub
             const double* wl = lds + offWl + 4 * q;
             double* stl = STASH ? act0 + (int64_t)(li + 1) * a.act_stride + srow : nullptr;
             double* sp[4];
-            int64_t sstride = live ? (int64_t)16 * a.Nb : 0;
+            int64_t sstride = live ? (int64_t)16 * a.Ns : 0;
             asm volatile("" : "+v"(sstride));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sp[r] = STASH ? (live ? stl : dmp) + (int64_t)r * a.Nb : nullptr;
+            for (int r = 0; r < 4; ++r) sp[r] = STASH ? (live ? stl : dmp) + (int64_t)r * a.Ns : nullptr;
             v4i accA[NLEV], accB[NLEV];
             sync_tile();
             burst(accA, ring + rd_slot * TILE_B + lofs);
@@ -1392,8 +1394,9 @@ double* qn_i8_wide_rowscale(const qn_desc* d, int B, int Nb, int want_grad, void
 // One launch: sse [B] (+ pred [B][Nb], dz_last [B][Nb] = 2 (pred - y), hidden activations act0 + l * act_stride
 // [B][h][Nb] for l = 0 .. L-2, each optional)
 int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const double* Y, const int32_t* row_idx, int B,
-                       int Nb, double* act0, int64_t act_stride, double* dz_last, double* pred, double* sse, void* ws,
+                       int Nb, double* act0, int64_t act_stride, int Ns, double* dz_last, double* pred, double* sse, void* ws,
                        hipStream_t st) {
+    if (act0 && Ns < Nb) return QN_EINVAL;
     if (!qn_i8_wide_applies(d)) return QN_EUNSUPPORTED;
     const int h = d->dims[1], nhh = d->nlayers - 2;
     I8Net net;
@@ -1418,7 +1421,7 @@ int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const
     base += qn_align((size_t)B * a.nsplit * sizeof(double));
     double* dump = reinterpret_cast<double*>(base);
     a.p = d->p; a.act_stride = act_stride; a.B = B; a.Nb = Nb; a.d = d->dims[0]; a.nhid = d->nlayers - 1;
-    a.has_bias = d->has_bias;
+    a.has_bias = d->has_bias; a.Ns = act0 ? Ns : Nb;
     QN_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), st));
     hipLaunchKernelGGL((k_i8_slice_w<QN_I8_LMIN>), dim3(B, nhh, 8), dim3(256), 0, st, net, W, Wd, sb, flags);
     const int dp = a.d <= 2 ? 2 : 4;
@@ -1462,9 +1465,10 @@ int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const
 // gradW (may be null): the flat gradient [B][p]; at h = 128 the OUTPUT layer's weight / bias gradient is written there too
 // (*last_done = 1: the caller skips its own kernel for that layer)
 int qn_i8_wide_backward(const qn_desc* d, const double* W, const double* X, const int32_t* row_idx, int B, int Nb,
-                        const double* act0, int64_t act_stride, const double* dz_last, double* dz0, int64_t dz_stride, void* ws,
+                        const double* act0, int64_t act_stride, int Ns, const double* dz_last, double* dz0, int64_t dz_stride, void* ws,
                         double* gradW, int* last_done, hipStream_t st) {
     if (last_done) *last_done = 0;
+    if (Ns < Nb) return QN_EINVAL;
     if (!qn_i8_wide_applies(d)) return QN_EUNSUPPORTED;
     const int h = d->dims[1], nhh = d->nlayers - 2;
     I8Net net;
@@ -1492,7 +1496,7 @@ int qn_i8_wide_backward(const qn_desc* d, const double* W, const double* X, cons
     double* dwl_slab = reinterpret_cast<double*>(base);
     const bool fold_last = (h == 128 || QN_WIDE_FOLD_ALL) && gradW != nullptr && last_done != nullptr;
     WideBwdArgs a;
-    a.p = d->p; a.act_stride = act_stride; a.dz_stride = dz_stride; a.B = B; a.Nb = Nb; a.d = d->dims[0];
+    a.p = d->p; a.act_stride = act_stride; a.dz_stride = dz_stride; a.B = B; a.Nb = Nb; a.Ns = Ns; a.d = d->dims[0];
     a.nhid = d->nlayers - 1; a.has_bias = d->has_bias;
     a.nsplit = fa.nsplit; a.rows_per_split = fa.rows_per_split; a.iters = fa.iters;
     QN_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), st));
