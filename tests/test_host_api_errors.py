@@ -48,8 +48,15 @@ def test_descriptor_validation_and_sizes(L):
             # per-descriptor kernel-family override
             assert L.qn_mlp_desc_set_path(d, 1) == 0 and L.qn_mlp_path(d, 8, 64, 0, 0) == 1
             assert L.qn_mlp_desc_set_path(d, 99) == 1 and L.qn_mlp_desc_set_path(d, 0) == 1
+            # row split of the fused kernels planned for a larger batch than the launch's (chain groups): more chains -> fewer
+            # (or as many) row shares per chain; a negative value only queries
+            n1 = L.qn_mlp_sse_parts(d, 8, 4096, 0)
+            assert L.qn_mlp_desc_set_plan_batch(d, 64) == 0 and L.qn_mlp_desc_set_plan_batch(d, -1) == 64
+            assert 1 <= L.qn_mlp_sse_parts(d, 8, 4096, 0) <= n1 and L.qn_mlp_sse_parts(d, 64, 4096, 0) == L.qn_mlp_sse_parts(d, 8, 4096, 0)
+            assert L.qn_mlp_desc_set_plan_batch(d, 0) == 64 and L.qn_mlp_sse_parts(d, 8, 4096, 0) == n1
             assert L.qn_mlp_desc_destroy(d) == 0
     assert L.qn_mlp_num_params(None) == -1 and L.qn_mlp_desc_set_path(None, 0) == EINVAL
+    assert L.qn_mlp_desc_set_plan_batch(None, 4) == EINVAL
 
 
 def test_residual_network_descriptor(L):
