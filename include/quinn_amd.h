@@ -85,7 +85,7 @@ int qn_mlp_arith(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
  * unpadded network's).  QN_PATH_FUSED_DP is QN_PATH_FUSED restricted to the kernels that use the float64 matrix
  * instructions: it excludes the forward kernel that forms the 64-wide hidden layers as sliced exact int8 products
  * (same results to ~1e-14 relative; kept selectable as the second implementation the tests compare it with).  Under
- * QN_PATH_AUTO the float64 networks with hidden widths all 128 or all 256 (one output, <= 4 inputs) take the layer-wise
+ * QN_PATH_AUTO the float64 networks with hidden widths all 128 or all 256 (one output, <= 8 inputs) take the layer-wise
  * family with their hidden layers -- forward, activation gradient and, for tanh, weight gradient -- as sliced exact int8
  * products (~1e-13 relative; relu / identity: one activation scale per data row and layer, and every weight and bias below
  * 2^20, inputs below 2^100); QN_PATH_GENERIC is the all-float64 reference of that family as well.

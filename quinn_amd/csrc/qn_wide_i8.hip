@@ -784,9 +784,7 @@ __global__ __launch_bounds__(WWG, 1) void k_i8_wide_bwd(WideBwdArgs a, const dou
         const int64_t rr = row_idx ? (int64_t)row_idx[(int64_t)b * a.Nb + nn] : (int64_t)nn;
         const double dzl = dz_last[(int64_t)b * a.Nb + nn];
         int xbad = !qn_bounded100(dzl);
-#pragma unroll
-        for (int k = 0; k < DP; ++k)
-            if (k < d) xbad |= !qn_bounded(X[rr * d + k]);
+        for (int k = 0; k < d; ++k) xbad |= !qn_bounded(X[rr * d + k]);      // (run-time d: the instances for 5..8 inputs are the DP = 4 ones)
         const bool exceptional = block_or(w_bad | xbad, red + 6);
         if (exceptional) {
             wide_slow_bwd_rows<KC>(a.Nb, a.Ns, d, NH, a.has_bias, a.act_stride, a.dz_stride, Wb,
@@ -1355,9 +1353,11 @@ int wide_arm(const void* fn, size_t bytes) {
 
 }  // namespace
 
+// columns of the first layer's LDS image / registers of a row's inputs: 2, 4 or (5..8 inputs: round 4) 8
+static int wide_dp(int d) { return d <= 2 ? 2 : (d <= 4 ? 4 : 8); }
 bool qn_i8_wide_applies(const qn_desc* d) {
     const int L = d->nlayers;
-    if (d->kind != QN_KIND_MLP || L < 3 || d->dims[0] > 4 || d->dims[L] != 1) return false;
+    if (d->kind != QN_KIND_MLP || L < 3 || d->dims[0] > 8 || d->dims[L] != 1) return false;
 #ifdef QN_WIDE_TANH_ONLY                                            // (A/B: relu / identity on the layer-wise float64 kernels, as until round 4)
     if (d->act != QN_ACT_TANH) return false;
 #endif
@@ -1365,7 +1365,7 @@ bool qn_i8_wide_applies(const qn_desc* d) {
     if (h != 128 && h != 256) return false;
     for (int l = 1; l < L; ++l)
         if (d->dims[l] != h) return false;
-    return wide_lds_bytes(h / 64, d->dims[0] <= 2 ? 2 : 4, L - 1) <= 160 * 1024 && wideb_lds_bytes(h / 64, L - 1) <= 160 * 1024;
+    return wide_lds_bytes(h / 64, wide_dp(d->dims[0]), L - 1) <= 160 * 1024 && wideb_lds_bytes(h / 64, L - 1) <= 160 * 1024;
 }
 // bytes of: weight digit planes | {scale, bias} pairs | chain flags | SSE partials | dump area of the activation stash
 size_t qn_i8_wide_workspace(const qn_desc* d, int B, int Nb, int want_grad) {
@@ -1424,27 +1424,27 @@ int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const
     a.has_bias = d->has_bias; a.Ns = act0 ? Ns : Nb;
     QN_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), st));
     hipLaunchKernelGGL((k_i8_slice_w<QN_I8_LMIN>), dim3(B, nhh, 8), dim3(256), 0, st, net, W, Wd, sb, flags);
-    const int dp = a.d <= 2 ? 2 : 4;
+    const int dp = wide_dp(a.d);
     const size_t lds = wide_lds_bytes(h / 64, dp, a.nhid);
     using kfn = void (*)(WideArgs, const double*, const double*, const double*, const int32_t*, const unsigned char*,
                          const double*, const int*, double*, double*, double*, double*, double*);
     kfn kern;
     if (act0)
-        kern = h == 128 ? (dp == 2 ? k_i8_wide_fwd<2, 2, QN_I8_LMIN, true> : k_i8_wide_fwd<2, 4, QN_I8_LMIN, true>)
-                        : (dp == 2 ? k_i8_wide_fwd<4, 2, QN_I8_LMIN, true> : k_i8_wide_fwd<4, 4, QN_I8_LMIN, true>);
+        kern = h == 128 ? (dp == 2 ? k_i8_wide_fwd<2, 2, QN_I8_LMIN, true> : dp == 4 ? k_i8_wide_fwd<2, 4, QN_I8_LMIN, true> : k_i8_wide_fwd<2, 8, QN_I8_LMIN, true>)
+                        : (dp == 2 ? k_i8_wide_fwd<4, 2, QN_I8_LMIN, true> : dp == 4 ? k_i8_wide_fwd<4, 4, QN_I8_LMIN, true> : k_i8_wide_fwd<4, 8, QN_I8_LMIN, true>);
     else
-        kern = h == 128 ? (dp == 2 ? k_i8_wide_fwd<2, 2, QN_I8_LMIN, false> : k_i8_wide_fwd<2, 4, QN_I8_LMIN, false>)
-                        : (dp == 2 ? k_i8_wide_fwd<4, 2, QN_I8_LMIN, false> : k_i8_wide_fwd<4, 4, QN_I8_LMIN, false>);
+        kern = h == 128 ? (dp == 2 ? k_i8_wide_fwd<2, 2, QN_I8_LMIN, false> : dp == 4 ? k_i8_wide_fwd<2, 4, QN_I8_LMIN, false> : k_i8_wide_fwd<2, 8, QN_I8_LMIN, false>)
+                        : (dp == 2 ? k_i8_wide_fwd<4, 2, QN_I8_LMIN, false> : dp == 4 ? k_i8_wide_fwd<4, 4, QN_I8_LMIN, false> : k_i8_wide_fwd<4, 8, QN_I8_LMIN, false>);
     if (d->act != QN_ACT_TANH) {                                    // relu / identity: per-row activation scales
         using ufn = void (*)(WideArgs, const double*, const double*, const double*, const int32_t*, const unsigned char*,
                              const double*, const int*, double*, double*, double*, double*, double*, int, double*, int64_t);
         ufn ku;
         if (act0)
-            ku = h == 128 ? (dp == 2 ? k_i8_wide_fwd_u<2, 2, QN_I8_LMIN, true> : k_i8_wide_fwd_u<2, 4, QN_I8_LMIN, true>)
-                          : (dp == 2 ? k_i8_wide_fwd_u<4, 2, QN_I8_LMIN, true> : k_i8_wide_fwd_u<4, 4, QN_I8_LMIN, true>);
+            ku = h == 128 ? (dp == 2 ? k_i8_wide_fwd_u<2, 2, QN_I8_LMIN, true> : dp == 4 ? k_i8_wide_fwd_u<2, 4, QN_I8_LMIN, true> : k_i8_wide_fwd_u<2, 8, QN_I8_LMIN, true>)
+                          : (dp == 2 ? k_i8_wide_fwd_u<4, 2, QN_I8_LMIN, true> : dp == 4 ? k_i8_wide_fwd_u<4, 4, QN_I8_LMIN, true> : k_i8_wide_fwd_u<4, 8, QN_I8_LMIN, true>);
         else
-            ku = h == 128 ? (dp == 2 ? k_i8_wide_fwd_u<2, 2, QN_I8_LMIN, false> : k_i8_wide_fwd_u<2, 4, QN_I8_LMIN, false>)
-                          : (dp == 2 ? k_i8_wide_fwd_u<4, 2, QN_I8_LMIN, false> : k_i8_wide_fwd_u<4, 4, QN_I8_LMIN, false>);
+            ku = h == 128 ? (dp == 2 ? k_i8_wide_fwd_u<2, 2, QN_I8_LMIN, false> : dp == 4 ? k_i8_wide_fwd_u<2, 4, QN_I8_LMIN, false> : k_i8_wide_fwd_u<2, 8, QN_I8_LMIN, false>)
+                          : (dp == 2 ? k_i8_wide_fwd_u<4, 2, QN_I8_LMIN, false> : dp == 4 ? k_i8_wide_fwd_u<4, 4, QN_I8_LMIN, false> : k_i8_wide_fwd_u<4, 8, QN_I8_LMIN, false>);
         if (int rc = wide_arm(reinterpret_cast<const void*>(ku), lds)) return rc;
         hipLaunchKernelGGL(ku, dim3(qn_fused_grid(a.nsplit, B)), dim3(WWG), lds, st, a, W, X, Y, row_idx,
                            (const unsigned char*)Wd, (const double*)sb, (const int*)flags, act0, dz_last, pred, partial, dump, d->act,

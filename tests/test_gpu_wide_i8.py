@@ -49,7 +49,9 @@ CASES = [((2, 128, 128, 128, 1), 8192, 6, True), ((1, 256, 256, 256, 256, 1), 10
          ((1, 256, 256, 256, 256, 256, 256, 1), 65, 2, True),
          # whole 64-row chunks (the group-scale weight-gradient kernel k_i8_dw_g): a partial last group, a single chunk,
          # slabs of several groups
-         ((2, 128, 128, 128, 1), 448, 5, True), ((1, 256, 256, 256, 1), 64, 3, True), ((3, 256, 256, 256, 1), 2368, 2, False)]
+         ((2, 128, 128, 128, 1), 448, 5, True), ((1, 256, 256, 256, 1), 64, 3, True), ((3, 256, 256, 256, 1), 2368, 2, False),
+         # 5..8 inputs (round 4: a third width of the first layer's LDS image and input registers)
+         ((6, 128, 128, 128, 1), 300, 3, True), ((8, 256, 256, 1), 130, 2, True), ((5, 128, 128, 1), 77, 4, False), ((7, 256, 256, 256, 1), 1000, 2, True)]
 
 
 @pytest.mark.parametrize("act", ACTS)
