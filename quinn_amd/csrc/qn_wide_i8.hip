@@ -24,9 +24,16 @@
 #include "qn_fused_args.h"
 #include "qn_math.h"
 #include "qn_i8_slice.h"
+#include <cstring>
 #include <mutex>
 #include <unordered_set>
 
+// This file is compiled as TWO objects so that its ~40 kernel instances build in parallel: part 0 (this file) holds everything but the
+// relu / identity forward instances, part 1 (qn_wide_u_i8.hip: `#define QN_WIDE_PART 1` + `#include` of this file) holds those and
+// their launcher qn_i8_wide_launch_u.  -1: one object with everything.
+#ifndef QN_WIDE_PART
+#define QN_WIDE_PART 0
+#endif
 #ifndef QN_WIDE_FOLD_ALL
 #define QN_WIDE_FOLD_ALL 0            // 1: the output layer's weight gradient rides on the backward kernel at h = 256 too (A/B)
 #endif
@@ -1354,6 +1361,36 @@ int wide_arm(const void* fn, size_t bytes) {
 }  // namespace
 
 // columns of the first layer's LDS image / registers of a row's inputs: 2, 4 or (5..8 inputs: round 4) 8
+// launch of k_i8_wide_fwd_u (relu / identity); `args`: the WideArgs of the call (opaque here: the struct lives in each object's
+// anonymous namespace)
+int qn_i8_wide_launch_u(int h, int dp, int stash, size_t lds, unsigned grid, hipStream_t st, const void* args, const double* W,
+                        const double* X, const double* Y, const int32_t* row_idx, const unsigned char* Wd, const double* sb,
+                        const int* flags, double* act0, double* dz_last, double* pred, double* partial, double* dump, int act,
+                        double* rowsc, int64_t rs_stride);
+#if QN_WIDE_PART != 0
+int qn_i8_wide_launch_u(int h, int dp, int stash, size_t lds, unsigned grid, hipStream_t st, const void* args, const double* W,
+                        const double* X, const double* Y, const int32_t* row_idx, const unsigned char* Wd, const double* sb,
+                        const int* flags, double* act0, double* dz_last, double* pred, double* partial, double* dump, int act,
+                        double* rowsc, int64_t rs_stride) {
+    WideArgs a;
+    memcpy(&a, args, sizeof(a));
+    using ufn = void (*)(WideArgs, const double*, const double*, const double*, const int32_t*, const unsigned char*,
+                         const double*, const int*, double*, double*, double*, double*, double*, int, double*, int64_t);
+    ufn ku;
+    if (stash)
+        ku = h == 128 ? (dp == 2 ? k_i8_wide_fwd_u<2, 2, QN_I8_LMIN, true> : dp == 4 ? k_i8_wide_fwd_u<2, 4, QN_I8_LMIN, true> : k_i8_wide_fwd_u<2, 8, QN_I8_LMIN, true>)
+                      : (dp == 2 ? k_i8_wide_fwd_u<4, 2, QN_I8_LMIN, true> : dp == 4 ? k_i8_wide_fwd_u<4, 4, QN_I8_LMIN, true> : k_i8_wide_fwd_u<4, 8, QN_I8_LMIN, true>);
+    else
+        ku = h == 128 ? (dp == 2 ? k_i8_wide_fwd_u<2, 2, QN_I8_LMIN, false> : dp == 4 ? k_i8_wide_fwd_u<2, 4, QN_I8_LMIN, false> : k_i8_wide_fwd_u<2, 8, QN_I8_LMIN, false>)
+                      : (dp == 2 ? k_i8_wide_fwd_u<4, 2, QN_I8_LMIN, false> : dp == 4 ? k_i8_wide_fwd_u<4, 4, QN_I8_LMIN, false> : k_i8_wide_fwd_u<4, 8, QN_I8_LMIN, false>);
+    if (int rc = wide_arm(reinterpret_cast<const void*>(ku), lds)) return rc;
+    hipLaunchKernelGGL(ku, dim3(grid), dim3(WWG), lds, st, a, W, X, Y, row_idx, Wd, sb, flags, act0, dz_last, pred, partial, dump, act,
+                       rowsc, rs_stride);
+    return QN_OK;
+}
+#endif
+
+#if QN_WIDE_PART != 1
 static int wide_dp(int d) { return d <= 2 ? 2 : (d <= 4 ? 4 : 8); }
 bool qn_i8_wide_applies(const qn_desc* d) {
     const int L = d->nlayers;
@@ -1435,20 +1472,11 @@ int qn_i8_wide_forward(const qn_desc* d, const double* W, const double* X, const
     else
         kern = h == 128 ? (dp == 2 ? k_i8_wide_fwd<2, 2, QN_I8_LMIN, false> : dp == 4 ? k_i8_wide_fwd<2, 4, QN_I8_LMIN, false> : k_i8_wide_fwd<2, 8, QN_I8_LMIN, false>)
                         : (dp == 2 ? k_i8_wide_fwd<4, 2, QN_I8_LMIN, false> : dp == 4 ? k_i8_wide_fwd<4, 4, QN_I8_LMIN, false> : k_i8_wide_fwd<4, 8, QN_I8_LMIN, false>);
-    if (d->act != QN_ACT_TANH) {                                    // relu / identity: per-row activation scales
-        using ufn = void (*)(WideArgs, const double*, const double*, const double*, const int32_t*, const unsigned char*,
-                             const double*, const int*, double*, double*, double*, double*, double*, int, double*, int64_t);
-        ufn ku;
-        if (act0)
-            ku = h == 128 ? (dp == 2 ? k_i8_wide_fwd_u<2, 2, QN_I8_LMIN, true> : dp == 4 ? k_i8_wide_fwd_u<2, 4, QN_I8_LMIN, true> : k_i8_wide_fwd_u<2, 8, QN_I8_LMIN, true>)
-                          : (dp == 2 ? k_i8_wide_fwd_u<4, 2, QN_I8_LMIN, true> : dp == 4 ? k_i8_wide_fwd_u<4, 4, QN_I8_LMIN, true> : k_i8_wide_fwd_u<4, 8, QN_I8_LMIN, true>);
-        else
-            ku = h == 128 ? (dp == 2 ? k_i8_wide_fwd_u<2, 2, QN_I8_LMIN, false> : dp == 4 ? k_i8_wide_fwd_u<2, 4, QN_I8_LMIN, false> : k_i8_wide_fwd_u<2, 8, QN_I8_LMIN, false>)
-                          : (dp == 2 ? k_i8_wide_fwd_u<4, 2, QN_I8_LMIN, false> : dp == 4 ? k_i8_wide_fwd_u<4, 4, QN_I8_LMIN, false> : k_i8_wide_fwd_u<4, 8, QN_I8_LMIN, false>);
-        if (int rc = wide_arm(reinterpret_cast<const void*>(ku), lds)) return rc;
-        hipLaunchKernelGGL(ku, dim3(qn_fused_grid(a.nsplit, B)), dim3(WWG), lds, st, a, W, X, Y, row_idx,
-                           (const unsigned char*)Wd, (const double*)sb, (const int*)flags, act0, dz_last, pred, partial, dump, d->act,
-                           act0 ? qn_i8_wide_rowscale(d, B, Nb, 1, ws) : (double*)nullptr, (int64_t)B * Nb);
+    if (d->act != QN_ACT_TANH) {                                    // relu / identity: per-row activation scales (qn_wide_u_i8.hip)
+        if (int rc = qn_i8_wide_launch_u(h, dp, act0 != nullptr, lds, qn_fused_grid(a.nsplit, B), st, &a, W, X, Y, row_idx,
+                                         (const unsigned char*)Wd, (const double*)sb, (const int*)flags, act0, dz_last, pred, partial,
+                                         dump, d->act, act0 ? qn_i8_wide_rowscale(d, B, Nb, 1, ws) : (double*)nullptr, (int64_t)B * Nb))
+            return rc;
     } else {
         if (int rc = wide_arm(reinterpret_cast<const void*>(kern), lds)) return rc;
         hipLaunchKernelGGL(kern, dim3(qn_fused_grid(a.nsplit, B)), dim3(WWG), lds, st, a, W, X, Y, row_idx,
@@ -1525,3 +1553,4 @@ int qn_i8_wide_backward(const qn_desc* d, const double* W, const double* X, cons
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }
+#endif  // QN_WIDE_PART != 1
