@@ -336,7 +336,9 @@ def main():
                 res_ = fn(batches[i])
         torch.cuda.current_stream(dev).wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # with a process group alive its watchdog / heartbeat threads may issue HIP calls of their own: relaxed (thread-local)
+        # capture keeps them from invalidating this thread's capture; a single process keeps the strict default
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if dist is not None else "global"):
             for i in range(nsteps):
                 res_ = fn(batches[i % NBATCH])
         g.replay()
@@ -381,8 +383,9 @@ def main():
             for i in range(args.steps):
                 out = run(batches[i % NBATCH])
         e1.record()
-        barrier()
-        el_r.append(time.perf_counter() - t0)
+        torch.cuda.synchronize(dev)
+        el_r.append(time.perf_counter() - t0)                                 # this rank's K steps, done and synchronized;
+        barrier()                                                            # the closing barrier; MAX over ranks below
         dev_r.append(e0.elapsed_time(e1) / args.steps)                       # device ms per step (HIP events, launch stream)
         # ---- the kernel alone, same number of steps, right behind the region
         k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -456,7 +459,7 @@ def main():
                "kind": args.kind, "kernel_path": kpath, "kernel": kernel, "settle_ms": args.settle_ms, "settle_steps": settle_steps,
                "launch": (f"HIP graph of {args.graph} steps, replayed {args.steps // args.graph}x" if args.graph
                           else "direct launches"),
-               "timed_regions": int(regions), "value_from": f"median of {regions} timed regions of {args.steps} steps each (max over ranks per region)",
+               "timed_regions": int(regions), "value_from": f"median of {regions} timed regions of {args.steps} steps each (per region: barrier + synchronize, K steps, synchronize -> this rank's time, closing barrier; MAX over ranks)",
                "region_ms_per_step": [1e3 * float(v) / args.steps for v in el_t],
                "parallelism": f"chains sharded x{world}, no data-path collective, one all_gather at the end"}
         if backend != "nccl" and world > 1:
