@@ -29,6 +29,14 @@
 #include <mutex>
 #include <unordered_set>
 
+// Compiled as two objects: part 0 (this file) holds the kernels' instances with up to 4 inputs (forward, tanh: up to 16) and all
+// the host code; part 1 (qn_fused_d8.hip: `#define QN_FUSED_PART 1` + `#include` of this file) the instances for networks with
+// 5..8 inputs -- the gradient kernel k_fused_bwd_f64<H, NH, 8, UNB> and the relu / identity forward k_fused_fwd_f64<H, G, ACT, 8>
+// (round 4; until then such gradients ran on the layer-wise kernels) -- behind two pick functions.
+#ifndef QN_FUSED_PART
+#define QN_FUSED_PART 0
+#endif
+
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -1147,6 +1155,28 @@ __global__ void k_sum_partials(const double* __restrict__ partial, int n, int B,
     out[b] = s;
 }
 
+constexpr int G_FWD = 2;
+
+#if QN_FUSED_PART == 1
+}  // namespace
+
+qn_bwd_f64_fn qn_fused_bwd_d8_kernel(int H, int nhid, int act) {
+#define QN_PICK(HH, NN) if (H == HH && nhid == NN) return act == QN_ACT_TANH ? k_fused_bwd_f64<HH, NN, 8, false> : k_fused_bwd_f64<HH, NN, 8, true>;
+    QN_PICK(16, 1) QN_PICK(16, 2) QN_PICK(16, 3) QN_PICK(16, 4)
+    QN_PICK(32, 1) QN_PICK(32, 2) QN_PICK(32, 3) QN_PICK(32, 4)
+    QN_PICK(64, 1) QN_PICK(64, 2) QN_PICK(64, 3)
+#undef QN_PICK
+    return nullptr;
+}
+qn_fwd_fn qn_fused_fwd_d8_kernel(int H, int act) {
+#define QN_PICK(HH, AA) if (H == HH && act == AA) return k_fused_fwd_f64<HH, G_FWD, AA, 8, WG>;
+    QN_PICK(16, QN_ACT_RELU) QN_PICK(16, QN_ACT_IDENTITY) QN_PICK(32, QN_ACT_RELU) QN_PICK(32, QN_ACT_IDENTITY)
+    QN_PICK(64, QN_ACT_RELU) QN_PICK(64, QN_ACT_IDENTITY)
+#undef QN_PICK
+    return nullptr;
+}
+#else
+
 bool uniform_hidden(const qn_desc* d, int* H, int* nhid) {
     if (d->nlayers < 2) return false;
     const int h = d->dims[1];
@@ -1156,8 +1186,6 @@ bool uniform_hidden(const qn_desc* d, int* H, int* nhid) {
     *nhid = d->nlayers - 1;
     return true;
 }
-
-constexpr int G_FWD = 2;
 
 bool streams(const qn_desc* d, int want_grad) { return !want_grad && d->nlayers >= 2 && d->dims[1] == HS; }
 
@@ -1202,15 +1230,16 @@ void plan(const qn_desc* d, int B, int Nb, int want_grad, FusedArgs* a) {
     a->iters = rps / rows_it;
 }
 
+constexpr int DBWD = 8;                                    // inputs of the gradient kernel: DP = 4 (part 0) or 8 (part 1)
+inline int bwd_dp(int d) { return d <= DMAX ? DMAX : DBWD; }
 size_t lds_need(int H, int d, int o, int nhid, int want_grad) {
     if (H == HS) return sizeof(double) * (size_t)(stream_lds_doubles(padded_d(d), o, nhid) + 2);
-    return sizeof(double) * (size_t)((want_grad ? bwd_lds_doubles(H, 4, o, nhid) : lds_doubles(H, padded_d(d), o, nhid)) +
+    return sizeof(double) * (size_t)((want_grad ? bwd_lds_doubles(H, bwd_dp(d), o, nhid) : lds_doubles(H, padded_d(d), o, nhid)) +
                                      2 + TANH_TAB);
 }
 
 using fwd_fn = qn_fwd_fn;
-using bwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*,
-                        double*, const int*, double*, double*, unsigned long long*);
+using bwd_fn = qn_bwd_f64_fn;
 
 // Forward geometry: 4 waves x 2 row groups per workgroup (2 workgroups / CU, 2 waves / SIMD).  The
 // alternative 8 waves x 1 row group (4 waves / SIMD, same 128 rows per iteration) measured 3.5 % slower
@@ -1221,7 +1250,7 @@ fwd_fn pick_fwd(int H, int act, int dp, int o) {
     if (H == HH && dp == DD)                                                                      \
         return o > OMAX ? k_fused_fwd_f64<HH, G_FWD, QN_ACT_TANH, DD, WG, OWIDE>                  \
                         : k_fused_fwd_f64<HH, G_FWD, QN_ACT_TANH, DD, WG, OMAX>;
-        if (act != QN_ACT_TANH) return nullptr;
+        if (act != QN_ACT_TANH) return dp == 8 && o <= OMAX ? qn_fused_fwd_d8_kernel(H, act) : nullptr;
         QN_PICKW(16, 2) QN_PICKW(16, 4) QN_PICKW(16, 8) QN_PICKW(16, 16)
         QN_PICKW(32, 2) QN_PICKW(32, 4) QN_PICKW(32, 8) QN_PICKW(32, 16)
         QN_PICKW(64, 2) QN_PICKW(64, 4) QN_PICKW(64, 8) QN_PICKW(64, 16)
@@ -1245,7 +1274,9 @@ fwd_fn pick_fwd(int H, int act, int dp, int o) {
     return nullptr;
 }
 
-bwd_fn pick_bwd(int H, int nhid, int act = QN_ACT_TANH) {
+bwd_fn pick_bwd(int H, int nhid, int act = QN_ACT_TANH, int dp = DMAX) {
+    if (dp == DBWD) return qn_fused_bwd_d8_kernel(H, nhid, act);
+    if (dp != DMAX) return nullptr;
 #define QN_PICK(HH, NN) if (H == HH && nhid == NN) return act == QN_ACT_TANH ? k_fused_bwd_f64<HH, NN, 4, false> : k_fused_bwd_f64<HH, NN, 4, true>;
     QN_PICK(16, 1) QN_PICK(16, 2) QN_PICK(16, 3) QN_PICK(16, 4)
     QN_PICK(32, 1) QN_PICK(32, 2) QN_PICK(32, 3) QN_PICK(32, 4)
@@ -1284,10 +1315,13 @@ bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtyp
     if (H != 16 && H != 32 && H != 64 && H != HS) return false;
     const int din = d->dims[0], dout = d->dims[d->nlayers];
     if (din > DMAX || dout > OMAX) {
-        // wide first / last layer: forward kernel only, tanh, hidden width <= 64
-        if (want_grad || H == HS || d->act != QN_ACT_TANH || din > DWIDE || dout > OWIDE) return false;
+        // wide first / last layer, hidden width <= 64.  Forward: tanh up to 16 inputs / outputs; relu / identity up to 8 inputs
+        // (and 4 outputs).  Gradient: up to 8 inputs (and 4 outputs), any activation.
+        if (H == HS || din > DWIDE || dout > OWIDE) return false;
+        if (want_grad ? (din > DBWD || dout > OMAX) : (d->act != QN_ACT_TANH && (din > 8 || dout > OMAX))) return false;
     }
-    if (want_grad && !pick_bwd(H, nhid)) return false;
+    if (want_grad && !pick_bwd(H, nhid, d->act, bwd_dp(din))) return false;
+    if (!want_grad && !pick_fwd(H, d->act, padded_d(din), dout)) return false;
     return lds_need(H, d->dims[0], d->dims[d->nlayers], nhid, want_grad) <= 160 * 1024;
 }
 
@@ -1356,7 +1390,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
         hipLaunchKernelGGL(kern, grid, dim3(H == HS ? NTS : WG), lds_bytes, st, a, (const double*)W,
                            (const double*)X, (const double*)Y, row_idx, (double*)pred, partial, arrive, sse);
     } else {
-        bwd_fn kern = pick_bwd(H, nhid, d->act);
+        bwd_fn kern = pick_bwd(H, nhid, d->act, bwd_dp(a.d));
         if (!kern) {
             qn_set_error("qn_fused_run: no backward kernel instance for H=%d nhid=%d", H, nhid);
             return QN_EUNSUPPORTED;
@@ -1396,3 +1430,4 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }
+#endif  // QN_FUSED_PART != 1

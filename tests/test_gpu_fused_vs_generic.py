@@ -227,7 +227,8 @@ def test_partial_sums_add_up_to_the_sse_bit_for_bit(dims, N, B):
                                   (8, 11, 11, 11, 12)])
 def test_wide_first_and_last_layer_in_the_fused_forward(dims):
     """Up to 16 inputs / outputs (tanh): the fused FORWARD kernel takes them (inputs / targets beyond 4 are read where
-    they are used instead of being prefetched); the gradient of such a network runs on the layer-wise kernels."""
+    they are used instead of being prefetched); the gradient runs on the fused kernel up to 8 inputs and 4 outputs (round 4),
+    beyond that on the layer-wise kernels."""
     rs = np.random.RandomState(sum(dims))
     arch = MLPArch(dims, "tanh")
     N, B = 777, 4
@@ -235,7 +236,8 @@ def test_wide_first_and_last_layer_in_the_fused_forward(dims):
     W = rs.randn(B, arch.nparams) / np.sqrt(max(dims))
     idx = rs.randint(0, N, size=(B, 300))
     op = BatchedMLP(arch, x, y)
-    assert op.path(B, N, False) == _lib.PATH_FUSED and op.path(B, N, True) == _lib.PATH_GENERIC
+    grad_fused = dims[0] <= 8 and dims[-1] <= 4
+    assert op.path(B, N, False) == _lib.PATH_FUSED and op.path(B, N, True) == (_lib.PATH_FUSED if grad_fused else _lib.PATH_GENERIC)
     L = _lib.lib()
     res = {}
     for path in (_lib.PATH_GENERIC, _lib.PATH_AUTO):
@@ -259,6 +261,61 @@ def test_wide_first_and_last_layer_in_the_fused_forward(dims):
     finally:
         op2.set_path(old)
     np.testing.assert_allclose(op2.sse(W).cpu().numpy(), ref, rtol=1e-12, equal_nan=True)
+
+
+def _d8_cases():
+    """5..8 inputs: the gradient kernel's DP = 8 instances (every width / depth the kernel has, tanh and the unbounded activations)
+    and the relu / identity forward's."""
+    rs = np.random.RandomState(808)
+    out = []
+    for H, NH in [(16, 1), (16, 2), (16, 3), (16, 4), (32, 1), (32, 2), (32, 3), (32, 4), (64, 1), (64, 2), (64, 3), (50, 2), (11, 3)]:
+        for act in ("tanh", "relu", "identity"):
+            d, o = int(rs.randint(5, 9)), int(rs.randint(1, 5))
+            out.append(((d,) + (H,) * NH + (o,), act, bool(rs.rand() < 0.8), int(rs.choice([1, 63, 64, 65, 200, 513])),
+                        int(rs.randint(1, 7)), bool(rs.rand() < 0.4)))
+    return out
+
+
+@pytest.mark.parametrize("case", _d8_cases(), ids=lambda c: f"{c[0]}-{c[1]}-b{int(c[2])}-N{c[3]}-B{c[4]}-idx{int(c[5])}")
+def test_five_to_eight_inputs_on_the_fused_kernels(case):
+    """Networks with 5..8 inputs (and up to 4 outputs): gradient and forward of every activation run on the fused float64-MFMA
+    kernels (k_fused_bwd_f64<H, NH, 8, UNB>, k_fused_fwd_f64<.., 8>; qn_fused_d8.hip) and agree with the layer-wise kernels."""
+    dims, act, bias, N, B, use_idx = case
+    rs = np.random.RandomState(sum(dims) * 1000 + N * 7 + B)
+    arch = MLPArch(dims, act, bias)
+    x, y = rs.randn(N, dims[0]), rs.randn(N, dims[-1])
+    W = rs.randn(B, arch.nparams) / np.sqrt(max(dims))
+    idx = rs.randint(0, N, size=(B, max(1, N // 2 + 3))) if use_idx else None
+    op = BatchedMLP(arch, x, y)
+    assert op.path(B, N, True) == _lib.PATH_FUSED and op.path(B, N, False) == _lib.PATH_FUSED
+    res = {}
+    for path in (_lib.PATH_GENERIC, _lib.PATH_AUTO):
+        old = op.set_path(path)
+        try:
+            s, g = op.sse_grad(W, row_idx=idx)
+            s2, pr = op.sse_pred(W, row_idx=idx)
+        finally:
+            op.set_path(old)
+        res[path] = (s.cpu().numpy(), g.cpu().numpy(), s2.cpu().numpy(), pr.cpu().numpy())
+    a, b = res[_lib.PATH_GENERIC], res[_lib.PATH_AUTO]
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-12)
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-12)
+    assert np.abs(b[1] - a[1]).max() <= 1e-10 * max(np.abs(a[1]).max(), 1e-300)
+    np.testing.assert_allclose(b[3], a[3], rtol=1e-11, atol=1e-12)
+    # a not-finite input in the LAST column (beyond the four the DP = 4 instances hold): same NaN pattern as the layer-wise kernels
+    if N > 5:
+        x2 = x.copy(); x2[5, dims[0] - 1] = np.inf
+        op2 = BatchedMLP(arch, x2, y)
+        out = {}
+        for path in (_lib.PATH_GENERIC, _lib.PATH_AUTO):
+            old = op2.set_path(path)
+            try:
+                s, g = op2.sse_grad(W)
+            finally:
+                op2.set_path(old)
+            out[path] = (s.cpu().numpy(), g.cpu().numpy())
+        np.testing.assert_array_equal(np.isnan(out[_lib.PATH_AUTO][0]), np.isnan(out[_lib.PATH_GENERIC][0]))
+        np.testing.assert_array_equal(np.isfinite(out[_lib.PATH_AUTO][1]), np.isfinite(out[_lib.PATH_GENERIC][1]))
 
 
 def _dispatch_cases(n=120, seed=2024):

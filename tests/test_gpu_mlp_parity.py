@@ -70,6 +70,9 @@ CASES = [  # dims, activ, bias, N, B
     ((1, 32, 32, 1), "relu", False, 1, 2),           # one data row
     ((2, 128, 128, 1), "tanh", True, 777, 1),        # MFMA GEMM layer path with split-K dW (ragged rows)
     ((1, 64, 128, 64, 2), "relu", True, 300, 3),     # non-uniform widths, all multiples of 64
+    ((6, 64, 64, 64, 1), "tanh", True, 200, 3),      # 5..8 inputs: fused float64 kernels' DP = 8 instances (qn_fused_d8.hip)
+    ((8, 32, 32, 2), "relu", True, 129, 3),
+    ((5, 20, 20, 20, 1), "identity", False, 65, 2),  # (and on a zero-padded twin)
 ]
 
 
