@@ -24,7 +24,7 @@
 // k-slots), C/D: lane (q, c) holds features 16 t + 4 q + r (r = 0..3) of row c.  The k-slot <-> feature map is free
 // as long as both operands use it: byte j of lane group q is feature 16 (j >> 2) + 4 q + (j & 3), which makes the four
 // results of output tile t exactly bytes 4 t .. 4 t + 3 of the NEXT layer's B operand: activations go
-// accumulator -> float64 (tanh) -> digits -> operand without leaving the lane.  First layer (d <= 4) and last layer
+// accumulator -> float64 (tanh) -> digits -> operand without leaving the lane.  First layer (d <= 8: DP = 2, 4 or 8 padded input columns) and last layer
 // (o <= 4) on the VALU as in k_fused_fwd_f64; the last hidden layer's outputs are consumed as float64 (no slicing).
 //
 // Anything that could make a NaN / inf (a weight or input that is not finite and < 2^500) leaves the fast path: the
@@ -644,7 +644,7 @@ int qn_fused_i8_rows_per_iteration() { return (WGT / 64) * 16 * G; }
 bool qn_fused_i8_applies(int Hh, int nhid, int act, int d, int o) {
     // (1..4 outputs: the 4-output instance took ~170 spilled registers in round 2; with the shorter tanh tail and the
     // constants out of the way it fits -- 216 registers, no scratch)
-    if (Hh != H || (act != QN_ACT_TANH && act != QN_ACT_RELU && act != QN_ACT_IDENTITY) || nhid < 2 || d > 4 || o < 1 || o > OMAX) return false;
+    if (Hh != H || (act != QN_ACT_TANH && act != QN_ACT_RELU && act != QN_ACT_IDENTITY) || nhid < 2 || d > 8 || o < 1 || o > OMAX) return false;
 #ifdef QN_I8_TANH_ONLY
     if (act != QN_ACT_TANH) return false;                      // A/B builds: relu / identity on the float64-MFMA kernel
 #endif
@@ -652,11 +652,13 @@ bool qn_fused_i8_applies(int Hh, int nhid, int act, int d, int o) {
     return qn_fused_i8_lds_bytes(d, nhid) <= 160 * 1024;
 }
 size_t qn_fused_i8_lds_bytes(int d, int nhid) {
-    const int dp = d <= 2 ? 2 : 4;
+    const int dp = d <= 2 ? 2 : d <= 4 ? 4 : 8;
     return sizeof(double) * (size_t)head_doubles(dp, nhid) + (size_t)(nhid - 1) * LAYER_BYTES;
 }
 template <int ACT>
 static qn_fwd_fn pick_i8(int d, int o) {
+    // (5..8 inputs, round 4: the first layer is a VALU dot over DP padded input columns)
+    if (d > 4) return o > 1 ? k_fused_fwd_i8<8, QN_I8_LMIN, OMAX, ACT> : k_fused_fwd_i8<8, QN_I8_LMIN, 1, ACT>;
     if (o > 1) return d <= 2 ? k_fused_fwd_i8<2, QN_I8_LMIN, OMAX, ACT> : k_fused_fwd_i8<4, QN_I8_LMIN, OMAX, ACT>;
     return d <= 2 ? k_fused_fwd_i8<2, QN_I8_LMIN, 1, ACT> : k_fused_fwd_i8<4, QN_I8_LMIN, 1, ACT>;
 }

@@ -34,8 +34,9 @@ def _both(op, fn):
 
 @pytest.mark.parametrize("dims,N,B,wscale", [((1, 64, 64, 64, 1), 4096, 64, 0.1), ((1, 64, 64, 1), 300, 5, 1.0),
                                              ((3, 64, 64, 64, 64, 2), 257, 3, 0.3), ((4, 64, 64, 4), 64, 2, 3.0),
-                                             ((2, 64, 64, 64, 1), 1000, 9, 1e-3), ((1, 50, 50, 50, 1), 333, 4, 0.2)],
-                         ids=["cfg2", "2hid", "4hid_d3_o2", "d4_o4_bigw", "tinyw", "padded50"])
+                                             ((2, 64, 64, 64, 1), 1000, 9, 1e-3), ((1, 50, 50, 50, 1), 333, 4, 0.2),
+                                             ((6, 64, 64, 64, 1), 777, 5, 0.2), ((8, 64, 64, 3), 129, 3, 0.5), ((5, 40, 40, 1), 300, 4, 0.3)],
+                         ids=["cfg2", "2hid", "4hid_d3_o2", "d4_o4_bigw", "tinyw", "padded50", "d6", "d8_o3", "d5_padded40"])
 @pytest.mark.parametrize("act", ["tanh", "relu", "identity"])
 def test_matches_oracle_and_float64_kernels(dims, N, B, wscale, act):
     x, y = _data(N, dims[0], dims[-1])
@@ -83,22 +84,22 @@ def test_row_subsets_and_ragged_tail(o, act):
 
 
 @pytest.mark.parametrize("where", ["weight_nan", "weight_inf", "weight_huge", "bias_nan", "x_nan", "x_inf", "y_nan", "w0_inf"])
-@pytest.mark.parametrize("o", [1, 3])                                   # (o > 1: the 4-output instance of the int8-slice kernel)
+@pytest.mark.parametrize("o,d", [(1, 1), (3, 1), (1, 7)])                 # (o > 1: the 4-output instance of the int8-slice kernel; d = 7: the 8-column one)
 @pytest.mark.parametrize("act", ["tanh", "relu", "identity"])
-def test_exceptional_values_follow_the_layerwise_kernels(where, o, act):
-    dims = (1, 64, 64, 64, o)
+def test_exceptional_values_follow_the_layerwise_kernels(where, o, d, act):
+    dims = (d, 64, 64, 64, o)
     arch = MLPArch(dims, act)
-    x, y = _data(200, 1, o, seed=1)
+    x, y = _data(200, d, o, seed=1)
     rs = np.random.RandomState(2)
     W = 0.2 * rs.randn(3, arch.nparams)
-    off_w1 = 64 + 64 + 5 * 64 + 7                                        # an entry of the first hidden matrix
+    off_w1 = 64 * d + 64 + 5 * 64 + 7                                    # an entry of the first hidden matrix
     if where == "weight_nan": W[1, off_w1] = np.nan
     if where == "weight_inf": W[1, off_w1] = np.inf
     if where == "weight_huge": W[1, off_w1] = 1e200
-    if where == "bias_nan": W[1, 64 + 3] = np.nan
-    if where == "w0_inf": W[1, 3] = -np.inf
-    if where == "x_nan": x[17, 0] = np.nan
-    if where == "x_inf": x[150, 0] = -np.inf
+    if where == "bias_nan": W[1, 64 * d + 3] = np.nan
+    if where == "w0_inf": W[1, 3 * d + d - 1] = -np.inf
+    if where == "x_nan": x[17, d - 1] = np.nan
+    if where == "x_inf": x[150, d - 1] = -np.inf
     if where == "y_nan": y[17, 0] = np.nan
     op = BatchedMLP(arch, x, y)
     (s8, p8), (sd, pd), (sg, pg) = _both(op, lambda: tuple(t.cpu().numpy() for t in op.sse_pred(W)))
