@@ -167,7 +167,7 @@ def run_mcmc(ncases=12, seed=0, verbose=True):
     nfail = 0
     try:
         for case in range(ncases):
-            d = int(rs.randint(1, 4)); o = int(rs.choice([1, 1, 2])); hid = tuple(int(v) for v in rs.choice([2, 3, 5, 8, 16, 64, 70], size=rs.randint(1, 4)))
+            d = int(rs.choice([1, 2, 3, 3, 6, 8])); o = int(rs.choice([1, 1, 2])); hid = tuple(int(v) for v in rs.choice([2, 3, 5, 8, 16, 64, 70], size=rs.randint(1, 4)))
             act = str(rs.choice(["tanh", "relu"])); N = int(rs.randint(5, 300)); sigma = float(rs.choice([0.05, 0.2, 1.0]))
             sampler = str(rs.choice(["amcmc", "amcmc", "hmc", "mala"])); C = int(rs.randint(1, 5)); nmcmc = int(rs.randint(40, 160))
             seeds = [int(v) for v in rs.randint(0, 10000, size=C)]
@@ -311,7 +311,7 @@ def run_fit(ncases=30, seed=0, verbose=True):
     flat = lambda m: np.concatenate([q.detach().flatten().cpu().numpy() for q in m.parameters()])
     try:
         for case in range(ncases):
-            d = int(rs.randint(1, 4)); o = int(rs.choice([1, 1, 2])); hid = tuple(int(v) for v in rs.choice([3, 8, 11, 32, 64, 70, 128], size=rs.randint(1, 4)))
+            d = int(rs.choice([1, 2, 3, 3, 6, 8])); o = int(rs.choice([1, 1, 2])); hid = tuple(int(v) for v in rs.choice([3, 8, 11, 32, 64, 70, 128], size=rs.randint(1, 4)))
             act = str(rs.choice(["tanh", "tanh", "relu"])); N = int(rs.randint(2, 200)); Nv = int(rs.randint(1, 60))
             bs = None if rs.rand() < 0.3 else int(rs.randint(1, N + 5)); opt = str(rs.choice(["adam", "adam", "sgd"]))
             lr = float(rs.choice([1e-3, 1e-2, 5e-2])); wd = float(rs.choice([0.0, 1e-3, 0.1])); nep = int(rs.randint(1, 9))
@@ -376,7 +376,7 @@ def run_ens(ncases=12, seed=0, verbose=True):
     nfail = 0
     try:
         for case in range(ncases):
-            d = int(rs.randint(1, 4)); o = int(rs.choice([1, 1, 2])); hid = tuple(int(v) for v in rs.choice([3, 8, 11, 32, 64, 70, 128], size=rs.randint(1, 4)))
+            d = int(rs.choice([1, 2, 3, 3, 6, 8])); o = int(rs.choice([1, 1, 2])); hid = tuple(int(v) for v in rs.choice([3, 8, 11, 32, 64, 70, 128], size=rs.randint(1, 4)))
             act = str(rs.choice(["tanh", "tanh", "relu"])); N = int(rs.randint(4, 150)); Nv = int(rs.randint(1, 40))
             M = int(rs.randint(1, 7)); dfrac = float(rs.choice([1.0, 0.8, 0.5])); kind = str(rs.choice(["ens", "ens", "rms"]))
             bs = None if rs.rand() < 0.3 else int(rs.randint(1, N + 5)); lr = float(rs.choice([1e-3, 1e-2, 5e-2])); nep = int(rs.randint(1, 7))
@@ -478,7 +478,7 @@ def run_device(ncases=20, seed=0, verbose=True):
     nfail = 0
     try:
         for case in range(ncases):
-            d = int(rs.randint(1, 4)); o = int(rs.choice([1, 1, 2])); hid = tuple(int(v) for v in rs.choice([4, 8, 11, 16, 33, 64, 64, 100, 128], size=rs.randint(1, 4)))
+            d = int(rs.choice([1, 2, 3, 3, 6, 8])); o = int(rs.choice([1, 1, 2])); hid = tuple(int(v) for v in rs.choice([4, 8, 11, 16, 33, 64, 64, 100, 128], size=rs.randint(1, 4)))
             act = str(rs.choice(["tanh", "tanh", "relu"])); N = int(rs.randint(3, 500)); sigma = float(rs.choice([0.1, 0.3, 1.0]))
             sampler = str(rs.choice(["amcmc", "hmc"])); C = int(rs.choice([1, 3, 8, 20])); nmcmc = int(rs.randint(30, 120))
             x = rs.rand(N, d) * 4 - 2; y = np.sin(x.sum(axis=1, keepdims=True)) * np.ones((1, o)) + sigma * rs.randn(N, o)
@@ -527,7 +527,7 @@ def run_vi(ncases=40, seed=0, verbose=True):
     worst = [0.0, 0.0]; nfail = 0
     try:
         for case in range(ncases):
-            d = int(rs.randint(1, 5)); o = int(rs.choice([1, 1, 2, 3]))
+            d = int(rs.choice([1, 2, 3, 4, 5, 7])); o = int(rs.choice([1, 1, 2, 3]))
             hid = tuple(int(v) for v in rs.choice([2, 5, 11, 16, 64, 64, 70, 128], size=rs.randint(1, 4)))
             act = str(rs.choice(["tanh", "tanh", "relu"])); N = int(rs.choice([rs.randint(1, 30), rs.randint(30, 500)])); S = int(rs.choice([1, 2, 5, 16, 33]))
             prior = dict(pi=float(rs.choice([0.5, 0.25, 1.0])), sigma1=float(rs.choice([1.0, 0.5, 2.0])), sigma2=float(rs.choice([1.0, 0.1, 0.0025])))
