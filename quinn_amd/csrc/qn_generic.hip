@@ -171,63 +171,10 @@ __global__ __launch_bounds__(BLK) void k_dW(LayerArgs a, const T* __restrict__ d
 #pragma unroll
         for (int kk = 0; kk < TK; ++kk) acc[jj][kk] = T(0);
     }
-    // float64, even row strides (the padded stashes of the wide int8 path always; any even row count otherwise): PAIRS of data rows
-    // per thread as 16-byte loads -- half the load instructions for the same bytes in flight (round 4: the first layer's
-    // k_dW<double, 8, 2> streams a whole dZ stash, 1.07 GB at cfg3, and ran at 3.7 TB/s with 8-byte loads)
-    int n_begin = threadIdx.x, n_step = BLK;
-    if constexpr (std::is_same<T, double>::value) {
-#ifdef QN_DW_SCALAR
-        const bool vec = false;                                // (A/B builds)
-        (void)n_step;
-#else
-        const bool vec0 = (a.Nsz & 1) == 0 && (a.first || (a.Nsa & 1) == 0) && (reinterpret_cast<uintptr_t>(dz) & 15) == 0 &&
-                          (a.first || (reinterpret_cast<uintptr_t>(a_prev) & 15) == 0);
-        const bool vec = vec0;
-#endif
-        if (vec) {
-            typedef double v2d __attribute__((ext_vector_type(2)));
-            const int npairs = a.Nb >> 1;
-#pragma unroll 2
-            for (int m = threadIdx.x; m < npairs; m += BLK) {
-                const int n = 2 * m;
-                v2d g[TJ];
-                double v0[TK], v1[TK];
-#pragma unroll
-                for (int jj = 0; jj < TJ; ++jj)
-                    g[jj] = (j0 + jj < a.h_out) ? *reinterpret_cast<const v2d*>(&dz[((int64_t)b * a.h_out + j0 + jj) * a.Nsz + n]) : (v2d){0.0, 0.0};
-                if (a.first) {
-                    int64_t r0 = n, r1 = n + 1;
-                    if (row_idx) { r0 = row_idx[(int64_t)b * a.Nb + n]; r1 = row_idx[(int64_t)b * a.Nb + n + 1]; }
-#pragma unroll
-                    for (int kk = 0; kk < TK; ++kk) {
-                        v0[kk] = (k0 + kk < a.h_in) ? X[r0 * a.d + k0 + kk] : 0.0;
-                        v1[kk] = (k0 + kk < a.h_in) ? X[r1 * a.d + k0 + kk] : 0.0;
-                    }
-                } else {
-#pragma unroll
-                    for (int kk = 0; kk < TK; ++kk) {
-                        const v2d t = (k0 + kk < a.h_in) ? *reinterpret_cast<const v2d*>(&a_prev[((int64_t)b * a.h_in + k0 + kk) * a.Nsa + n]) : (v2d){0.0, 0.0};
-                        v0[kk] = t.x; v1[kk] = t.y;
-                    }
-                }
-#pragma unroll
-                for (int jj = 0; jj < TJ; ++jj) {
-                    accb[jj] += g[jj].x;
-                    accb[jj] += g[jj].y;
-#pragma unroll
-                    for (int kk = 0; kk < TK; ++kk) {
-                        acc[jj][kk] = fma(g[jj].x, v0[kk], acc[jj][kk]);
-                        acc[jj][kk] = fma(g[jj].y, v1[kk], acc[jj][kk]);
-                    }
-                }
-            }
-            n_begin = 2 * npairs + threadIdx.x;                // (the odd last row, if any: thread 0 in the scalar loop below)
-        }
-    }
     // (thin shapes stream one operand from HBM: two row steps in flight per thread keep enough loads outstanding; four measured
     // the same at the cfg3 / cfg4 gradient: 4.18 / 17.5 ms either way)
 #pragma unroll 2
-    for (int n = n_begin; n < a.Nb; n += n_step) {
+    for (int n = threadIdx.x; n < a.Nb; n += BLK) {
         T g[TJ], v[TK];
 #pragma unroll
         for (int jj = 0; jj < TJ; ++jj)
