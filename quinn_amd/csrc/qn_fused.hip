@@ -31,7 +31,7 @@
 
 // Compiled as two objects: part 0 (this file) holds the kernels' instances with up to 4 inputs (forward, tanh: up to 16) and all
 // the host code; part 1 (qn_fused_d8.hip: `#define QN_FUSED_PART 1` + `#include` of this file) the instances for networks with
-// 5..8 inputs -- the gradient kernel k_fused_bwd_f64<H, NH, 8, UNB> and the relu / identity forward k_fused_fwd_f64<H, G, ACT, 8>
+// 5..16 inputs -- the gradient kernel k_fused_bwd_f64<H, NH, 8 | 16, UNB> and the relu / identity forward k_fused_fwd_f64<H, G, ACT, 8 | 16>
 // (round 4; until then such gradients ran on the layer-wise kernels) -- behind two pick functions.
 #ifndef QN_FUSED_PART
 #define QN_FUSED_PART 0
@@ -1160,18 +1160,23 @@ constexpr int G_FWD = 2;
 #if QN_FUSED_PART == 1
 }  // namespace
 
-qn_bwd_f64_fn qn_fused_bwd_d8_kernel(int H, int nhid, int act) {
-#define QN_PICK(HH, NN) if (H == HH && nhid == NN) return act == QN_ACT_TANH ? k_fused_bwd_f64<HH, NN, 8, false> : k_fused_bwd_f64<HH, NN, 8, true>;
-    QN_PICK(16, 1) QN_PICK(16, 2) QN_PICK(16, 3) QN_PICK(16, 4)
-    QN_PICK(32, 1) QN_PICK(32, 2) QN_PICK(32, 3) QN_PICK(32, 4)
-    QN_PICK(64, 1) QN_PICK(64, 2) QN_PICK(64, 3)
+// dp = 8, 16: every (H, NH) the kernel has (no spills; the largest LDS image, 3 x 64 with 16 inputs and 4 outputs, is 158 KB)
+qn_bwd_f64_fn qn_fused_bwd_d8_kernel(int H, int nhid, int act, int dp) {
+#define QN_PICK(HH, NN, DD) if (H == HH && nhid == NN && dp == DD) return act == QN_ACT_TANH ? k_fused_bwd_f64<HH, NN, DD, false> : k_fused_bwd_f64<HH, NN, DD, true>;
+    QN_PICK(16, 1, 8) QN_PICK(16, 2, 8) QN_PICK(16, 3, 8) QN_PICK(16, 4, 8)
+    QN_PICK(32, 1, 8) QN_PICK(32, 2, 8) QN_PICK(32, 3, 8) QN_PICK(32, 4, 8)
+    QN_PICK(64, 1, 8) QN_PICK(64, 2, 8) QN_PICK(64, 3, 8)
+    QN_PICK(16, 1, 16) QN_PICK(16, 2, 16) QN_PICK(16, 3, 16) QN_PICK(16, 4, 16)
+    QN_PICK(32, 1, 16) QN_PICK(32, 2, 16) QN_PICK(32, 3, 16) QN_PICK(32, 4, 16)
+    QN_PICK(64, 1, 16) QN_PICK(64, 2, 16) QN_PICK(64, 3, 16)
 #undef QN_PICK
     return nullptr;
 }
-qn_fwd_fn qn_fused_fwd_d8_kernel(int H, int act) {
-#define QN_PICK(HH, AA) if (H == HH && act == AA) return k_fused_fwd_f64<HH, G_FWD, AA, 8, WG>;
-    QN_PICK(16, QN_ACT_RELU) QN_PICK(16, QN_ACT_IDENTITY) QN_PICK(32, QN_ACT_RELU) QN_PICK(32, QN_ACT_IDENTITY)
-    QN_PICK(64, QN_ACT_RELU) QN_PICK(64, QN_ACT_IDENTITY)
+qn_fwd_fn qn_fused_fwd_d8_kernel(int H, int act, int dp) {
+#define QN_PICK(HH, AA, DD) if (H == HH && act == AA && dp == DD) return k_fused_fwd_f64<HH, G_FWD, AA, DD, WG>;
+#define QN_PICK_A(HH, DD) QN_PICK(HH, QN_ACT_RELU, DD) QN_PICK(HH, QN_ACT_IDENTITY, DD)
+    QN_PICK_A(16, 8) QN_PICK_A(32, 8) QN_PICK_A(64, 8) QN_PICK_A(16, 16) QN_PICK_A(32, 16) QN_PICK_A(64, 16)
+#undef QN_PICK_A
 #undef QN_PICK
     return nullptr;
 }
@@ -1230,8 +1235,8 @@ void plan(const qn_desc* d, int B, int Nb, int want_grad, FusedArgs* a) {
     a->iters = rps / rows_it;
 }
 
-constexpr int DBWD = 8;                                    // inputs of the gradient kernel: DP = 4 (part 0) or 8 (part 1)
-inline int bwd_dp(int d) { return d <= DMAX ? DMAX : DBWD; }
+constexpr int DBWD = 16;                                   // inputs of the gradient kernel: DP = 4 (part 0), 8 or 16 (part 1)
+inline int bwd_dp(int d) { return d <= DMAX ? DMAX : d <= 8 ? 8 : 16; }
 size_t lds_need(int H, int d, int o, int nhid, int want_grad) {
     if (H == HS) return sizeof(double) * (size_t)(stream_lds_doubles(padded_d(d), o, nhid) + 2);
     return sizeof(double) * (size_t)((want_grad ? bwd_lds_doubles(H, bwd_dp(d), o, nhid) : lds_doubles(H, padded_d(d), o, nhid)) +
@@ -1250,7 +1255,7 @@ fwd_fn pick_fwd(int H, int act, int dp, int o) {
     if (H == HH && dp == DD)                                                                      \
         return o > OMAX ? k_fused_fwd_f64<HH, G_FWD, QN_ACT_TANH, DD, WG, OWIDE>                  \
                         : k_fused_fwd_f64<HH, G_FWD, QN_ACT_TANH, DD, WG, OMAX>;
-        if (act != QN_ACT_TANH) return dp == 8 && o <= OMAX ? qn_fused_fwd_d8_kernel(H, act) : nullptr;
+        if (act != QN_ACT_TANH) return o <= OMAX ? qn_fused_fwd_d8_kernel(H, act, dp) : nullptr;
         QN_PICKW(16, 2) QN_PICKW(16, 4) QN_PICKW(16, 8) QN_PICKW(16, 16)
         QN_PICKW(32, 2) QN_PICKW(32, 4) QN_PICKW(32, 8) QN_PICKW(32, 16)
         QN_PICKW(64, 2) QN_PICKW(64, 4) QN_PICKW(64, 8) QN_PICKW(64, 16)
@@ -1275,8 +1280,7 @@ fwd_fn pick_fwd(int H, int act, int dp, int o) {
 }
 
 bwd_fn pick_bwd(int H, int nhid, int act = QN_ACT_TANH, int dp = DMAX) {
-    if (dp == DBWD) return qn_fused_bwd_d8_kernel(H, nhid, act);
-    if (dp != DMAX) return nullptr;
+    if (dp != DMAX) return qn_fused_bwd_d8_kernel(H, nhid, act, dp);
 #define QN_PICK(HH, NN) if (H == HH && nhid == NN) return act == QN_ACT_TANH ? k_fused_bwd_f64<HH, NN, 4, false> : k_fused_bwd_f64<HH, NN, 4, true>;
     QN_PICK(16, 1) QN_PICK(16, 2) QN_PICK(16, 3) QN_PICK(16, 4)
     QN_PICK(32, 1) QN_PICK(32, 2) QN_PICK(32, 3) QN_PICK(32, 4)
@@ -1315,10 +1319,10 @@ bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtyp
     if (H != 16 && H != 32 && H != 64 && H != HS) return false;
     const int din = d->dims[0], dout = d->dims[d->nlayers];
     if (din > DMAX || dout > OMAX) {
-        // wide first / last layer, hidden width <= 64.  Forward: tanh up to 16 inputs / outputs; relu / identity up to 8 inputs
-        // (and 4 outputs).  Gradient: up to 8 inputs (and 4 outputs), any activation.
+        // wide first / last layer, hidden width <= 64.  Forward: up to 16 inputs; tanh up to 16 outputs, relu / identity 4.
+        // Gradient, any activation: up to 4 outputs and 16 inputs.
         if (H == HS || din > DWIDE || dout > OWIDE) return false;
-        if (want_grad ? (din > DBWD || dout > OMAX) : (d->act != QN_ACT_TANH && (din > 8 || dout > OMAX))) return false;
+        if (want_grad ? dout > OMAX : (d->act != QN_ACT_TANH && dout > OMAX)) return false;
     }
     if (want_grad && !pick_bwd(H, nhid, d->act, bwd_dp(din))) return false;
     if (!want_grad && !pick_fwd(H, d->act, padded_d(din), dout)) return false;

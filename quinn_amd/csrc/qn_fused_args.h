@@ -92,12 +92,13 @@ __device__ __forceinline__ void qn_sse_finish(double* __restrict__ partial, unsi
 using qn_fwd_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*,
                            unsigned long long*, double*);
 
-// float64-MFMA fused kernels for networks with 5..8 inputs (qn_fused_d8.hip, the second object of qn_fused.hip): the gradient
-// kernel k_fused_bwd_f64<H, NH, 8, UNB> and the relu / identity forward k_fused_fwd_f64<H, G, ACT, 8>; null = no such instance
+// float64-MFMA fused kernels for networks with 5..16 inputs (qn_fused_d8.hip, the second object of qn_fused.hip): the gradient
+// kernel k_fused_bwd_f64<H, NH, dp, UNB> (dp = 8, 16) and the relu / identity forward
+// k_fused_fwd_f64<H, G, ACT, dp> (dp = 8, 16); null = no such instance
 using qn_bwd_f64_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*,
                                double*, const int*, double*, double*, unsigned long long*);
-qn_bwd_f64_fn qn_fused_bwd_d8_kernel(int H, int nhid, int act);
-qn_fwd_fn qn_fused_fwd_d8_kernel(int H, int act);
+qn_bwd_f64_fn qn_fused_bwd_d8_kernel(int H, int nhid, int act, int dp);
+qn_fwd_fn qn_fused_fwd_d8_kernel(int H, int act, int dp);
 
 // sliced int8-product forward for 64-wide tanh networks (qn_fused_i8.hip): same grid, block and partial-sum
 // conventions as k_fused_fwd_f64<64, 2, tanh, DP, 256>

@@ -227,8 +227,8 @@ def test_partial_sums_add_up_to_the_sse_bit_for_bit(dims, N, B):
                                   (8, 11, 11, 11, 12)])
 def test_wide_first_and_last_layer_in_the_fused_forward(dims):
     """Up to 16 inputs / outputs (tanh): the fused FORWARD kernel takes them (inputs / targets beyond 4 are read where
-    they are used instead of being prefetched); the gradient runs on the fused kernel up to 8 inputs and 4 outputs (round 4),
-    beyond that on the layer-wise kernels."""
+    they are used instead of being prefetched); the gradient runs on the fused kernel up to 16 inputs and
+    4 outputs (round 4), beyond that on the layer-wise kernels."""
     rs = np.random.RandomState(sum(dims))
     arch = MLPArch(dims, "tanh")
     N, B = 777, 4
@@ -236,7 +236,7 @@ def test_wide_first_and_last_layer_in_the_fused_forward(dims):
     W = rs.randn(B, arch.nparams) / np.sqrt(max(dims))
     idx = rs.randint(0, N, size=(B, 300))
     op = BatchedMLP(arch, x, y)
-    grad_fused = dims[0] <= 8 and dims[-1] <= 4
+    grad_fused = dims[-1] <= 4 and dims[0] <= 16
     assert op.path(B, N, False) == _lib.PATH_FUSED and op.path(B, N, True) == (_lib.PATH_FUSED if grad_fused else _lib.PATH_GENERIC)
     L = _lib.lib()
     res = {}
@@ -273,13 +273,20 @@ def _d8_cases():
             d, o = int(rs.randint(5, 9)), int(rs.randint(1, 5))
             out.append(((d,) + (H,) * NH + (o,), act, bool(rs.rand() < 0.8), int(rs.choice([1, 63, 64, 65, 200, 513])),
                         int(rs.randint(1, 7)), bool(rs.rand() < 0.4)))
+    # 9..16 inputs: the gradient kernel's DP = 16 instances (hidden widths 16 / 32 / 64 and their zero-padded twins)
+    for H, NH in [(16, 1), (16, 2), (16, 3), (16, 4), (32, 1), (32, 2), (32, 3), (32, 4), (11, 3), (20, 2), (64, 1), (64, 2), (64, 3), (50, 2)]:
+        for act in ("tanh", "relu", "identity"):
+            d, o = int(rs.randint(9, 17)), int(rs.randint(1, 5))
+            out.append(((d,) + (H,) * NH + (o,), act, bool(rs.rand() < 0.8), int(rs.choice([1, 63, 64, 65, 200, 513])),
+                        int(rs.randint(1, 7)), bool(rs.rand() < 0.4)))
     return out
 
 
 @pytest.mark.parametrize("case", _d8_cases(), ids=lambda c: f"{c[0]}-{c[1]}-b{int(c[2])}-N{c[3]}-B{c[4]}-idx{int(c[5])}")
 def test_five_to_eight_inputs_on_the_fused_kernels(case):
-    """Networks with 5..8 inputs (and up to 4 outputs): gradient and forward of every activation run on the fused float64-MFMA
-    kernels (k_fused_bwd_f64<H, NH, 8, UNB>, k_fused_fwd_f64<.., 8>; qn_fused_d8.hip) and agree with the layer-wise kernels."""
+    """Networks with 5..16 inputs and up to 4 outputs: gradient and forward of every activation
+    run on the fused float64-MFMA kernels (k_fused_bwd_f64<H, NH, 8 | 16, UNB>, k_fused_fwd_f64<.., 8 | 16>; qn_fused_d8.hip) and
+    agree with the layer-wise kernels."""
     dims, act, bias, N, B, use_idx = case
     rs = np.random.RandomState(sum(dims) * 1000 + N * 7 + B)
     arch = MLPArch(dims, act, bias)

@@ -73,6 +73,9 @@ CASES = [  # dims, activ, bias, N, B
     ((6, 64, 64, 64, 1), "tanh", True, 200, 3),      # 5..8 inputs: fused float64 kernels' DP = 8 instances (qn_fused_d8.hip)
     ((8, 32, 32, 2), "relu", True, 129, 3),
     ((5, 20, 20, 20, 1), "identity", False, 65, 2),  # (and on a zero-padded twin)
+    ((12, 32, 32, 1), "tanh", True, 150, 3),         # 9..16 inputs: DP = 16 instances
+    ((16, 16, 16, 16, 2), "relu", True, 77, 2),
+    ((10, 64, 64, 64, 1), "relu", True, 100, 2),
 ]
 
 
