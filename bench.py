@@ -268,12 +268,22 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cdev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    # QN_BENCH_FORCE_DIST=1: create the process group even for ONE rank (WORLD_SIZE=1 RANK=0 MASTER_PORT=... in the environment):
+    # on a one-GPU box this runs RCCL's communicator set-up, barrier, all_reduce and all_gather and the graph capture beside a
+    # live process group -- everything of the N > 1 path but the transport between ranks
+    if world > 1 or os.environ.get("QN_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # One process per GPU, started by torchrun (or by this script's parent, before it touched the GPU).  A rank whose RCCL
         # set-up fails says so in ONE line and exits non-zero: torchrun then ends the other ranks and returns that code; nothing
         # here restarts or re-execs a process that has initialised the GPU.
+        # RCCL announces itself on STDOUT when the first communicator is made ("RCCL version : ..." and four more lines, seen in the
+        # one-rank rehearsal on the GPU box): while the communicator is set up, file descriptor 1 points at stderr, so that rank 0's
+        # stdout carries the ONE JSON line and nothing else
+        import ctypes
+        sys.stdout.flush()
+        saved_out = os.dup(1)
+        os.dup2(2, 1)
         try:
             if backend == "nccl":
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -289,6 +299,14 @@ def main():
                   f"{str(e).splitlines()[0] if str(e) else ''} -- HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, "
                   f"MASTER_ADDR={os.environ.get('MASTER_ADDR')}, visible GPUs {torch.cuda.device_count()}", file=sys.stderr, flush=True)
             sys.exit(3)
+        finally:
+            sys.stdout.flush()
+            try:
+                ctypes.CDLL(None).fflush(None)                   # (the C library's buffered stdout, while it still goes to stderr)
+            except Exception:  # noqa: BLE001
+                pass
+            os.dup2(saved_out, 1)
+            os.close(saved_out)
 
     from quinn_amd.parallel import shard_bounds
     # this rank's chains [lo, hi) of the job's `total`; global chain id c: W[c] = 0.1*RandomState(1000+c).randn(p)
@@ -464,6 +482,8 @@ def main():
                "parallelism": f"chains sharded x{world}, no data-path collective, one all_gather at the end"}
         if backend != "nccl" and world > 1:
             cfg["rehearsal"] = f"{world} ranks share cuda:0 of a {torch.cuda.device_count()}-GPU box, {backend} collectives"
+        if dist is not None and world == 1:
+            cfg["rehearsal"] = f"one rank with a live {backend} process group (QN_BENCH_FORCE_DIST=1): communicator set-up, barriers, all_reduce, all_gather"
         res = {
             "metric": "log-posterior evals/sec (64 chains, 3x64 MLP, N=4096) at 1/2/4/8 GPU",
             "value": value, "unit": "log-posterior evals/s", "n_gpus": world, "steps": args.steps,

@@ -53,6 +53,25 @@ def test_bench_gpus_2_starts_two_ranks(scaling):
     assert d["config"]["timed_regions"] == 3 and len(d["config"]["region_ms_per_step"]) == 3
 
 
+def test_bench_one_rank_with_a_live_rccl_process_group_prints_one_json_line():
+    """QN_BENCH_FORCE_DIST=1: one rank creates the RCCL process group (communicator on cuda:0, the probe all_reduce, the barriers of
+    every timed region, the closing all_gather, graph capture beside the live group) -- everything of the driver's N > 1 launch but
+    the transport between ranks.  RCCL prints a version banner on stdout while the communicator is made: bench.py points fd 1 at
+    stderr for that time, so that stdout is exactly the one JSON line the driver parses."""
+    _no_gpu_yet()
+    from quinn_amd.parallel import free_port
+    env = dict(os.environ, QN_BENCH_FORCE_DIST="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("QN_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", "--regions", "3", "--no-extras",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = r.stdout.strip()
+    assert out.count("\n") == 0 and out.startswith("{") and out.endswith("}"), out[:400]
+    d = json.loads(out)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "nccl process group" in d["config"]["rehearsal"]
+
+
 def test_bench_rank_without_a_gpu_of_its_own_exits_with_one_clear_line():
     """Two RCCL ranks on a one-GPU box (launched as the driver launches them, no gloo rehearsal): the rank that has no GPU says
     so in one line and exits non-zero, torchrun ends the other one and returns a non-zero code; nothing hangs or restarts."""
