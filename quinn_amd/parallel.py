@@ -77,7 +77,10 @@ def gather_rows(local, n_total, dst="all", chunk_bytes=DEFAULT_CHUNK_BYTES, max_
         raise ValueError(f"gather mode {dst!r} is not one of {GATHER_MODES}")
     rank, world = dist_info()
     t = local if isinstance(local, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(local))
-    if world == 1 or dst == "none":
+    # (QN_FORCE_GATHER=1: a single rank with a live process group goes through the collectives too -- the one-GPU rehearsal of the
+    # RCCL path, tests/test_gpu_00_launch.py)
+    forced = os.environ.get("QN_FORCE_GATHER") == "1" and dist.is_available() and dist.is_initialized()
+    if (world == 1 and not forced) or dst == "none":
         return t.detach().cpu().numpy()
     lo, hi = shard_bounds(n_total, rank, world)
     if t.shape[0] != hi - lo:

@@ -72,6 +72,18 @@ def test_bench_one_rank_with_a_live_rccl_process_group_prints_one_json_line():
     assert d["n_gpus"] == 1 and d["value"] > 0 and "nccl process group" in d["config"]["rehearsal"]
 
 
+def test_gather_rows_through_rccl_with_one_rank():
+    """`quinn_amd.parallel.gather_rows` / `gather_results` on device tensors through RCCL's all_gather_into_tensor / gather (one
+    rank, QN_FORCE_GATHER=1): piece loop, every dtype the result dicts carry, root / all modes (tests/rccl_one_rank_worker.py)."""
+    _no_gpu_yet()
+    from quinn_amd.parallel import free_port
+    env = dict(os.environ, QN_FORCE_GATHER="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank_worker.py")], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.strip() == "rccl one-rank gather ok", r.stdout[-500:]
+
+
 def test_bench_rank_without_a_gpu_of_its_own_exits_with_one_clear_line():
     """Two RCCL ranks on a one-GPU box (launched as the driver launches them, no gloo rehearsal): the rank that has no GPU says
     so in one line and exits non-zero, torchrun ends the other one and returns a non-zero code; nothing hangs or restarts."""
