@@ -44,6 +44,34 @@ def main():
     got = gather_results(res, 3, gather="all", gather_chain="root")
     for k, v in res.items():
         assert np.array_equal(got[k], v.cpu().numpy()), k
+    # the solver path: NN_MCMC.fit(engine='device') gathers its result dict from the device buffers -- through RCCL (forced) and by
+    # the single-process short cut: same chains, bit for bit
+    from quinn_amd.nns.mlp import MLP
+    from quinn_amd.solvers.nn_mcmc import NN_MCMC
+    torch.set_default_dtype(torch.double)
+    x = rs.rand(200, 1) * 4 - 2
+    y = np.sin(2 * x) + 0.1 * rs.randn(200, 1)
+
+    def fit(sampler, gather):
+        torch.manual_seed(0)
+        uq = NN_MCMC(MLP(1, 1, (16, 16), activ='tanh'), verbose=False)
+        if sampler == "amcmc":
+            uq.fit(x, y, zflag=False, datanoise=0.1, nmcmc=300, sampler='amcmc', sampler_params={'gamma': 0.1, 't0': 50, 'tadapt': 100},
+                   seeds=range(5), engine='device', gather=gather)
+        else:
+            uq.fit(x, y, zflag=False, datanoise=0.1, nmcmc=40, sampler='hmc', sampler_params={'epsilon': 0.002, 'L': 3},
+                   seeds=range(5), engine='device', gather=gather)
+        return uq.mcmc_results
+
+    for sampler in ("amcmc", "hmc"):
+        for gather in ("all", "root"):
+            os.environ["QN_FORCE_GATHER"] = "1"
+            a = fit(sampler, gather)
+            os.environ["QN_FORCE_GATHER"] = "0"
+            b = fit(sampler, gather)
+            for k in a:
+                assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (sampler, gather, k)
+            assert np.isfinite(a["logpost"]).all() and a["chain"].shape[0] == 5
     dist.barrier()
     dist.destroy_process_group()
     print("rccl one-rank gather ok", flush=True)

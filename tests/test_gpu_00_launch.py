@@ -81,7 +81,7 @@ def test_gather_rows_through_rccl_with_one_rank():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank_worker.py")], capture_output=True, text=True,
                        timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert r.stdout.strip() == "rccl one-rank gather ok", r.stdout[-500:]
+    assert r.stdout.strip().splitlines()[-1] == "rccl one-rank gather ok", r.stdout[-500:]      # (MLP prints its parameter count, as the reference does)
 
 
 def test_bench_rank_without_a_gpu_of_its_own_exits_with_one_clear_line():
