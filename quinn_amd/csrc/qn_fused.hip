@@ -1172,11 +1172,18 @@ qn_bwd_f64_fn qn_fused_bwd_d8_kernel(int H, int nhid, int act, int dp) {
 #undef QN_PICK
     return nullptr;
 }
-qn_fwd_fn qn_fused_fwd_d8_kernel(int H, int act, int dp) {
-#define QN_PICK(HH, AA, DD) if (H == HH && act == AA && dp == DD) return k_fused_fwd_f64<HH, G_FWD, AA, DD, WG>;
+// relu / identity forward with a wide first or last layer (tanh: pick_fwd of part 0): more than 4 inputs, or -- `wide_out` -- 5..16 outputs
+qn_fwd_fn qn_fused_fwd_d8_kernel(int H, int act, int dp, int wide_out) {
+#define QN_PICK(HH, AA, DD) if (H == HH && act == AA && dp == DD && !wide_out) return k_fused_fwd_f64<HH, G_FWD, AA, DD, WG>;
+#define QN_PICKO(HH, AA, DD) if (H == HH && act == AA && dp == DD && wide_out) return k_fused_fwd_f64<HH, G_FWD, AA, DD, WG, OWIDE>;
 #define QN_PICK_A(HH, DD) QN_PICK(HH, QN_ACT_RELU, DD) QN_PICK(HH, QN_ACT_IDENTITY, DD)
-    QN_PICK_A(16, 8) QN_PICK_A(32, 8) QN_PICK_A(64, 8) QN_PICK_A(16, 16) QN_PICK_A(32, 16) QN_PICK_A(64, 16)
+#define QN_PICKO_A(HH, DD) QN_PICKO(HH, QN_ACT_RELU, DD) QN_PICKO(HH, QN_ACT_IDENTITY, DD)
+#define QN_PICK_H(HH) QN_PICK_A(HH, 8) QN_PICK_A(HH, 16) QN_PICKO_A(HH, 2) QN_PICKO_A(HH, 4) QN_PICKO_A(HH, 8) QN_PICKO_A(HH, 16)
+    QN_PICK_H(16) QN_PICK_H(32) QN_PICK_H(64)
+#undef QN_PICK_H
+#undef QN_PICKO_A
 #undef QN_PICK_A
+#undef QN_PICKO
 #undef QN_PICK
     return nullptr;
 }
@@ -1255,7 +1262,7 @@ fwd_fn pick_fwd(int H, int act, int dp, int o) {
     if (H == HH && dp == DD)                                                                      \
         return o > OMAX ? k_fused_fwd_f64<HH, G_FWD, QN_ACT_TANH, DD, WG, OWIDE>                  \
                         : k_fused_fwd_f64<HH, G_FWD, QN_ACT_TANH, DD, WG, OMAX>;
-        if (act != QN_ACT_TANH) return o <= OMAX ? qn_fused_fwd_d8_kernel(H, act, dp) : nullptr;
+        if (act != QN_ACT_TANH) return qn_fused_fwd_d8_kernel(H, act, dp, o > OMAX);
         QN_PICKW(16, 2) QN_PICKW(16, 4) QN_PICKW(16, 8) QN_PICKW(16, 16)
         QN_PICKW(32, 2) QN_PICKW(32, 4) QN_PICKW(32, 8) QN_PICKW(32, 16)
         QN_PICKW(64, 2) QN_PICKW(64, 4) QN_PICKW(64, 8) QN_PICKW(64, 16)
@@ -1319,10 +1326,9 @@ bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtyp
     if (H != 16 && H != 32 && H != 64 && H != HS) return false;
     const int din = d->dims[0], dout = d->dims[d->nlayers];
     if (din > DMAX || dout > OMAX) {
-        // wide first / last layer, hidden width <= 64.  Forward: up to 16 inputs; tanh up to 16 outputs, relu / identity 4.
-        // Gradient, any activation: up to 4 outputs and 16 inputs.
+        // wide first / last layer, hidden width <= 64.  Forward: up to 16 inputs and 16 outputs.  Gradient: up to 16 inputs and 4 outputs.
         if (H == HS || din > DWIDE || dout > OWIDE) return false;
-        if (want_grad ? dout > OMAX : (d->act != QN_ACT_TANH && dout > OMAX)) return false;
+        if (want_grad && dout > OMAX) return false;
     }
     if (want_grad && !pick_bwd(H, nhid, d->act, bwd_dp(din))) return false;
     if (!want_grad && !pick_fwd(H, d->act, padded_d(din), dout)) return false;

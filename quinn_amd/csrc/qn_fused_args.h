@@ -98,7 +98,7 @@ using qn_fwd_fn = void (*)(FusedArgs, const double*, const double*, const double
 using qn_bwd_f64_fn = void (*)(FusedArgs, const double*, const double*, const double*, const int32_t*, double*, double*,
                                double*, const int*, double*, double*, unsigned long long*);
 qn_bwd_f64_fn qn_fused_bwd_d8_kernel(int H, int nhid, int act, int dp);
-qn_fwd_fn qn_fused_fwd_d8_kernel(int H, int act, int dp);
+qn_fwd_fn qn_fused_fwd_d8_kernel(int H, int act, int dp, int wide_out);
 
 // sliced int8-product forward for 64-wide tanh networks (qn_fused_i8.hip): same grid, block and partial-sum
 // conventions as k_fused_fwd_f64<64, 2, tanh, DP, 256>

@@ -223,14 +223,15 @@ def test_partial_sums_add_up_to_the_sse_bit_for_bit(dims, N, B):
         assert parts.shape[1] == 8                       # cfg2: 8 row splits per chain
 
 
+@pytest.mark.parametrize("act", ["tanh", "relu", "identity"])
 @pytest.mark.parametrize("dims", [(6, 64, 64, 64, 1), (10, 32, 32, 10), (16, 16, 16), (3, 64, 64, 7), (5, 50, 40, 2),
-                                  (8, 11, 11, 11, 12)])
-def test_wide_first_and_last_layer_in_the_fused_forward(dims):
-    """Up to 16 inputs / outputs (tanh): the fused FORWARD kernel takes them (inputs / targets beyond 4 are read where
+                                  (8, 11, 11, 11, 12), (1, 32, 32, 9)])
+def test_wide_first_and_last_layer_in_the_fused_forward(dims, act):
+    """Up to 16 inputs / outputs (every activation since round 4): the fused FORWARD kernel takes them (inputs / targets beyond 4 are read where
     they are used instead of being prefetched); the gradient runs on the fused kernel up to 16 inputs and
     4 outputs (round 4), beyond that on the layer-wise kernels."""
     rs = np.random.RandomState(sum(dims))
-    arch = MLPArch(dims, "tanh")
+    arch = MLPArch(dims, act)
     N, B = 777, 4
     x, y = rs.randn(N, dims[0]), rs.randn(N, dims[-1])
     W = rs.randn(B, arch.nparams) / np.sqrt(max(dims))
