@@ -90,8 +90,8 @@ int qn_mlp_arith(const qn_desc* desc, int B, int Nb, int want_grad, int dtype);
  * products (~1e-13 relative; relu / identity: one activation scale per data row and layer, and every weight and bias below
  * 2^20, inputs below 2^100); QN_PATH_GENERIC is the all-float64 reference of that family as well.
  * Shapes of the one-launch (QN_PATH_FUSED) kernels: uniform hidden width 16 / 32 / 64 (any width <= 64 through the twin), up to
- * 4 (64-wide: 3) hidden layers in a gradient call; forward: up to 16 inputs and 16 outputs; gradient: up to 16 inputs and
- * 4 outputs.  Everything else runs layer-wise.
+ * 4 (64-wide: 3) hidden layers in a gradient call; forward and gradient: up to 16 inputs and 16 outputs (gradient of three
+ * 64-wide hidden layers: not more than 4 inputs together with more than 4 outputs).  Everything else runs layer-wise.
  * Accuracy of the int8-slice kernels: operands are rounded to 2^-47 of (1 x the weight row's maximum), the products are
  * exact -- a norm-wise bound, 47-bit against float64's 53; rows whose activations are all below ~2^-5 and chains with a
  * hidden-matrix weight >= 2^20 (or not finite) are computed in plain float64 instead.

@@ -11,9 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libquinn_amd.so")
-SOURCES = ["qn_api.hip", "qn_generic.hip", "qn_fused.hip", "qn_fused_d8.hip", "qn_fused_i8.hip", "qn_fused_bwd_i8.hip", "qn_wide_i8.hip", "qn_wide_u_i8.hip", "qn_dw_i8.hip", "qn_mcmc.hip", "qn_rnet.hip"]
+SOURCES = ["qn_api.hip", "qn_generic.hip", "qn_fused.hip", "qn_fused_d8.hip", "qn_fused_o16.hip", "qn_fused_i8.hip", "qn_fused_bwd_i8.hip", "qn_wide_i8.hip", "qn_wide_u_i8.hip", "qn_dw_i8.hip", "qn_mcmc.hip", "qn_rnet.hip"]
 # sources that #include another source (the second object of a file compiled in two parts): rebuilt when that one changes
-SOURCE_DEPS = {"qn_wide_u_i8.hip": ["qn_wide_i8.hip"], "qn_fused_d8.hip": ["qn_fused.hip"]}
+SOURCE_DEPS = {"qn_wide_u_i8.hip": ["qn_wide_i8.hip"], "qn_fused_d8.hip": ["qn_fused.hip"], "qn_fused_o16.hip": ["qn_fused.hip"]}
 
 QN_F64, QN_F32 = 0, 1
 ACT_CODES = {"identity": 0, "tanh": 1, "relu": 2}

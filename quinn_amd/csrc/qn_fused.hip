@@ -32,7 +32,8 @@
 // Compiled as two objects: part 0 (this file) holds the kernels' instances with up to 4 inputs (forward, tanh: up to 16) and all
 // the host code; part 1 (qn_fused_d8.hip: `#define QN_FUSED_PART 1` + `#include` of this file) the instances for networks with
 // 5..16 inputs -- the gradient kernel k_fused_bwd_f64<H, NH, 8 | 16, UNB> and the relu / identity forward k_fused_fwd_f64<H, G, ACT, 8 | 16>
-// (round 4; until then such gradients ran on the layer-wise kernels) -- behind two pick functions.
+// (round 4; until then such gradients ran on the layer-wise kernels) -- behind two pick functions; part 2 (qn_fused_o16.hip) the gradient
+// kernel's instances for 5..16 outputs.
 #ifndef QN_FUSED_PART
 #define QN_FUSED_PART 0
 #endif
@@ -571,8 +572,8 @@ constexpr int NHMAX = 4;
 constexpr int ROWS_IT = 64;          // rows per workgroup iteration in the backward kernel
 constexpr int NSP = ROWS_IT + 2;     // stash row stride (doubles)
 
-__host__ __device__ inline int bwd_lds_doubles(int H, int dp, int o, int nhid) {
-    return lds_doubles(H, dp, o, nhid) + 2 * H * NSP + ROWS_IT * dp + ROWS_IT * OMAX + 8;
+__host__ __device__ inline int bwd_lds_doubles(int H, int dp, int o, int nhid, int om = OMAX) {
+    return lds_doubles(H, dp, o, nhid) + 2 * H * NSP + ROWS_IT * dp + ROWS_IT * om + 8;
 }
 
 // activation of one 16x16 tile (4 values per lane); the switch is wave-uniform and sits OUTSIDE the
@@ -600,7 +601,8 @@ __device__ __forceinline__ void act_tile(const v4d& z, double (&out)[4], int act
 
 // UNB: the activation is unbounded (relu / identity): the masked rows of a ragged tail are zeroed outright (below).  A
 // template parameter, not a test of the runtime activation: the test alone cost the tanh instance 3.8 % (tools/ab_grad_mask.sh).
-template <int H, int NH, int DP, bool UNB>
+// OM: padded output count of the thin last layer (OMAX = 4; OWIDE = 16 for networks with 5..16 outputs: part 2, qn_fused_o16.hip)
+template <int H, int NH, int DP, bool UNB, int OM = OMAX>
 __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const double* __restrict__ W,
                                                          const double* __restrict__ X, const double* __restrict__ Y,
                                                          const int32_t* __restrict__ row_idx,
@@ -651,9 +653,9 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
     double* SD = SA + H * NSP;
     double* Sx = SD + H * NSP;
     double* Sdl = Sx + ROWS_IT * DP;
-    double* red = Sdl + ROWS_IT * OMAX;
-    const double* tanh_tab = lds + ((bwd_lds_doubles(H, DP, o, NH) + 1) & ~1);
-    qn_tanh_table_stage(lds + ((bwd_lds_doubles(H, DP, o, NH) + 1) & ~1), threadIdx.x, WG);   // barrier: block_or below
+    double* red = Sdl + ROWS_IT * OM;
+    const double* tanh_tab = lds + ((bwd_lds_doubles(H, DP, o, NH, OM) + 1) & ~1);
+    qn_tanh_table_stage(lds + ((bwd_lds_doubles(H, DP, o, NH, OM) + 1) & ~1), threadIdx.x, WG);   // barrier: block_or below
 
     const bool w_unbounded = block_or(stage_weights<H, DP>(lds, W + (int64_t)b * a.p, a), red + 6);
 
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
     double dbacc[NH];
 #pragma unroll
     for (int k = 0; k < NH; ++k) dbacc[k] = 0.0;
-    double dW0acc[DP], dWlacc[OMAX], dblacc[OMAX] = {0.0, 0.0, 0.0, 0.0};
+    double dW0acc[DP], dWlacc[OM], dblacc[OM] = {0.0, 0.0, 0.0, 0.0};
     // o == 1 and d == 1 (every BASELINE config): the thin layers' gradients are accumulated lane-locally in the
     // accumulator layout over all iterations and reduced across lanes / waves ONCE at the end, instead of two
     // stash round trips (4 barriers + column sums) per iteration
@@ -692,7 +694,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
     for (int k = 0; k < DP; ++k) dW0acc[k] = 0.0;
 #pragma unroll
-    for (int k = 0; k < OMAX; ++k) dWlacc[k] = 0.0;
+    for (int k = 0; k < OM; ++k) dWlacc[k] = 0.0;
 
     for (int it = 0; it < a.iters; ++it) {
         const int n = split * a.rows_per_split + it * ROWS_IT + wrow;
@@ -774,9 +776,9 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
         double (&alast)[T][4] = act[NH - 1];
         QN_STAMP(1);                                       // 1: forward layers
         // ------------------------------------------------------------------ last layer, residual
-        double delta[OMAX];
+        double delta[OM];
 #pragma unroll
-        for (int qo = 0; qo < OMAX; ++qo) {
+        for (int qo = 0; qo < OM; ++qo) {
             delta[qo] = 0.0;
             if (qo < o) {
                 double pd = 0.0;
@@ -814,27 +816,27 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
                 for (int i = 0; i < 4; ++i) SA[(16 * t + q + 4 * i) * NSP + wrow] = alast[t][i];
             if (q == 0) {
     #pragma unroll
-                for (int qo = 0; qo < OMAX; ++qo) Sdl[wrow * OMAX + qo] = delta[qo];
+                for (int qo = 0; qo < OM; ++qo) Sdl[wrow * OM + qo] = delta[qo];
     #pragma unroll
                 for (int k = 0; k < DP; ++k) Sx[wrow * DP + k] = xk[k];
             }
             __syncthreads();
             QN_STAMP(4);                                       // 4: stash write + barrier B (last stage)
             {
-                double sum[OMAX] = {0.0, 0.0, 0.0, 0.0}, sdl[OMAX] = {0.0, 0.0, 0.0, 0.0};
+                double sum[OM] = {0.0, 0.0, 0.0, 0.0}, sdl[OM] = {0.0, 0.0, 0.0, 0.0};
     #pragma unroll 4
                 for (int rr = 0; rr < RPT; ++rr) {
                     const int row = part + TPF * rr;          // interleaved rows: conflict-free Sdl / Sx reads
                     const double av = SA[fj * NSP + row];
     #pragma unroll
-                    for (int qo = 0; qo < OMAX; ++qo) {
-                        const double dv = Sdl[row * OMAX + qo];
+                    for (int qo = 0; qo < OM; ++qo) {
+                        const double dv = Sdl[row * OM + qo];
                         sum[qo] = fma(av, dv, sum[qo]);
                         sdl[qo] += dv;                        // every feature's threads see all deltas: feature 0 keeps the bias sum
                     }
                 }
     #pragma unroll
-                for (int qo = 0; qo < OMAX; ++qo) {
+                for (int qo = 0; qo < OM; ++qo) {
                     dWlacc[qo] += sum[qo];
                     dblacc[qo] += sdl[qo];
                 }
@@ -846,7 +848,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
             for (int i = 0; i < 4; ++i) dz[t][i] = 0.0;
 #pragma unroll
-        for (int qo = 0; qo < OMAX; ++qo) {
+        for (int qo = 0; qo < OM; ++qo) {
             if (qo < o) {                                  // one uniform branch per output, 16 LDS reads in flight
 #pragma unroll
                 for (int t = 0; t < T; ++t)
@@ -1014,7 +1016,7 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
 #pragma unroll
         for (int k = 0; k < DP; ++k) dW0acc[k] += __shfl_xor(dW0acc[k], m, 64);
 #pragma unroll
-        for (int k = 0; k < OMAX; ++k) {
+        for (int k = 0; k < OM; ++k) {
             dWlacc[k] += __shfl_xor(dWlacc[k], m, 64);
             dblacc[k] += __shfl_xor(dblacc[k], m, 64);
         }
@@ -1033,13 +1035,13 @@ __global__ __launch_bounds__(WG, 1) void k_fused_bwd_f64(FusedArgs a, const doub
         }
         if (!thin_fast) {
 #pragma unroll
-            for (int qo = 0; qo < OMAX; ++qo)
+            for (int qo = 0; qo < OM; ++qo)
                 if (qo < o) out[gWl + (int64_t)qo * H + fj] = dWlacc[qo];
         }
     }
     if (!thin_fast && nb && tid == 0) {
 #pragma unroll
-        for (int qo = 0; qo < OMAX; ++qo)
+        for (int qo = 0; qo < OM; ++qo)
             if (qo < o) out[gbl + qo] = dblacc[qo];
     }
     if (thin_fast) {
@@ -1157,7 +1159,21 @@ __global__ void k_sum_partials(const double* __restrict__ partial, int n, int B,
 
 constexpr int G_FWD = 2;
 
-#if QN_FUSED_PART == 1
+#if QN_FUSED_PART == 2
+}  // namespace
+
+// gradient kernel for networks with 5..16 outputs (OM = OWIDE): 4 or 16 padded input columns
+qn_bwd_f64_fn qn_fused_bwd_o16_kernel(int H, int nhid, int act, int dp) {
+#define QN_PICK(HH, NN, DD) if (H == HH && nhid == NN && dp == DD) return act == QN_ACT_TANH ? k_fused_bwd_f64<HH, NN, DD, false, OWIDE> : k_fused_bwd_f64<HH, NN, DD, true, OWIDE>;
+#define QN_PICK_D(HH, NN) QN_PICK(HH, NN, 4) QN_PICK(HH, NN, 16)
+    QN_PICK_D(16, 1) QN_PICK_D(16, 2) QN_PICK_D(16, 3) QN_PICK_D(16, 4)
+    QN_PICK_D(32, 1) QN_PICK_D(32, 2) QN_PICK_D(32, 3) QN_PICK_D(32, 4)
+    QN_PICK_D(64, 1) QN_PICK_D(64, 2) QN_PICK_D(64, 3)
+#undef QN_PICK_D
+#undef QN_PICK
+    return nullptr;
+}
+#elif QN_FUSED_PART == 1
 }  // namespace
 
 // dp = 8, 16: every (H, NH) the kernel has (no spills; the largest LDS image, 3 x 64 with 16 inputs and 4 outputs, is 158 KB)
@@ -1243,10 +1259,11 @@ void plan(const qn_desc* d, int B, int Nb, int want_grad, FusedArgs* a) {
 }
 
 constexpr int DBWD = 16;                                   // inputs of the gradient kernel: DP = 4 (part 0), 8 or 16 (part 1)
-inline int bwd_dp(int d) { return d <= DMAX ? DMAX : d <= 8 ? 8 : 16; }
+inline int bwd_dp(int d, int o = 1) { return o > OMAX ? (d <= DMAX ? DMAX : 16) : (d <= DMAX ? DMAX : d <= 8 ? 8 : 16); }   // (5..16 outputs: 4 or 16 columns)
+inline int bwd_om(int o) { return o > OMAX ? OWIDE : OMAX; }
 size_t lds_need(int H, int d, int o, int nhid, int want_grad) {
     if (H == HS) return sizeof(double) * (size_t)(stream_lds_doubles(padded_d(d), o, nhid) + 2);
-    return sizeof(double) * (size_t)((want_grad ? bwd_lds_doubles(H, bwd_dp(d), o, nhid) : lds_doubles(H, padded_d(d), o, nhid)) +
+    return sizeof(double) * (size_t)((want_grad ? bwd_lds_doubles(H, bwd_dp(d, o), o, nhid, bwd_om(o)) : lds_doubles(H, padded_d(d), o, nhid)) +
                                      2 + TANH_TAB);
 }
 
@@ -1286,7 +1303,8 @@ fwd_fn pick_fwd(int H, int act, int dp, int o) {
     return nullptr;
 }
 
-bwd_fn pick_bwd(int H, int nhid, int act = QN_ACT_TANH, int dp = DMAX) {
+bwd_fn pick_bwd(int H, int nhid, int act = QN_ACT_TANH, int dp = DMAX, int om = OMAX) {
+    if (om != OMAX) return qn_fused_bwd_o16_kernel(H, nhid, act, dp);
     if (dp != DMAX) return qn_fused_bwd_d8_kernel(H, nhid, act, dp);
 #define QN_PICK(HH, NN) if (H == HH && nhid == NN) return act == QN_ACT_TANH ? k_fused_bwd_f64<HH, NN, 4, false> : k_fused_bwd_f64<HH, NN, 4, true>;
     QN_PICK(16, 1) QN_PICK(16, 2) QN_PICK(16, 3) QN_PICK(16, 4)
@@ -1326,11 +1344,10 @@ bool qn_fused_supported(const qn_desc* d, int B, int Nb, int want_grad, int dtyp
     if (H != 16 && H != 32 && H != 64 && H != HS) return false;
     const int din = d->dims[0], dout = d->dims[d->nlayers];
     if (din > DMAX || dout > OMAX) {
-        // wide first / last layer, hidden width <= 64.  Forward: up to 16 inputs and 16 outputs.  Gradient: up to 16 inputs and 4 outputs.
+        // wide first / last layer, hidden width <= 64: up to 16 inputs and 16 outputs, forward and gradient
         if (H == HS || din > DWIDE || dout > OWIDE) return false;
-        if (want_grad && dout > OMAX) return false;
     }
-    if (want_grad && !pick_bwd(H, nhid, d->act, bwd_dp(din))) return false;
+    if (want_grad && !pick_bwd(H, nhid, d->act, bwd_dp(din, dout), bwd_om(dout))) return false;
     if (!want_grad && !pick_fwd(H, d->act, padded_d(din), dout)) return false;
     return lds_need(H, d->dims[0], d->dims[d->nlayers], nhid, want_grad) <= 160 * 1024;
 }
@@ -1400,7 +1417,7 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
         hipLaunchKernelGGL(kern, grid, dim3(H == HS ? NTS : WG), lds_bytes, st, a, (const double*)W,
                            (const double*)X, (const double*)Y, row_idx, (double*)pred, partial, arrive, sse);
     } else {
-        bwd_fn kern = pick_bwd(H, nhid, d->act, bwd_dp(a.d));
+        bwd_fn kern = pick_bwd(H, nhid, d->act, bwd_dp(a.d, a.o), bwd_om(a.o));
         if (!kern) {
             qn_set_error("qn_fused_run: no backward kernel instance for H=%d nhid=%d", H, nhid);
             return QN_EUNSUPPORTED;
@@ -1440,4 +1457,4 @@ int qn_fused_run(const qn_desc* d, int dtype, const void* W, const void* X, cons
     QN_HIP_CHECK(hipGetLastError());
     return QN_OK;
 }
-#endif  // QN_FUSED_PART != 1
+#endif  // QN_FUSED_PART == 0

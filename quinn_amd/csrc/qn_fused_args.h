@@ -99,6 +99,8 @@ using qn_bwd_f64_fn = void (*)(FusedArgs, const double*, const double*, const do
                                double*, const int*, double*, double*, unsigned long long*);
 qn_bwd_f64_fn qn_fused_bwd_d8_kernel(int H, int nhid, int act, int dp);
 qn_fwd_fn qn_fused_fwd_d8_kernel(int H, int act, int dp, int wide_out);
+// the gradient kernel for networks with 5..16 outputs (qn_fused_o16.hip, the third object): dp = 4 or 16
+qn_bwd_f64_fn qn_fused_bwd_o16_kernel(int H, int nhid, int act, int dp);
 
 // sliced int8-product forward for 64-wide tanh networks (qn_fused_i8.hip): same grid, block and partial-sum
 // conventions as k_fused_fwd_f64<64, 2, tanh, DP, 256>

@@ -229,7 +229,7 @@ def test_partial_sums_add_up_to_the_sse_bit_for_bit(dims, N, B):
 def test_wide_first_and_last_layer_in_the_fused_forward(dims, act):
     """Up to 16 inputs / outputs (every activation since round 4): the fused FORWARD kernel takes them (inputs / targets beyond 4 are read where
     they are used instead of being prefetched); the gradient runs on the fused kernel up to 16 inputs and
-    4 outputs (round 4), beyond that on the layer-wise kernels."""
+    16 outputs as well (round 4), beyond that on the layer-wise kernels."""
     rs = np.random.RandomState(sum(dims))
     arch = MLPArch(dims, act)
     N, B = 777, 4
@@ -237,7 +237,7 @@ def test_wide_first_and_last_layer_in_the_fused_forward(dims, act):
     W = rs.randn(B, arch.nparams) / np.sqrt(max(dims))
     idx = rs.randint(0, N, size=(B, 300))
     op = BatchedMLP(arch, x, y)
-    grad_fused = dims[-1] <= 4 and dims[0] <= 16
+    grad_fused = True                                # (up to 16 inputs and 16 outputs since round 4)
     assert op.path(B, N, False) == _lib.PATH_FUSED and op.path(B, N, True) == (_lib.PATH_FUSED if grad_fused else _lib.PATH_GENERIC)
     L = _lib.lib()
     res = {}
@@ -280,12 +280,19 @@ def _d8_cases():
             d, o = int(rs.randint(9, 17)), int(rs.randint(1, 5))
             out.append(((d,) + (H,) * NH + (o,), act, bool(rs.rand() < 0.8), int(rs.choice([1, 63, 64, 65, 200, 513])),
                         int(rs.randint(1, 7)), bool(rs.rand() < 0.4)))
+    # 5..16 outputs: the gradient kernel's OM = 16 instances (4 or 16 input columns)
+    for H, NH in [(16, 1), (16, 2), (16, 3), (16, 4), (32, 1), (32, 2), (32, 3), (32, 4), (64, 1), (64, 2), (64, 3), (11, 2), (40, 2)]:
+        for act in ("tanh", "relu", "identity"):
+            d = int(rs.choice([1, 2, 4, 7, 12, 16])) if (H, NH) != (64, 3) else int(rs.choice([1, 2, 4]))   # (3 x 64 with 16 x 16: over the LDS)
+            o = int(rs.randint(5, 17))
+            out.append(((d,) + (H,) * NH + (o,), act, bool(rs.rand() < 0.8), int(rs.choice([1, 63, 64, 65, 200, 513])),
+                        int(rs.randint(1, 7)), bool(rs.rand() < 0.4)))
     return out
 
 
 @pytest.mark.parametrize("case", _d8_cases(), ids=lambda c: f"{c[0]}-{c[1]}-b{int(c[2])}-N{c[3]}-B{c[4]}-idx{int(c[5])}")
 def test_five_to_eight_inputs_on_the_fused_kernels(case):
-    """Networks with 5..16 inputs and up to 4 outputs: gradient and forward of every activation
+    """Networks with 5..16 inputs or 5..16 outputs: gradient and forward of every activation
     run on the fused float64-MFMA kernels (k_fused_bwd_f64<H, NH, 8 | 16, UNB>, k_fused_fwd_f64<.., 8 | 16>; qn_fused_d8.hip) and
     agree with the layer-wise kernels."""
     dims, act, bias, N, B, use_idx = case

@@ -76,6 +76,9 @@ CASES = [  # dims, activ, bias, N, B
     ((12, 32, 32, 1), "tanh", True, 150, 3),         # 9..16 inputs: DP = 16 instances
     ((16, 16, 16, 16, 2), "relu", True, 77, 2),
     ((10, 64, 64, 64, 1), "relu", True, 100, 2),
+    ((3, 32, 32, 8), "tanh", True, 120, 3),          # 5..16 outputs: the gradient kernel's OM = 16 instances (qn_fused_o16.hip)
+    ((12, 16, 16, 16, 16), "relu", True, 90, 2),
+    ((2, 64, 64, 6), "identity", True, 70, 2),
 ]
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Networks with 5..16 inputs: gradient and forward launch times on the layer-wise kernels (QN_PATH_GENERIC: where such gradients ran
+"""Networks with 5..16 inputs or outputs: gradient and forward launch times on the layer-wise kernels (QN_PATH_GENERIC: where such gradients ran
 until round 4) against the default dispatch (the fused float64-MFMA kernels' DP = 8 instances, qn_fused_d8.hip)."""
 import os, sys, time
 import numpy as np, torch
@@ -21,9 +21,10 @@ def rate(f):
 
 for dims, act, N, B in (((6, 64, 64, 64, 1), "tanh", 4096, 64), ((8, 64, 64, 64, 1), "relu", 4096, 64), ((5, 32, 32, 1), "tanh", 4096, 64),
                         ((8, 16, 16, 1), "tanh", 256, 64), ((6, 11, 11, 11, 1), "tanh", 1000, 256), ((12, 32, 32, 1), "tanh", 4096, 64),
-                        ((16, 20, 20, 20, 1), "relu", 1000, 256), ((10, 64, 64, 64, 1), "relu", 4096, 64), ((12, 64, 64, 1), "tanh", 4096, 64)):
+                        ((16, 20, 20, 20, 1), "relu", 1000, 256), ((10, 64, 64, 64, 1), "relu", 4096, 64), ((12, 64, 64, 1), "tanh", 4096, 64), ((2, 32, 32, 8), "tanh", 4096, 64),
+                        ((8, 20, 20, 10), "relu", 1000, 256), ((1, 64, 64, 64, 6), "tanh", 4096, 64), ((10, 64, 64, 12), "relu", 4096, 64)):
     arch = MLPArch(dims, act); rs = np.random.RandomState(0)
-    x = rs.rand(N, dims[0]) * 6 - 3; y = np.sin(x).sum(axis=1, keepdims=True)
+    x = rs.rand(N, dims[0]) * 6 - 3; y = np.sin(x).sum(axis=1, keepdims=True) * np.ones((1, dims[-1]))
     op = BatchedMLP(arch, x, y); W = op.weights(0.3 * rs.randn(B, arch.nparams))
     res = {}
     for name, path in (("layerwise", _lib.PATH_GENERIC), ("default", _lib.PATH_AUTO)):
