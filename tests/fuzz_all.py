@@ -40,7 +40,7 @@ def run(ncases=100, seed=0, verbose=True):
             hid = (int(rs.choice([3, 17, 32, 64, 64, 65, 100, 128, 200, 256])),) * nhid
         else:
             hid = tuple(int(v) for v in rs.randint(1, 90, size=nhid))
-        d = int(rs.choice([1, 1, 2, 3, 4, 5, 8, 16])); o = int(rs.choice([1, 1, 1, 2, 3, 4]))
+        d = int(rs.choice([1, 1, 2, 3, 4, 5, 8, 16])); o = int(rs.choice([1, 1, 1, 2, 3, 4, 6, 12]))
         act = str(rs.choice(sorted(_lib.ACT_CODES))); bias = bool(rs.rand() < 0.75)
         N = int(rs.choice([rs.randint(1, 40), rs.randint(40, 700)])); B = int(rs.choice([1, 2, rs.randint(3, 13)]))
         if max(hid) > 128: N = min(N, 200)
@@ -236,7 +236,7 @@ def _run_exceptional(ncases, seed, verbose, paths):
             spec, arch, _ = _random_rnet(rs)
             dims, act, bias, d, o, h = spec, spec.activ, spec.bias, spec.d, spec.o, spec.rdim
         else:
-            h = int(rs.choice([8, 33, 64, 64, 128, 256])); nhid = int(rs.randint(1, 5)); d = int(rs.choice([1, 2, 4, 6])); o = int(rs.choice([1, 1, 2]))
+            h = int(rs.choice([8, 33, 64, 64, 128, 256])); nhid = int(rs.randint(1, 5)); d = int(rs.choice([1, 2, 4, 6, 12])); o = int(rs.choice([1, 1, 2, 7]))
             act = str(rs.choice(["tanh", "tanh", "relu", "identity"])); bias = bool(rs.rand() < 0.8)
             dims = (d,) + (h,) * nhid + (o,)
             arch = MLPArch(dims, act, bias=bias)
@@ -275,7 +275,17 @@ def _run_exceptional(ncases, seed, verbose, paths):
                     for b in range(B):                          # per vector: a huge vector must not hide the others
                         fb = np.isfinite(v[b])
                         if np.any(fb) and np.abs(u[b][fb] - v[b][fb]).max() > tol * max(np.abs(v[b][fb]).max(), 1e-300):
-                            ok = False; why += " %s:val(%s[%d] %.1e)" % (pname, name, b, np.abs(u[b][fb] - v[b][fb]).max() / max(np.abs(v[b][fb]).max(), 1e-300))
+                            err = np.abs(u[b][fb] - v[b][fb]).max() / max(np.abs(v[b][fb]).max(), 1e-300)
+                            # beyond the fixed bar: as in run(), an all-finite chain's own one-ulp sensitivity decides (a deep bias-free
+                            # linear network whose last dot product cancels to 1e-4 of its terms moves by 4e-13 per ulp: round 4,
+                            # seed 61).  Its own generator: the case stream does not depend on which chains needed it.
+                            if not isinstance(spec, mlp_ref.MLPSpec) or not (np.all(np.isfinite(ref[0][b])) and np.all(np.isfinite(ref[1][b])) and np.all(np.isfinite(ref[2][b])) and np.all(np.isfinite(W[b]))):
+                                floor = 0.0
+                            else:
+                                sens = _sensitivity(mod, W[b], x, y, np.random.RandomState(977 + b))
+                                floor = K_SLICED * sens[{"sse": 0, "sse2": 0, "grad": 1, "pred": 2}[name]]
+                            if err > max(tol, floor):
+                                ok = False; why += " %s:val(%s[%d] %.1e, floor %.1e)" % (pname, name, b, err, floor)
         op.set_path(_lib.PATH_AUTO)
         nfail += not ok
         if verbose or not ok:
