@@ -282,8 +282,14 @@ def main():
         # stdout carries the ONE JSON line and nothing else
         import ctypes
         sys.stdout.flush()
-        saved_out = os.dup(1)
-        os.dup2(2, 1)
+        saved_out = None
+        try:
+            saved_out = os.dup(1)
+            os.dup2(2, 1)
+        except OSError:                                      # (no usable fd 1 / fd 2: leave stdout alone)
+            if saved_out is not None:
+                os.close(saved_out)
+            saved_out = None
         try:
             if backend == "nccl":
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -305,8 +311,9 @@ def main():
                 ctypes.CDLL(None).fflush(None)                   # (the C library's buffered stdout, while it still goes to stderr)
             except Exception:  # noqa: BLE001
                 pass
-            os.dup2(saved_out, 1)
-            os.close(saved_out)
+            if saved_out is not None:
+                os.dup2(saved_out, 1)
+                os.close(saved_out)
 
     from quinn_amd.parallel import shard_bounds
     # this rank's chains [lo, hi) of the job's `total`; global chain id c: W[c] = 0.1*RandomState(1000+c).randn(p)
